@@ -1,0 +1,471 @@
+// bayesnmf_amd/csrc/api.hip — C ABI of libbnmf.so (include/bnmf.h) over the gfx950 kernels.
+// Host side: device memory, one HIP stream per handle, launch sequencing of the sweep
+// (R/bayesNMF_sampler.R:273-285) and of the constructor draws (:232-257).  There is no CPU path.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "kernels.h"
+
+using namespace bnmf;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+  return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(BNMF_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+enum { KN_PSIDE = 0, KN_ESIDE = 1, KN_ZALLOC = 2, KN_FINALIZE = 3, KN_RANK = 4, KN_MH_P = 5, KN_MH_E = 6, KN_OTHER = 7 };
+static const char* k_names[BNMF_NKERNEL] = {"k_pside", "k_eside", "k_zalloc", "k_finalize", "k_rank", "k_mh_p", "k_mh_e", "other"};
+
+struct Arr { double* d = nullptr; size_t n = 0; int stride = 1; bool set = false; std::vector<int> redraw; };
+
+struct bnmf_handle {
+  bnmf_config cfg{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int iter = 0;
+  bool inited = false;
+  Dev dev{};
+  Arr arr[BNMF_ID_MAX];
+  int32_t *dM = nullptr, *dZsumK = nullptr, *dZsumG = nullptr, *dZ = nullptr;
+  int* dR = nullptr; int* dRedraw = nullptr;
+  double *dEsum = nullptr, *dPsum = nullptr, *dlpPn = nullptr, *dlpE = nullptr, *dcol = nullptr;
+  double *dLut = nullptr, *dTemp = nullptr, *dMetrics = nullptr;
+  size_t metrics_rows = 0;
+  int maxM = 0, nblkE = 0;
+  int z_grid = 0, z_NP = 0, z_CB = 1; size_t z_lds = 0;
+  hipEvent_t ev[2 * BNMF_NKERNEL]{};
+  bool have_ev = false;
+};
+
+static size_t id_len(const bnmf_handle* h, int id) {
+  const size_t K = h->cfg.K, G = h->cfg.G, N = h->cfg.N;
+  switch (id) {
+    case BNMF_P: case BNMF_ZSUMG: case BNMF_ALPHA_P: case BNMF_BETA_P: case BNMF_MU_P: case BNMF_SIGMASQ_P:
+    case BNMF_LAMBDA_P: case BNMF_HA_P: case BNMF_HB_P: case BNMF_HC_P: case BNMF_HD_P: case BNMF_HM_P:
+    case BNMF_HS_P: case BNMF_ACC_P: return K * N;
+    case BNMF_E: case BNMF_ZSUMK: case BNMF_ALPHA_E: case BNMF_BETA_E: case BNMF_MU_E: case BNMF_SIGMASQ_E:
+    case BNMF_LAMBDA_E: case BNMF_HA_E: case BNMF_HB_E: case BNMF_HC_E: case BNMF_HD_E: case BNMF_HM_E:
+    case BNMF_HS_E: case BNMF_ACC_E: return N * G;
+    case BNMF_A: return N;
+    case BNMF_R: return 1;
+    case BNMF_Z: return K * N * G;
+    case BNMF_SIGMASQ: case BNMF_ALPHA: case BNMF_BETA: return G;
+    case BNMF_MHAT: return K * G;
+    default: return 0;
+  }
+}
+static bool is_hyper(int id) { return id >= 30 && id < 50; }
+static bool is_pside(int id) { size_t dummy = 0; (void)dummy; return id == BNMF_P || id == BNMF_ALPHA_P || id == BNMF_BETA_P || id == BNMF_MU_P || id == BNMF_SIGMASQ_P || id == BNMF_LAMBDA_P; }
+
+static int ensure(bnmf_handle* h, int id) {
+  Arr& a = h->arr[id];
+  if (a.d) return 0;
+  const size_t n = id_len(h, id);
+  HIPCHK(hipMalloc(&a.d, n * sizeof(double)));
+  std::vector<double> nan(n, std::nan(""));
+  HIPCHK(hipMemcpy(a.d, nan.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  a.n = n; a.stride = 1;
+  return 0;
+}
+
+static void refresh_dev(bnmf_handle* h) {
+  Dev& d = h->dev;
+  const bnmf_config& c = h->cfg;
+  d.K = c.K; d.G = c.G; d.N = c.N;
+  d.prior = c.prior; d.likelihood = c.likelihood; d.MH = c.MH; d.learning_rank = c.learning_rank;
+  d.rank_method = c.rank_method; d.save_Z = c.save_Z;
+  d.k0 = (uint32_t)c.seed; d.k1 = (uint32_t)(c.seed >> 32) ^ c.chain_id;
+  d.maxM = h->maxM;
+  d.M = h->dM; d.R = h->dR;
+  d.P = h->arr[BNMF_P].d; d.E = h->arr[BNMF_E].d; d.A = h->arr[BNMF_A].d;
+  d.ZsumK = h->dZsumK; d.ZsumG = h->dZsumG; d.Z = h->dZ;
+  d.Alpha_p = h->arr[BNMF_ALPHA_P].d; d.Beta_p = h->arr[BNMF_BETA_P].d;
+  d.Alpha_e = h->arr[BNMF_ALPHA_E].d; d.Beta_e = h->arr[BNMF_BETA_E].d;
+  d.Mu_p = h->arr[BNMF_MU_P].d; d.Sig_p = h->arr[BNMF_SIGMASQ_P].d;
+  d.Mu_e = h->arr[BNMF_MU_E].d; d.Sig_e = h->arr[BNMF_SIGMASQ_E].d;
+  d.Lam_p = h->arr[BNMF_LAMBDA_P].d; d.Lam_e = h->arr[BNMF_LAMBDA_E].d;
+  auto hr = [&](int id) { return HRef{h->arr[id].d, h->arr[id].stride}; };
+  d.hA_p = hr(BNMF_HA_P); d.hB_p = hr(BNMF_HB_P); d.hC_p = hr(BNMF_HC_P); d.hD_p = hr(BNMF_HD_P);
+  d.hM_p = hr(BNMF_HM_P); d.hS_p = hr(BNMF_HS_P);
+  d.hA_e = hr(BNMF_HA_E); d.hB_e = hr(BNMF_HB_E); d.hC_e = hr(BNMF_HC_E); d.hD_e = hr(BNMF_HD_E);
+  d.hM_e = hr(BNMF_HM_E); d.hS_e = hr(BNMF_HS_E);
+  d.Esum = h->dEsum; d.Psum = h->dPsum; d.lpPn = h->dlpPn; d.lpE_part = h->dlpE;
+  d.colsse = h->dcol; d.colll = h->dcol + c.G; d.colkl = h->dcol + 2 * (size_t)c.G;
+  d.lgfact = h->dLut; d.logm = h->dLut + (h->maxM + 1);
+  d.temperature = h->dTemp; d.n_temperature = c.n_temperature;
+  d.metrics = h->dMetrics;
+}
+
+extern "C" {
+
+int bnmf_version(void) { return BNMF_VERSION; }
+const char* bnmf_last_error(void) { return g_err; }
+const char* bnmf_kernel_name(int i) { return (i >= 0 && i < BNMF_NKERNEL) ? k_names[i] : ""; }
+
+int bnmf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+int bnmf_device_info(int device, char* buf, size_t buflen) {
+  hipDeviceProp_t p;
+  HIPCHK(hipGetDeviceProperties(&p, device));
+  snprintf(buf, buflen, "%s arch=%s CUs=%d clock=%dMHz mem=%.1fGiB lds/block=%zu",
+           p.name, p.gcnArchName, p.multiProcessorCount, p.clockRate / 1000,
+           (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), (size_t)p.sharedMemPerBlock);
+  return 0;
+}
+
+int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
+  if (!cfg || !M || !out) return fail(BNMF_EINVAL, "bnmf_create: null argument");
+  if (cfg->K < 1 || cfg->G < 1 || cfg->N < 1) return fail(BNMF_EINVAL, "bnmf_create: dims must be positive");
+  if (cfg->N > 1024) return fail(BNMF_EINVAL, "bnmf_create: N > 1024 unsupported");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(BNMF_ENODEVICE, "bnmf_create: no HIP device visible (libbnmf has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(BNMF_ENODEVICE, "bnmf_create: device %d out of range (%d visible)", cfg->device, ndev);
+  // model check: check_model R/bayesNMF_sampler.R:623-645
+  if (cfg->likelihood == BNMF_NORMAL) {
+    if (cfg->prior == BNMF_GAMMA) return fail(BNMF_EMODEL, "prior must be one of c('truncnormal','exponential') with `likelihood = 'normal'`");
+  } else if (cfg->likelihood == BNMF_POISSON) {
+    if (cfg->prior == BNMF_GAMMA && cfg->MH) return fail(BNMF_EMODEL, "gamma prior cannot be used in a MH-within-gibbs sampler");
+    if (cfg->prior == BNMF_TRUNCNORMAL && !cfg->MH) return fail(BNMF_EMODEL, "truncnormal prior can only be used in a MH-within-gibbs sampler");
+  } else return fail(BNMF_EMODEL, "likelihood must be one of normal, poisson");
+  HIPCHK(hipSetDevice(cfg->device));
+  bnmf_handle* h = new bnmf_handle();
+  h->cfg = *cfg;
+  h->device = cfg->device;
+  const size_t K = cfg->K, G = cfg->G, N = cfg->N;
+  HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIPCHK(hipMalloc(&h->dM, K * G * sizeof(int32_t)));
+  HIPCHK(hipMemcpy(h->dM, M, K * G * sizeof(int32_t), hipMemcpyHostToDevice));
+  int mx = 0;
+  for (size_t i = 0; i < K * G; ++i) { if (M[i] < 0) { delete h; return fail(BNMF_EINVAL, "bnmf_create: negative count in M"); } if (M[i] > mx) mx = M[i]; }
+  h->maxM = mx;
+  HIPCHK(hipMalloc(&h->dZsumK, N * G * sizeof(int32_t)));
+  HIPCHK(hipMalloc(&h->dZsumG, K * N * sizeof(int32_t)));
+  HIPCHK(hipMemset(h->dZsumK, 0, N * G * sizeof(int32_t)));
+  HIPCHK(hipMemset(h->dZsumG, 0, K * N * sizeof(int32_t)));
+  if (cfg->save_Z) HIPCHK(hipMalloc(&h->dZ, K * N * G * sizeof(int32_t)));
+  HIPCHK(hipMalloc(&h->dR, sizeof(int)));
+  int Rinit = (int)N;
+  HIPCHK(hipMemcpy(h->dR, &Rinit, sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&h->dRedraw, N * sizeof(int)));
+  HIPCHK(hipMalloc(&h->dEsum, N * sizeof(double)));
+  HIPCHK(hipMalloc(&h->dPsum, N * sizeof(double)));
+  HIPCHK(hipMalloc(&h->dlpPn, N * sizeof(double)));
+  h->nblkE = (int)((N * G + ES_T - 1) / ES_T);
+  HIPCHK(hipMalloc(&h->dlpE, h->nblkE * sizeof(double)));
+  HIPCHK(hipMalloc(&h->dcol, 3 * G * sizeof(double)));
+  HIPCHK(hipMalloc(&h->dLut, 2 * (size_t)(mx + 1) * sizeof(double)));
+  if (cfg->n_temperature > 0 && cfg->temperature) {
+    HIPCHK(hipMalloc(&h->dTemp, cfg->n_temperature * sizeof(double)));
+    HIPCHK(hipMemcpy(h->dTemp, cfg->temperature, cfg->n_temperature * sizeof(double), hipMemcpyHostToDevice));
+  } else h->cfg.n_temperature = 0;
+  h->cfg.temperature = nullptr;
+  h->metrics_rows = 1024;
+  HIPCHK(hipMalloc(&h->dMetrics, h->metrics_rows * BNMF_NMETRIC * sizeof(double)));
+  hipLaunchKernelGGL(k_luts, dim3((mx + 256) / 256), dim3(256), 0, h->stream, h->dLut, h->dLut + (mx + 1), mx);
+  HIPCHK(hipGetLastError());
+  // k_zalloc geometry: CB columns per pass so that K*CB <= 256 cells; odd row pitch NP
+  if (K > 256) { delete h; return fail(BNMF_EINVAL, "bnmf_create: K > 256 not supported yet by k_zalloc"); }
+  h->z_CB = (int)(256 / K); if (h->z_CB < 1) h->z_CB = 1; if (h->z_CB > 4) h->z_CB = 4;
+  h->z_NP = (int)(N | 1);
+  const size_t ncell = K * h->z_CB;
+  h->z_lds = ncell * h->z_NP * 4 * (cfg->save_Z ? 3 : 2) + 3 * ZT * 8 + (ZT + 4 + ZT + ZT + h->z_CB * N + 4) * 4;
+  h->z_lds = (h->z_lds + 15) & ~(size_t)15;
+  if (h->z_lds > 160 * 1024) { delete h; return fail(BNMF_EINVAL, "bnmf_create: K*N too large for k_zalloc LDS (%zu B)", h->z_lds); }
+  if (h->z_lds > 64 * 1024) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_zalloc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->z_lds));
+    HIPCHK(hipFuncSetAttribute((const void*)k_zalloc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->z_lds));
+  }
+  const int npass = (int)((G + h->z_CB - 1) / h->z_CB);
+  h->z_grid = npass < 2048 ? npass : 2048;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  refresh_dev(h);
+  *out = h;
+  return 0;
+}
+
+int bnmf_destroy(bnmf_handle* h) {
+  if (!h) return 0;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  for (auto& a : h->arr) if (a.d) hipFree(a.d);
+  hipFree(h->dM); hipFree(h->dZsumK); hipFree(h->dZsumG); if (h->dZ) hipFree(h->dZ);
+  hipFree(h->dR); hipFree(h->dRedraw); hipFree(h->dEsum); hipFree(h->dPsum); hipFree(h->dlpPn);
+  hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics);
+  if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+int bnmf_set_array(bnmf_handle* h, int id, const double* x, size_t n) {
+  if (!h || !x) return fail(BNMF_EINVAL, "bnmf_set_array: null argument");
+  const size_t len = id_len(h, id);
+  if (len == 0) return fail(BNMF_EINVAL, "bnmf_set_array: unknown id %d", id);
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (id == BNMF_R) { int r = (int)x[0]; HIPCHK(hipMemcpy(h->dR, &r, sizeof(int), hipMemcpyHostToDevice)); h->arr[BNMF_R].set = true; return 0; }
+  if (id == BNMF_ZSUMK || id == BNMF_ZSUMG || id == BNMF_Z) {
+    int32_t* dst = id == BNMF_ZSUMK ? h->dZsumK : id == BNMF_ZSUMG ? h->dZsumG : h->dZ;
+    if (!dst) return fail(BNMF_EUNSET, "bnmf_set_array: Z is not materialised (save_Z = 0)");
+    if (n != len) return fail(BNMF_ESIZE, "bnmf_set_array: id %d expects %zu values, got %zu", id, len, n);
+    std::vector<int32_t> tmp(n);
+    for (size_t i = 0; i < n; ++i) tmp[i] = (int32_t)x[i];
+    HIPCHK(hipMemcpy(dst, tmp.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    return 0;
+  }
+  Arr& a = h->arr[id];
+  if (is_hyper(id) && n == 1) {
+    if (a.d) { HIPCHK(hipFree(a.d)); a.d = nullptr; }
+    HIPCHK(hipMalloc(&a.d, sizeof(double)));
+    HIPCHK(hipMemcpy(a.d, x, sizeof(double), hipMemcpyHostToDevice));
+    a.n = 1; a.stride = 0; a.set = true;
+    refresh_dev(h);
+    return 0;
+  }
+  if (n != len) return fail(BNMF_ESIZE, "bnmf_set_array: id %d expects %zu values, got %zu", id, len, n);
+  if (a.d && a.n != len) { HIPCHK(hipFree(a.d)); a.d = nullptr; }
+  if (!a.d) HIPCHK(hipMalloc(&a.d, len * sizeof(double)));
+  HIPCHK(hipMemcpy(a.d, x, len * sizeof(double), hipMemcpyHostToDevice));
+  a.n = len; a.stride = 1; a.set = true;
+  // which columns n (P side) / rows n (E side) carry a missing (NaN) entry
+  if (!is_hyper(id) && len >= (size_t)h->cfg.N && id != BNMF_A && id < 30) {
+    const size_t K = h->cfg.K, N = h->cfg.N;
+    a.redraw.assign(N, 0);
+    const bool ps = is_pside(id);
+    for (size_t i = 0; i < len; ++i) if (x[i] != x[i]) a.redraw[ps ? i / K : i % N] = 1;
+  }
+  refresh_dev(h);
+  return 0;
+}
+
+int bnmf_get_array(bnmf_handle* h, int id, double* out, size_t n) {
+  if (!h || !out) return fail(BNMF_EINVAL, "bnmf_get_array: null argument");
+  const size_t len = id_len(h, id);
+  if (len == 0 || n != len) return fail(BNMF_ESIZE, "bnmf_get_array: id %d expects %zu values, got %zu", id, len, n);
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (id == BNMF_R) { int r; HIPCHK(hipMemcpy(&r, h->dR, sizeof(int), hipMemcpyDeviceToHost)); out[0] = r; return 0; }
+  if (id == BNMF_ZSUMK || id == BNMF_ZSUMG || id == BNMF_Z) {
+    const int32_t* src = id == BNMF_ZSUMK ? h->dZsumK : id == BNMF_ZSUMG ? h->dZsumG : h->dZ;
+    if (!src) return fail(BNMF_EUNSET, "bnmf_get_array: Z is not materialised (save_Z = 0)");
+    std::vector<int32_t> tmp(n);
+    HIPCHK(hipMemcpy(tmp.data(), src, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) out[i] = tmp[i];
+    return 0;
+  }
+  const Arr& a = h->arr[id];
+  if (!a.d) return fail(BNMF_EUNSET, "bnmf_get_array: id %d has no value", id);
+  if (a.stride == 0) { double v; HIPCHK(hipMemcpy(&v, a.d, sizeof(double), hipMemcpyDeviceToHost)); for (size_t i = 0; i < n; ++i) out[i] = v; return 0; }
+  HIPCHK(hipMemcpy(out, a.d, n * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int bnmf_get_array_i32(bnmf_handle* h, int id, int32_t* out, size_t n) {
+  if (!h || !out) return fail(BNMF_EINVAL, "bnmf_get_array_i32: null argument");
+  const size_t len = id_len(h, id);
+  const int32_t* src = id == BNMF_ZSUMK ? h->dZsumK : id == BNMF_ZSUMG ? h->dZsumG : id == BNMF_Z ? h->dZ : nullptr;
+  if (!(id == BNMF_ZSUMK || id == BNMF_ZSUMG || id == BNMF_Z)) return fail(BNMF_EINVAL, "bnmf_get_array_i32: id %d is not an integer array", id);
+  if (!src) return fail(BNMF_EUNSET, "bnmf_get_array_i32: Z is not materialised (save_Z = 0)");
+  if (n != len) return fail(BNMF_ESIZE, "bnmf_get_array_i32: id %d expects %zu values, got %zu", id, len, n);
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(out, src, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int bnmf_get_iter(bnmf_handle* h, int* iter) { if (!h || !iter) return fail(BNMF_EINVAL, "null"); *iter = h->iter; return 0; }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ launch helpers
+static int check_model_supported(const bnmf_handle* h) {
+  const bnmf_config& c = h->cfg;
+  if (c.likelihood != BNMF_POISSON || c.MH) return fail(BNMF_EMODEL, "this build implements the Poisson models without MH (gamma / exponential prior)");
+  if (c.learning_rank) return fail(BNMF_EMODEL, "learned rank is not implemented in this build yet");
+  return 0;
+}
+static int need_hyper(bnmf_handle* h, std::initializer_list<int> ids) {
+  for (int id : ids) if (!h->arr[id].d) return fail(BNMF_EUNSET, "hyper-prior array id %d was not set (fill_hyperprior_params, R/setup.R:15-88)", id);
+  return 0;
+}
+static int ensure_metrics(bnmf_handle* h, size_t rows) {
+  if (rows <= h->metrics_rows) return 0;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipFree(h->dMetrics));
+  h->metrics_rows = rows;
+  HIPCHK(hipMalloc(&h->dMetrics, rows * BNMF_NMETRIC * sizeof(double)));
+  refresh_dev(h);
+  return 0;
+}
+struct Timer {   // optional per-kernel HIP-event bracketing on the handle's own stream
+  bnmf_handle* h; bool on; double acc[BNMF_NKERNEL]{}; int cnt[BNMF_NKERNEL]{};
+  void begin(int k) { if (on) hipEventRecord(h->ev[2 * k], h->stream); }
+  void end(int k) { if (on) { hipEventRecord(h->ev[2 * k + 1], h->stream); hipEventSynchronize(h->ev[2 * k + 1]); float ms = 0; hipEventElapsedTime(&ms, h->ev[2 * k], h->ev[2 * k + 1]); acc[k] += ms; cnt[k]++; } }
+};
+static void launch_pside(bnmf_handle* h, uint32_t t, int from_prior, int do_hyper) {
+  const size_t lds = (PS_T + 2 + 2 * (size_t)h->cfg.K) * sizeof(double);
+  hipLaunchKernelGGL(k_pside, dim3(h->cfg.N), dim3(PS_T), lds, h->stream, h->dev, t, from_prior, do_hyper);
+}
+static void launch_eside(bnmf_handle* h, uint32_t t, int from_prior, int do_hyper) {
+  hipLaunchKernelGGL(k_eside, dim3(h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, from_prior, do_hyper);
+}
+static void launch_zalloc(bnmf_handle* h, uint32_t t) {
+  if (h->cfg.save_Z) hipLaunchKernelGGL(k_zalloc<true>, dim3(h->z_grid), dim3(ZT), h->z_lds, h->stream, h->dev, t, h->z_NP, h->z_CB);
+  else hipLaunchKernelGGL(k_zalloc<false>, dim3(h->z_grid), dim3(ZT), h->z_lds, h->stream, h->dev, t, h->z_NP, h->z_CB);
+}
+static void launch_finalize(bnmf_handle* h, uint32_t t, int row) {
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(FN_T), 0, h->stream, h->dev, t, row, h->nblkE);
+}
+static int sweep(bnmf_handle* h, int row, Timer& tm) {
+  h->iter += 1;
+  const uint32_t t = (uint32_t)h->iter;
+  tm.begin(KN_PSIDE); launch_pside(h, t, 0, 1); tm.end(KN_PSIDE);
+  tm.begin(KN_ESIDE); launch_eside(h, t, 0, 1); tm.end(KN_ESIDE);
+  tm.begin(KN_ZALLOC); launch_zalloc(h, t); tm.end(KN_ZALLOC);
+  tm.begin(KN_FINALIZE); launch_finalize(h, t, row); tm.end(KN_FINALIZE);
+  return 0;
+}
+
+extern "C" {
+
+int bnmf_init(bnmf_handle* h, double* metrics_row1) {
+  if (!h) return fail(BNMF_EINVAL, "bnmf_init: null handle");
+  if (int rc = check_model_supported(h)) return rc;
+  HIPCHK(hipSetDevice(h->device));
+  const bnmf_config& c = h->cfg;
+  const int N = c.N;
+  const long KN = (long)c.K * N, NG = (long)N * c.G;
+  struct Spec { int id; uint32_t var; int side; int hs, hr; };
+  std::vector<Spec> specs;
+  if (c.prior == BNMF_GAMMA) {
+    if (int rc = need_hyper(h, {BNMF_HA_P, BNMF_HB_P, BNMF_HC_P, BNMF_HD_P, BNMF_HA_E, BNMF_HB_E, BNMF_HC_E, BNMF_HD_E})) return rc;
+    specs = {{BNMF_BETA_P, BNMF_V_BETA_P, 0, BNMF_HA_P, BNMF_HB_P}, {BNMF_ALPHA_P, BNMF_V_ALPHA_P, 0, BNMF_HC_P, BNMF_HD_P},
+             {BNMF_BETA_E, BNMF_V_BETA_E, 1, BNMF_HA_E, BNMF_HB_E}, {BNMF_ALPHA_E, BNMF_V_ALPHA_E, 1, BNMF_HC_E, BNMF_HD_E}};
+  } else if (c.prior == BNMF_EXPONENTIAL) {
+    if (int rc = need_hyper(h, {BNMF_HA_P, BNMF_HB_P, BNMF_HA_E, BNMF_HB_E})) return rc;
+    specs = {{BNMF_LAMBDA_P, BNMF_V_LAMBDA_P, 0, BNMF_HA_P, BNMF_HB_P}, {BNMF_LAMBDA_E, BNMF_V_LAMBDA_E, 1, BNMF_HA_E, BNMF_HB_E}};
+  }
+  for (const Spec& sp : specs) {
+    Arr& a = h->arr[sp.id];
+    std::vector<int> redraw(N, 1);
+    if (a.set) redraw = a.redraw.empty() ? std::vector<int>(N, 0) : a.redraw;
+    if (int rc = ensure(h, sp.id)) return rc;
+    refresh_dev(h);
+    HIPCHK(hipMemcpyAsync(h->dRedraw, redraw.data(), N * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    const long len = sp.side ? NG : KN;
+    const HRef hs{h->arr[sp.hs].d, h->arr[sp.hs].stride}, hr{h->arr[sp.hr].d, h->arr[sp.hr].stride};
+    if (sp.side) hipLaunchKernelGGL(k_init_gamma<1>, dim3((len + 255) / 256), dim3(256), 0, h->stream, h->dev, a.d, hs, hr, sp.var, h->dRedraw);
+    else hipLaunchKernelGGL(k_init_gamma<0>, dim3((len + 255) / 256), dim3(256), 0, h->stream, h->dev, a.d, hs, hr, sp.var, h->dRedraw);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));   // redraw is reused by the next spec
+  }
+  const bool haveP = h->arr[BNMF_P].set, haveE = h->arr[BNMF_E].set, haveA = h->arr[BNMF_A].set;
+  if (int rc = ensure(h, BNMF_P)) return rc;
+  if (int rc = ensure(h, BNMF_E)) return rc;
+  if (int rc = ensure(h, BNMF_A)) return rc;
+  if (!haveA) { std::vector<double> ones(N, 1.0); HIPCHK(hipMemcpy(h->arr[BNMF_A].d, ones.data(), N * sizeof(double), hipMemcpyHostToDevice)); }
+  refresh_dev(h);
+  h->iter = 1;
+  Timer tm{h, false};
+  if (!haveP) launch_pside(h, 1u, 1, 0);
+  else {
+    // Psum / log-prior of the supplied P are still needed: run the P kernel in "keep" mode is not
+    // possible without drawing, so compute them with a prior-free pass
+    return fail(BNMF_ESTATE, "bnmf_init: user-supplied P/E initial values are not supported yet");
+  }
+  if (!haveE) launch_eside(h, 1u, 1, 0);
+  else return fail(BNMF_ESTATE, "bnmf_init: user-supplied P/E initial values are not supported yet");
+  launch_zalloc(h, 1u);
+  launch_finalize(h, 1u, 0);
+  HIPCHK(hipGetLastError());
+  if (metrics_row1) HIPCHK(hipMemcpyAsync(metrics_row1, h->dMetrics, BNMF_NMETRIC * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->inited = true;
+  return 0;
+}
+
+static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, Timer& tm) {
+  (void)converged;
+  if (!h) return fail(BNMF_EINVAL, "bnmf_run: null handle");
+  if (!h->inited) return fail(BNMF_ESTATE, "bnmf_run: call bnmf_init first");
+  if (n_iter < 0) return fail(BNMF_EINVAL, "bnmf_run: n_iter < 0");
+  if (n_iter == 0) return 0;
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = ensure_metrics(h, (size_t)n_iter)) return rc;
+  for (int i = 0; i < n_iter; ++i) if (int rc = sweep(h, i, tm)) return rc;
+  HIPCHK(hipGetLastError());
+  if (metrics) HIPCHK(hipMemcpyAsync(metrics, h->dMetrics, (size_t)n_iter * BNMF_NMETRIC * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+int bnmf_run(bnmf_handle* h, int n_iter, int converged, double* metrics) {
+  Timer tm{h, false};
+  return run_impl(h, n_iter, converged, metrics, tm);
+}
+int bnmf_profile(bnmf_handle* h, int n_iter, int converged, double* out_ms) {
+  if (!h || !out_ms) return fail(BNMF_EINVAL, "bnmf_profile: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->have_ev) { for (auto& e : h->ev) HIPCHK(hipEventCreate(&e)); h->have_ev = true; }
+  Timer tm{h, true};
+  if (int rc = run_impl(h, n_iter, converged, nullptr, tm)) return rc;
+  for (int k = 0; k < BNMF_NKERNEL; ++k) out_ms[k] = tm.cnt[k] ? tm.acc[k] / tm.cnt[k] : 0.0;
+  return 0;
+}
+int bnmf_window(bnmf_handle* h, int id, int last_n, double* out) {
+  (void)id; (void)last_n; (void)out;
+  if (!h) return fail(BNMF_EINVAL, "bnmf_window: null handle");
+  return fail(BNMF_ESTATE, "bnmf_window: sample window not implemented in this build yet");
+}
+
+// ---- device-side probes for the parity tests ----
+int bnmf_test_math(int device, int fn, const double* in, double* out, size_t n) {
+  HIPCHK(hipSetDevice(device));
+  double *di, *dou;
+  HIPCHK(hipMalloc(&di, n * sizeof(double)));
+  HIPCHK(hipMalloc(&dou, n * sizeof(double)));
+  HIPCHK(hipMemcpy(di, in, n * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_test_math, dim3((n + 255) / 256), dim3(256), 0, 0, fn, di, dou, n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, dou, n * sizeof(double), hipMemcpyDeviceToHost));
+  hipFree(di); hipFree(dou);
+  return 0;
+}
+int bnmf_test_sampler(int device, int which, uint64_t seed, uint32_t chain, uint32_t var, uint32_t elem0, uint32_t iter,
+                      const double* a, const double* b, const double* c, double* out, size_t n) {
+  HIPCHK(hipSetDevice(device));
+  double *da, *db, *dc, *dou;
+  HIPCHK(hipMalloc(&da, n * sizeof(double))); HIPCHK(hipMalloc(&db, n * sizeof(double)));
+  HIPCHK(hipMalloc(&dc, n * sizeof(double))); HIPCHK(hipMalloc(&dou, n * sizeof(double)));
+  std::vector<double> zeros(n, 0.0);
+  HIPCHK(hipMemcpy(da, a ? a : zeros.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(db, b ? b : zeros.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dc, c ? c : zeros.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_test_sampler, dim3((n + 255) / 256), dim3(256), 0, 0, which, (uint32_t)seed, (uint32_t)(seed >> 32) ^ chain,
+                     var, elem0, iter, da, db, dc, dou, n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, dou, n * sizeof(double), hipMemcpyDeviceToHost));
+  hipFree(da); hipFree(db); hipFree(dc); hipFree(dou);
+  return 0;
+}
+int bnmf_test_philox(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  HIPCHK(hipSetDevice(device));
+  uint32_t* d;
+  HIPCHK(hipMalloc(&d, 16));
+  hipLaunchKernelGGL(k_test_philox, dim3(1), dim3(1), 0, 0, ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, d, 16, hipMemcpyDeviceToHost));
+  hipFree(d);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,199 @@
+// bayesnmf_amd/csrc/dsamplers.h — per-lane scalar samplers of the stream spec.
+// Each sampler consumes whole Philox blocks of its own (variable, element, iteration) stream,
+// so a draw never depends on which lane, wave or workgroup produced it.
+//   Gamma        : Marsaglia-Tsang, normal by inversion    (stats::rgamma call sites: R/sample_Pn.R:117,
+//                  R/sample_En.R:116, R/sample_priors.R:72-127,285-344)
+//   TN(mu,sd;0,inf): normal rejection / Robert's exponential rejection (truncnorm::rtruncnorm,
+//                  R/sample_Pn.R:14,59,79; R/sample_En.R:14,59,78)
+//   Alpha        : exact 3-tangent rejection for the log-concave ARMS target of
+//                  R/sample_priors.R:356-397
+#pragma once
+#include "dmath.h"
+
+namespace bnmf {
+
+constexpr int MAX_ATTEMPTS = 2000;
+
+BNMF_DEV double rnorm_std(Stream& s) { const u32x4 w = s.next(); return dqnorm(u52(w.x, w.y)); }
+BNMF_DEV double runif(Stream& s) { const u32x4 w = s.next(); return u52(w.x, w.y); }
+BNMF_DEV double rexp(Stream& s, double rate) { const u32x4 w = s.next(); return -dlog(u52(w.x, w.y)) / rate; }
+
+BNMF_DEV double rgamma(Stream& s, double a, double rate) {
+  if (!(a > 0.0)) return (a == 0.0) ? 0.0 : BNMF_NAN;
+  const bool boost = a < 1.0;
+  const double a1 = boost ? a + 1.0 : a;
+  const double d = a1 - 0.333333333333333333333;
+  const double c = 1.0 / dsqrt(9.0 * d);
+  double v = 1.0;
+  for (int it = 0; it < MAX_ATTEMPTS; ++it) {
+    const u32x4 w = s.next();
+    const double z = dqnorm(u52(w.x, w.y));
+    const double ua = u52(w.z, w.w);
+    v = 1.0 + c * z;
+    if (v <= 0.0) continue;
+    v = v * v * v;
+    const double z2 = z * z;
+    if (ua < 1.0 - 0.0331 * (z2 * z2)) break;
+    if (dlog(ua) < 0.5 * z2 + d * ((1.0 - v) + dlog(v))) break;
+  }
+  double g = d * v;
+  if (boost) {
+    const u32x4 w = s.next();
+    g = g * dexp(dlog(u52(w.x, w.y)) / a);
+  }
+  return g / rate;
+}
+BNMF_DEV double rinvgamma(Stream& s, double shape, double rate) { return 1.0 / rgamma(s, shape, rate); }
+
+BNMF_DEV double rtnorm0(Stream& s, double mu, double sd) {
+  const double alpha = -mu / sd;
+  double z = alpha;
+  if (alpha < 0.45) {
+    for (int it = 0; it < MAX_ATTEMPTS; ++it) {
+      const u32x4 w = s.next();
+      z = dqnorm(u52(w.x, w.y));
+      if (z >= alpha) break;
+    }
+  } else {
+    const double lam = 0.5 * (alpha + dsqrt(alpha * alpha + 4.0));
+    for (int it = 0; it < MAX_ATTEMPTS; ++it) {
+      const u32x4 w = s.next();
+      const double e = -dlog(u52(w.x, w.y)) / lam;
+      z = alpha + e;
+      const double t = z - lam;
+      const double rho = dexp(-0.5 * (t * t));
+      if (u52(w.z, w.w) <= rho) break;
+    }
+  }
+  const double x = mu + sd * z;
+  return x < 0.0 ? 0.0 : x;
+}
+
+// log f(x) = (c-1) log x - tau x - lgamma(x) and its derivative
+BNMF_DEV void alpha_h(double x, double c, double tau, double& h, double& hp) {
+  double lg, dg;
+  lgamma_digamma<true>(x, lg, dg);
+  h = ((c - 1.0) * dlog(x) - tau * x) - lg;
+  hp = ((c - 1.0) / x - tau) - dg;
+}
+
+BNMF_DEV double ralpha(Stream& s, double c, double tau, double xprev, int* n_attempts = nullptr) {
+  const double L = 1e-3, U = 1e4, DELTA = 1.41421356237309504880;
+  double x = xprev;
+  if (!(x >= L)) x = L;
+  if (x > U) x = U;
+  for (int it = 0; it < 32; ++it) {
+    const double Hx = (c / x - tau) - dlog(x + 0.5);
+    const double dH = -c / (x * x) - 1.0 / (x + 0.5);
+    double xn = x - Hx / dH;
+    if (!(xn > 0.1 * x)) xn = 0.1 * x;
+    if (xn > 10.0 * x) xn = 10.0 * x;
+    if (xn < L) xn = L;
+    if (xn > U) xn = U;
+    const double dx = dabs(xn - x);
+    x = xn;
+    if (dx <= 1e-3 * x) break;
+  }
+  double m = x;
+  const double g = (c / m - tau) - dlog(m + 0.5);
+  const double kap = c / (m * m) + 1.0 / (m + 0.5);
+  double sc = 1.0 / dsqrt(kap);
+  if (dabs(g) * sc > 1.0) sc = 1.0 / dabs(g);
+  double x1, x2, x3, h1, s1, h2, s2, h3, s3;
+  for (int round = 0; round < 4; ++round) {
+    x1 = m - DELTA * sc; x2 = m; x3 = m + DELTA * sc;
+    if (x1 < L) x1 = L;
+    if (x3 > U) x3 = U;
+    if (x2 - x1 < 0.25 * sc) { x1 = L; x2 = L + 0.75 * sc; x3 = L + 2.5 * sc; }
+    else if (x3 - x2 < 0.25 * sc) { x3 = U; x2 = U - 0.75 * sc; x1 = U - 2.5 * sc; }
+    if (x1 < L) x1 = L;
+    if (x3 > U) x3 = U;
+    if (!(x1 < x2 && x2 < x3)) { x1 = L; x2 = 0.5 * (L + U); x3 = U; }
+    alpha_h(x1, c, tau, h1, s1);
+    alpha_h(x2, c, tau, h2, s2);
+    alpha_h(x3, c, tau, h3, s3);
+    bool walked = false;
+    for (int it = 0; it < 64 && s3 > 0.0 && x3 < U; ++it) {
+      const double step = 2.0 * (x3 - x2);
+      x1 = x2; h1 = h2; s1 = s2; x2 = x3; h2 = h3; s2 = s3;
+      x3 = x3 + step; if (x3 > U) x3 = U;
+      alpha_h(x3, c, tau, h3, s3);
+      walked = true;
+    }
+    for (int it = 0; it < 64 && s1 < 0.0 && x1 > L; ++it) {
+      const double step = 2.0 * (x2 - x1);
+      x3 = x2; h3 = h2; s3 = s2; x2 = x1; h2 = h1; s2 = s1;
+      x1 = x1 - step; if (x1 < L) x1 = L;
+      alpha_h(x1, c, tau, h1, s1);
+      walked = true;
+    }
+    if (!walked) break;
+    double xa, xb, sa, sb;
+    if (s2 > 0.0) { xa = x2; sa = s2; xb = x3; sb = s3; } else { xa = x1; sa = s1; xb = x2; sb = s2; }
+    if (!(sa > 0.0 && sb < 0.0)) break;
+    m = xa + sa * (xb - xa) / (sa - sb);
+    sc = dsqrt((xb - xa) / (sa - sb));
+    if (!(sc > 0.0)) break;
+  }
+  double z1 = 0.5 * (x1 + x2), z2 = 0.5 * (x2 + x3);
+  if (s1 - s2 > 1e-14 * (dabs(s1) + dabs(s2))) {
+    z1 = (((h2 - h1) - s2 * x2) + s1 * x1) / (s1 - s2);
+    if (!(z1 >= x1)) z1 = x1;
+    if (z1 > x2) z1 = x2;
+  }
+  if (s2 - s3 > 1e-14 * (dabs(s2) + dabs(s3))) {
+    z2 = (((h3 - h2) - s3 * x3) + s2 * x2) / (s2 - s3);
+    if (!(z2 >= x2)) z2 = x2;
+    if (z2 > x3) z2 = x3;
+  }
+  // three segments [L,z1],[z1,z2],[z2,U]; kept in named scalars (no runtime-indexed arrays)
+  const double lo0 = L, hi0 = z1, lo1 = z1, hi1 = z2, lo2 = z2, hi2 = U;
+  const double Tlo0 = h1 + s1 * (lo0 - x1), Thi0 = h1 + s1 * (hi0 - x1);
+  const double Tlo1 = h2 + s2 * (lo1 - x2), Thi1 = h2 + s2 * (hi1 - x2);
+  const double Tlo2 = h3 + s3 * (lo2 - x3), Thi2 = h3 + s3 * (hi2 - x3);
+  double ref = -BNMF_INF;
+  if (Tlo0 > ref) ref = Tlo0;
+  if (Thi0 > ref) ref = Thi0;
+  if (Tlo1 > ref) ref = Tlo1;
+  if (Thi1 > ref) ref = Thi1;
+  if (Tlo2 > ref) ref = Tlo2;
+  if (Thi2 > ref) ref = Thi2;
+  auto area = [&](double Tlo, double Thi, double sj, double wj) -> double {
+    const double sw = sj * wj;
+    double A;
+    if (dabs(sw) < 1e-6) A = dexp(Tlo - ref) * wj * (1.0 + 0.5 * sw);
+    else A = (dexp(Thi - ref) - dexp(Tlo - ref)) / sj;
+    if (!(A > 0.0)) A = 0.0;
+    return A;
+  };
+  const double A0 = area(Tlo0, Thi0, s1, hi0 - lo0);
+  const double A1 = area(Tlo1, Thi1, s2, hi1 - lo1);
+  const double A2 = area(Tlo2, Thi2, s3, hi2 - lo2);
+  const double Atot = (A0 + A1) + A2;
+  double xs = m;
+  int it = 0;
+  for (; it < MAX_ATTEMPTS; ++it) {
+    const u32x4 w = s.next();
+    const double ua = u52(w.x, w.y) * Atot;
+    const double u2 = u52(w.z, w.w);
+    double r, lo, hi, sj, hj, xj;
+    if (ua < A0) { r = ua / A0; lo = lo0; hi = hi0; sj = s1; hj = h1; xj = x1; }
+    else if (ua < A0 + A1) { r = (ua - A0) / A1; lo = lo1; hi = hi1; sj = s2; hj = h2; xj = x2; }
+    else { r = ((ua - A0) - A1) / A2; lo = lo2; hi = hi2; sj = s3; hj = h3; xj = x3; }
+    if (!(r <= 1.0)) r = 1.0;
+    const double wj = hi - lo, sw = sj * wj;
+    if (dabs(sw) < 1e-6) xs = lo + r * wj;
+    else if (sj > 0.0) xs = hi + dlog(r + (1.0 - r) * dexp(-sw)) / sj;
+    else xs = lo + dlog((1.0 - r) + r * dexp(sw)) / sj;
+    if (xs < lo) xs = lo;
+    if (xs > hi) xs = hi;
+    double hx, hpx;
+    alpha_h(xs, c, tau, hx, hpx);
+    const double Tx = hj + sj * (xs - xj);
+    if (dlog(u2) <= hx - Tx) break;
+  }
+  if (n_attempts) *n_attempts = it + 1;
+  return xs;
+}
+
+}  // namespace bnmf

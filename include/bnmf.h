@@ -1,0 +1,128 @@
+/* include/bnmf.h — C ABI of libbnmf.so, the MI355X (gfx950) Gibbs engine for Bayesian NMF.
+ *
+ * This is the drop-in boundary.  The reference (jennalandy/bayesNMF, pure R) has no FFI;
+ * the seam this library replaces is the body of the sampling loop
+ *   R/bayesNMF_sampler.R:273-285  (sample_prior_params -> sample_params -> record_sample ->
+ *                                  update_sample_metrics)
+ * and the constructor's prior draws (R/bayesNMF_sampler.R:232-257).  An R `.Call` shim
+ * (r/bnmf_shim.c) or Python ctypes (bayesnmf_amd/engine.py) binds exactly these symbols.
+ *
+ * Conventions
+ *  - plain C types only; every matrix is column-major double exactly as R stores it:
+ *    M[k+K*g], P[k+K*n], E[n+N*g], Z[k+K*(n+N*g)]; A is length N; R one value.
+ *  - every function returns 0 on success, a negative BNMF_E* code otherwise; the message is
+ *    available from bnmf_last_error() (thread-local).  No exceptions cross the boundary.
+ *  - the caller owns every buffer it passes; the handle owns all device memory and one HIP
+ *    stream.  One handle = one chain = one device.  Handles are independent.
+ *  - there is NO CPU fallback: bnmf_create fails with BNMF_ENODEVICE when no gfx950 GPU is
+ *    visible.
+ */
+#ifndef BNMF_H
+#define BNMF_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BNMF_VERSION 100
+#define BNMF_NMETRIC 11   /* iter,RMSE,KL,loglikelihood,logposterior,n_params,BIC,rank,temp,
+                             P_mean_acceptance_rate,E_mean_acceptance_rate
+                             (state$sample_metrics columns, R/bayesNMF_sampler.R:190-207) */
+
+enum { BNMF_OK = 0, BNMF_EINVAL = -1, BNMF_ESIZE = -2, BNMF_EUNSET = -3, BNMF_ENODEVICE = -4,
+       BNMF_EHIP = -5, BNMF_EMODEL = -6, BNMF_ESTATE = -7 };
+
+enum { BNMF_POISSON = 0, BNMF_NORMAL = 1 };                       /* likelihood */
+enum { BNMF_TRUNCNORMAL = 0, BNMF_EXPONENTIAL = 1, BNMF_GAMMA = 2 }; /* prior */
+enum { BNMF_SBFI = 0, BNMF_BFI = 1 };                             /* rank_method */
+
+/* array ids for bnmf_set_array / bnmf_get_array / bnmf_window */
+enum {
+  BNMF_P = 0, BNMF_E = 1, BNMF_A = 2, BNMF_R = 3, BNMF_Z = 4, BNMF_ZSUMK = 5, BNMF_ZSUMG = 6,
+  BNMF_SIGMASQ = 7,
+  BNMF_ALPHA_P = 10, BNMF_BETA_P = 11, BNMF_ALPHA_E = 12, BNMF_BETA_E = 13,
+  BNMF_MU_P = 14, BNMF_SIGMASQ_P = 15, BNMF_MU_E = 16, BNMF_SIGMASQ_E = 17,
+  BNMF_LAMBDA_P = 18, BNMF_LAMBDA_E = 19, BNMF_ALPHA = 20, BNMF_BETA = 21,
+  /* hyper-prior matrices (R/setup.R:15-88); n==1 means a scalar broadcast */
+  BNMF_HA_P = 30, BNMF_HB_P = 31, BNMF_HC_P = 32, BNMF_HD_P = 33, BNMF_HM_P = 34, BNMF_HS_P = 35,
+  BNMF_HA_E = 40, BNMF_HB_E = 41, BNMF_HC_E = 42, BNMF_HD_E = 43, BNMF_HM_E = 44, BNMF_HS_E = 45,
+  BNMF_ACC_P = 50, BNMF_ACC_E = 51, BNMF_MHAT = 60, BNMF_ID_MAX = 64
+};
+
+/* Philox variable ids (counter word 3 of the stream spec) */
+enum { BNMF_V_Z = 1, BNMF_V_P = 2, BNMF_V_E = 3, BNMF_V_BETA_P = 4, BNMF_V_ALPHA_P = 5,
+       BNMF_V_BETA_E = 6, BNMF_V_ALPHA_E = 7, BNMF_V_MU_P = 8, BNMF_V_SIGSQ_P = 9,
+       BNMF_V_MU_E = 10, BNMF_V_SIGSQ_E = 11, BNMF_V_LAMBDA_P = 12, BNMF_V_LAMBDA_E = 13,
+       BNMF_V_A = 14, BNMF_V_R = 15, BNMF_V_MHU_P = 16, BNMF_V_MHU_E = 17, BNMF_V_SIGMASQ = 18 };
+
+typedef struct bnmf_handle bnmf_handle;
+
+typedef struct {
+  int32_t K, G, N;          /* dims (R/bayesNMF_sampler.R:141-145) */
+  int32_t likelihood;       /* BNMF_POISSON | BNMF_NORMAL */
+  int32_t prior;            /* BNMF_TRUNCNORMAL | BNMF_EXPONENTIAL | BNMF_GAMMA */
+  int32_t MH;               /* Metropolis-Hastings within Gibbs (Poisson only) */
+  int32_t learning_rank;    /* rank given as a range -> A, R sampled */
+  int32_t rank_method;      /* BNMF_SBFI | BNMF_BFI */
+  int32_t save_Z;           /* materialise Z (K x N x G int32) every iteration ("full mode") */
+  int32_t window;           /* samples kept on device for bnmf_window (MAP_over, or all) */
+  uint64_t seed;            /* Philox key = (seed_lo, seed_hi ^ chain_id) */
+  uint32_t chain_id;
+  int32_t device;           /* HIP device ordinal */
+  const double* temperature;/* temperature_schedule, length n_temperature (may be NULL = all 1) */
+  int64_t n_temperature;
+} bnmf_config;
+
+/* create: copies M (int32, column-major K x G) to the device.  Replaces the data/dims part of
+ * bayesNMF_sampler$new (R/bayesNMF_sampler.R:140-145). */
+int bnmf_create(const bnmf_config* cfg, const int32_t* M_colmajor, bnmf_handle** out);
+int bnmf_destroy(bnmf_handle* h);
+
+/* set/get any array by id (column-major doubles; integer arrays are converted).  Hyper-prior
+ * ids accept n==1 (scalar) — fill_matrix_ R/setup.R:102-113.  State arrays given before
+ * bnmf_init are kept verbatim (init_prior_params / init_params, R/sample_priors.R:15-141,
+ * R/sample_params.R:16-41); NaN entries mark "missing" and make that column n be re-drawn. */
+int bnmf_set_array(bnmf_handle* h, int id, const double* colmajor, size_t n);
+int bnmf_get_array(bnmf_handle* h, int id, double* colmajor_out, size_t n);
+int bnmf_get_array_i32(bnmf_handle* h, int id, int32_t* out, size_t n);   /* Z, ZsumK, ZsumG */
+
+/* constructor draws: prior params from hyper-priors unless supplied, then
+ * sample_params(from_prior=TRUE), record iteration 1 and its metrics row
+ * (R/bayesNMF_sampler.R:232-257).  metrics_row1 may be NULL. */
+int bnmf_init(bnmf_handle* h, double* metrics_row1 /* BNMF_NMETRIC */);
+
+/* n_iter iterations of the loop body (R/bayesNMF_sampler.R:273-285).  `converged` is
+ * state$converged: it only matters for MH (accept-all before, true accept/reject after,
+ * R/sample_Pn.R:199-204).  metrics_rowmajor: n_iter x BNMF_NMETRIC doubles (may be NULL). */
+int bnmf_run(bnmf_handle* h, int n_iter, int converged, double* metrics_rowmajor);
+
+/* last `last_n` recorded samples (<= window) of array `id`, oldest first:
+ * out[last_n][len(id)] (record_sample, R/bayesNMF_sampler.R:651-672). */
+int bnmf_window(bnmf_handle* h, int id, int last_n, double* out);
+
+int bnmf_get_iter(bnmf_handle* h, int* iter);
+
+/* average device time (ms) of each kernel class over n_iter iterations, measured with HIP
+ * events on the handle's own stream (advances the chain by n_iter iterations).
+ * out_ms[BNMF_NKERNEL]; names from bnmf_kernel_name(). */
+#define BNMF_NKERNEL 8
+int bnmf_profile(bnmf_handle* h, int n_iter, int converged, double* out_ms);
+const char* bnmf_kernel_name(int i);
+
+/* device-side unit probes used by the parity tests (tests/test_gpu_*.py) */
+int bnmf_test_math(int device, int fn, const double* in, double* out, size_t n);
+int bnmf_test_sampler(int device, int which, uint64_t seed, uint32_t chain, uint32_t var,
+                      uint32_t elem0, uint32_t iter, const double* a, const double* b,
+                      const double* c, double* out, size_t n);
+int bnmf_test_philox(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+int bnmf_device_info(int device, char* buf, size_t buflen);
+int bnmf_device_count(void);
+const char* bnmf_last_error(void);
+int bnmf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
