@@ -5,10 +5,12 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 #include "kernels.h"
+#include "zalloc_reg.h"
 
 using namespace bnmf;
 
@@ -38,7 +40,7 @@ struct bnmf_handle {
   double *dLut = nullptr, *dTemp = nullptr, *dMetrics = nullptr;
   size_t metrics_rows = 0;
   int maxM = 0, nblkE = 0;
-  int z_grid = 0, z_NP = 0, z_CB = 1; size_t z_lds = 0;
+  int z_grid = 0, z_zw = 8, z_ablate = 0; bool z_reg = false; size_t z_lds = 0; ZGeom zg{};
   hipEvent_t ev[2 * BNMF_NKERNEL]{};
   bool have_ev = false;
 };
@@ -173,20 +175,43 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
   HIPCHK(hipMalloc(&h->dMetrics, h->metrics_rows * BNMF_NMETRIC * sizeof(double)));
   hipLaunchKernelGGL(k_luts, dim3((mx + 256) / 256), dim3(256), 0, h->stream, h->dLut, h->dLut + (mx + 1), mx);
   HIPCHK(hipGetLastError());
-  // k_zalloc geometry: CB columns per pass so that K*CB <= 256 cells; odd row pitch NP
-  if (K > 256) { delete h; return fail(BNMF_EINVAL, "bnmf_create: K > 256 not supported yet by k_zalloc"); }
-  h->z_CB = (int)(256 / K); if (h->z_CB < 1) h->z_CB = 1; if (h->z_CB > 4) h->z_CB = 4;
-  h->z_NP = (int)(N | 1);
-  const size_t ncell = K * h->z_CB;
-  h->z_lds = ncell * h->z_NP * 4 * (cfg->save_Z ? 3 : 2) + 3 * ZT * 8 + (ZT + 4 + ZT + ZT + h->z_CB * N + 4) * 4;
-  h->z_lds = (h->z_lds + 15) & ~(size_t)15;
-  if (h->z_lds > 160 * 1024) { delete h; return fail(BNMF_EINVAL, "bnmf_create: K*N too large for k_zalloc LDS (%zu B)", h->z_lds); }
-  if (h->z_lds > 64 * 1024) {
-    HIPCHK(hipFuncSetAttribute((const void*)k_zalloc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->z_lds));
-    HIPCHK(hipFuncSetAttribute((const void*)k_zalloc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->z_lds));
+  // k_zalloc geometry: independent waves, one LDS slab per wave, zacc shared per workgroup.
+  // N <= 24 takes the register-resident kernel (zalloc_reg.h), larger N the LDS-search kernel.
+  {
+    ZGeom& zg = h->zg;
+    zg.KP = (K % 32 == 0) ? (int)K + 1 : (int)(K | 1);
+    zg.HW = (int)((N + 3) / 4);
+    zg.TR = N <= 9 ? 8 : N <= 17 ? 16 : N <= 21 ? 20 : 24;   // threshold registers of the k_zalloc_reg instantiation
+    h->z_reg = N <= (size_t)ZNMAX;
+    if (const char* e = getenv("BNMF_ZREG")) h->z_reg = h->z_reg && atoi(e) != 0;   // diagnostics only
+    long colmax = 0;
+    for (size_t g = 0; g < G; ++g) { long cs = 0; for (size_t k = 0; k < K; ++k) cs += M[k + K * g]; if (cs > colmax) colmax = cs; }
+    if (colmax > 4000000) { delete h; return fail(BNMF_EINVAL, "bnmf_create: a column of M sums to %ld (> 4,000,000 counts): unsupported", colmax); }
+    size_t slab;
+    if (h->z_reg) slab = (size_t)zg.HW * ZH + K * (size_t)zg.TR + 2 * N + (K + 1) + N + (cfg->save_Z ? N * (size_t)zg.KP : 0);
+    else slab = (size_t)zg.HW * ZH + 2 * N + (N - 1) * (size_t)zg.KP + (K + 1) + K + N + (cfg->save_Z ? N * (size_t)zg.KP : 0);
+    slab = (slab + 3) & ~(size_t)3;
+    zg.slab_words = (int)slab;
+    zg.zacc_words = (int)((N * (size_t)zg.KP + 3) & ~(size_t)3);
+    // workgroup width: as many waves per CU as the 160 KiB of LDS allow (1 or 2 workgroups per CU)
+    int best_w = 0, best_per_cu = 0, best_total = 0;
+    for (int per_cu = 1; per_cu <= 2; ++per_cu)
+      for (int w : {16, 8, 4, 2, 1}) {
+        const size_t lds = ((size_t)zg.zacc_words + (size_t)w * slab) * 4;
+        if (lds * per_cu <= 160 * 1024 && w * per_cu <= 16 && w * per_cu >= best_total) { best_total = w * per_cu; best_w = w; best_per_cu = per_cu; }
+      }
+    if (const char* e = getenv("BNMF_ZW")) { best_w = atoi(e); best_per_cu = ((size_t)zg.zacc_words + (size_t)best_w * slab) * 4 * 2 <= 160 * 1024 ? 2 : 1; }
+    if (best_w == 0) { delete h; return fail(BNMF_EINVAL, "bnmf_create: K*N too large for k_zalloc LDS (slab %zu B); not supported yet", slab * 4); }
+    h->z_zw = best_w;
+    h->z_lds = (((size_t)zg.zacc_words + (size_t)best_w * slab) * 4 + 15) & ~(size_t)15;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+    const long resident = (long)prop.multiProcessorCount * best_per_cu;
+    const long want = ((long)G + best_w - 1) / best_w;
+    h->z_grid = (int)(want < resident ? want : resident);
+    if (const char* e = getenv("BNMF_ZGRID")) h->z_grid = atoi(e);          // diagnostics only
+    if (const char* e = getenv("BNMF_ABLATE")) h->z_ablate = atoi(e);       // diagnostics only
   }
-  const int npass = (int)((G + h->z_CB - 1) / h->z_CB);
-  h->z_grid = npass < 2048 ? npass : 2048;
   HIPCHK(hipStreamSynchronize(h->stream));
   refresh_dev(h);
   *out = h;
@@ -319,9 +344,32 @@ static void launch_pside(bnmf_handle* h, uint32_t t, int from_prior, int do_hype
 static void launch_eside(bnmf_handle* h, uint32_t t, int from_prior, int do_hyper) {
   hipLaunchKernelGGL(k_eside, dim3(h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, from_prior, do_hyper);
 }
-static void launch_zalloc(bnmf_handle* h, uint32_t t) {
-  if (h->cfg.save_Z) hipLaunchKernelGGL(k_zalloc<true>, dim3(h->z_grid), dim3(ZT), h->z_lds, h->stream, h->dev, t, h->z_NP, h->z_CB);
-  else hipLaunchKernelGGL(k_zalloc<false>, dim3(h->z_grid), dim3(ZT), h->z_lds, h->stream, h->dev, t, h->z_NP, h->z_CB);
+template <typename KernelT>
+static int launch_z(bnmf_handle* h, uint32_t t, KernelT kern, int zt, bool* attr_done) {
+  if (!*attr_done) { HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); *attr_done = true; }
+  hipLaunchKernelGGL(kern, dim3(h->z_grid), dim3(zt), h->z_lds, h->stream, h->dev, t, h->zg, h->z_ablate);
+  return 0;
+}
+template <bool SZ, int ZT_>
+static int launch_zalloc_t(bnmf_handle* h, uint32_t t) {
+  static bool done[5] = {false, false, false, false, false};
+  if (!h->z_reg) return launch_z(h, t, k_zalloc<SZ, ZT_, 0>, ZT_, &done[0]);
+  switch (h->zg.TR) {
+    case 8: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 8>, ZT_, &done[1]);
+    case 16: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 16>, ZT_, &done[2]);
+    case 20: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 20>, ZT_, &done[3]);
+    default: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 24>, ZT_, &done[4]);
+  }
+}
+static int launch_zalloc(bnmf_handle* h, uint32_t t) {
+  const bool sz = h->cfg.save_Z != 0;
+  switch (h->z_zw) {
+    case 16: return sz ? launch_zalloc_t<true, 1024>(h, t) : launch_zalloc_t<false, 1024>(h, t);
+    case 8: return sz ? launch_zalloc_t<true, 512>(h, t) : launch_zalloc_t<false, 512>(h, t);
+    case 4: return sz ? launch_zalloc_t<true, 256>(h, t) : launch_zalloc_t<false, 256>(h, t);
+    case 2: return sz ? launch_zalloc_t<true, 128>(h, t) : launch_zalloc_t<false, 128>(h, t);
+    default: return sz ? launch_zalloc_t<true, 64>(h, t) : launch_zalloc_t<false, 64>(h, t);
+  }
 }
 static void launch_finalize(bnmf_handle* h, uint32_t t, int row) {
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(FN_T), 0, h->stream, h->dev, t, row, h->nblkE);

@@ -180,153 +180,253 @@ __global__ __launch_bounds__(ES_T) void k_eside(Dev d, uint32_t t, int from_prio
 // ---- k_zalloc: the hot kernel ----
 // sample_Zkg R/sample_params.R:253-265 for every cell, fused with Mhat (R/utils.R:29-49) and the
 // per-cell RMSE / KL / Poisson log-lik terms (R/utils.R:62-112, :412-471).
-// A workgroup takes passes of CB columns x K rows (<= 256 cells).  Phase 1: one lane per cell
-// builds the cell's cumulative thresholds thr[cell][n] = floor(cum_n * 2^32 / Mhat) in LDS.
-// Phase 2: the pass's counts are flattened into "quads" (4 counts = one Philox block of the
-// cell's stream) and dealt round-robin to the 256 lanes, so lanes stay balanced whatever the
-// count distribution; each count binary-searches its cell's thresholds and bumps zacc[cell][n]
-// with an LDS atomic.  Phase 3: ZsumK of the pass's columns = column sums of zacc minus their
-// previous value; ZsumG is flushed once per workgroup with global integer atomics (exact,
-// order-independent).
-constexpr int ZT = 256;
-template <bool SAVE_Z>
-__global__ __launch_bounds__(ZT) void k_zalloc(Dev d, uint32_t t, int NP, int CB) {
+//
+// ONE WAVEFRONT PER COLUMN, no workgroup barrier inside the column loop.  A workgroup is ZT/64
+// independent waves that only share the running Z counts zacc[n][k] (LDS atomics), flushed to
+// ZsumG once per workgroup with global integer atomics (exact, order-independent).
+// Per column g a wave does, wave-synchronously:
+//  phase 1: lane l owns rows l, l+64, ...: p_n = (P[k,n] A[n]) E[n,g] (A is 0/1, so the product
+//           with ae[n] = A[n] E[n,g] is bit-identical), cumulative sums, thresholds
+//           thr[n][k] = floor(cum_n 2^32 / Mhat) into the wave's LDS slab ([n][k] layout: lanes
+//           hold consecutive k, so threshold reads and zacc atomics of different cells fall in
+//           different banks), the cell's metric terms (accumulated per lane in exactly the
+//           canonical 64-strided order, then a wave tree) and the cell's quad count.
+//  phase 2: the column's counts are flattened into quads (4 counts = one Philox block of the
+//           cell's stream); each lane takes a CONTIGUOUS range of quads; the 4 counts of a quad
+//           run 4 interleaved branch-free binary searches over the cell's thresholds, then one
+//           LDS atomic into zacc[n][k] and one into the lane's private packed 8-bit histogram.
+//  phase 3: ZsumK[:,g] = wave reduction of the packed histograms.
+// LDS hand-off between lanes of ONE wave: DS operations of a wave are executed in issue order,
+// so only the compiler has to be stopped from moving LDS accesses across this point.  (A
+// workgroup-scope fence would also wait for every outstanding global store: ~microseconds.)
+BNMF_DEV void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+BNMF_DEV uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+struct __attribute__((aligned(16))) u4 { uint32_t x, y, z, w; };
+struct ZGeom { int KP, HW, TR, slab_words, zacc_words; };
+constexpr int ZH = 68;             // pitch of the per-lane histogram rows (16-byte aligned rows)
+template <bool SAVE_Z, int ZT, int NMAX>
+__global__ __launch_bounds__(ZT) void k_zalloc(Dev d, uint32_t t, ZGeom zg, int ablate) {
+  // `ablate` is a diagnostic bitmask (0 in production): 1 no flush, 2 no phase 2, 4 no LDS atomics,
+  // 8 no threshold search, 16 no Philox
+  constexpr int ZW = ZT / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = d.K, G = d.G, N = d.N;
-  const int ncell = K * CB;
-  uint32_t* thr = (uint32_t*)smem;                       // [ncell][NP]
-  uint32_t* zacc = thr + (size_t)ncell * NP;             // [ncell][NP]
-  uint32_t* zprev = zacc + (size_t)ncell * NP;           // [ncell][NP] (SAVE_Z only)
-  double* red = (double*)(zprev + (SAVE_Z ? (size_t)ncell * NP : 0));   // [3][ZT]
-  int* qoff = (int*)(red + 3 * ZT);                      // [ZT+1]
-  int* mcnt = qoff + ZT + 4;                             // [ZT]
-  int* nlastA = mcnt + ZT;                               // [ZT]
-  int* totold = nlastA + ZT;                             // [CB*N]
-  int* wsum = totold + CB * N;                           // [4]
-  for (int i = tid; i < ncell * NP; i += ZT) { zacc[i] = 0; if (SAVE_Z) zprev[i] = 0; }
-  for (int i = tid; i < CB * N; i += ZT) totold[i] = 0;
+  const int KP = zg.KP, HW = zg.HW;
+  const int KR = (K + 63) >> 6;                          // row rounds per lane
+  uint32_t* zacc = (uint32_t*)smem;                      // [N][KP] shared by the workgroup
+  uint32_t* slab = zacc + zg.zacc_words + (size_t)wave * zg.slab_words;
+  uint32_t* hist = slab;                                 // [HW][ZH] per-lane packed 8-bit bucket counts (16-B aligned)
+  double* ae = (double*)(hist + HW * ZH);                // [N]  A[n] * E[n,g]
+  uint32_t* thr = (uint32_t*)(ae + N);                   // [N-1][KP] thresholds
+  uint32_t* qoff = thr + (size_t)(N - 1) * KP;           // [K+1]  quad offset (22 bits) | nlast << 22
+  int* mcnt = (int*)(qoff + K + 1);                      // [K]
+  uint32_t* zkt = (uint32_t*)(mcnt + K);                 // [N] column totals
+  uint32_t* zloc = zkt + N;                              // [N][KP]  (SAVE_Z only)
+  for (int i = tid; i < N * KP; i += ZT) zacc[i] = 0;
+  for (int i = lane; i < HW * ZH; i += 64) hist[i] = 0;
+  for (int i = lane; i < N; i += 64) zkt[i] = 0;
+  if (SAVE_Z) for (int i = lane; i < N * KP; i += 64) zloc[i] = 0;
   __syncthreads();
-  const int npass = (G + CB - 1) / CB;
-  for (int pass = blockIdx.x; pass < npass; pass += gridDim.x) {
-    const int g0 = pass * CB;
-    // ---------------- phase 1: thresholds + per-cell metric terms
-    int q = 0;
-    {
-      double sse = 0.0, ll = 0.0, kl = 0.0;
-      int m = 0, nl = -1;
-      if (tid < ncell) {
-        const int cb = tid / K, kk = tid - cb * K, g = g0 + cb;
-        if (g < G) {
-          const double* Eg = d.E + (size_t)N * g;
-          double c = 0.0;
-          for (int n = 0; n < N; ++n) {
-            const double p = (d.P[kk + (size_t)K * n] * d.A[n]) * Eg[n];
-            c = c + p;
-            if (p > 0.0) nl = n;
+  const int nthr = N - 1;
+  uint32_t* ztarget = SAVE_Z ? zloc : zacc;
+  const int gw = blockIdx.x * ZW + wave, nw = gridDim.x * ZW;
+  for (int g = gw; g < G; g += nw) {
+    // ---------------- phase 1
+    double a_sse = 0.0, a_ll = 0.0, a_kl = 0.0;
+    int carry = 0;
+    const double* Eg = d.E + (size_t)N * g;
+    for (int n = lane; n < N; n += 64) ae[n] = d.A[n] * Eg[n];
+    wave_lds_fence();
+    for (int r = 0; r < KR; ++r) {
+      const int kk = (r << 6) + lane;
+      int q = 0, nl = -1;
+      if (kk < K) {
+        const double* Pk = d.P + kk;
+        const int m = d.M[kk + (size_t)K * g];
+        double c = 0.0;
+        if (NMAX > 0) {
+          // single pass: all P loads in flight, cumulative sums kept in registers
+          double pv[NMAX > 0 ? NMAX : 1];
+#pragma unroll
+          for (int n = 0; n < NMAX; ++n) pv[n] = (ablate & 128) ? 1.0 + n : Pk[(size_t)K * min(n, N - 1)];
+#pragma unroll
+          for (int n = 0; n < NMAX; ++n) {
+            if (n < N) {
+              const double p = pv[n] * ae[n];
+              c = c + p;
+              if (p > 0.0) nl = n;
+            }
+            pv[n] = c;
           }
-          m = d.M[kk + (size_t)K * g];
-          if (c > 0.0 && m > 0 && nl >= 0) {
+          if (c > 0.0 && m > 0 && nl >= 0 && (ablate & 32)) q = (m + 3) >> 2;
+          else if (c > 0.0 && m > 0 && nl >= 0) {
             const double scale = 4294967296.0 / c;
-            double cc = 0.0;
-            uint32_t* row = thr + (size_t)tid * NP;
-            for (int n = 0; n < N - 1; ++n) {
-              const double p = (d.P[kk + (size_t)K * n] * d.A[n]) * Eg[n];
-              cc = cc + p;
-              const double tt = cc * scale;
-              row[n] = (tt >= 4294967295.0) ? 0xFFFFFFFFu : (uint32_t)tt;
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) {
+              if (n < nthr) {
+                const double tt = pv[n] * scale;
+                thr[(size_t)n * KP + kk] = (n >= nl || tt >= 4294967295.0) ? 0xFFFFFFFFu : (uint32_t)tt;
+              }
             }
             q = (m + 3) >> 2;
           }
-          const double dd = c - (double)m;
-          sse = dd * dd;
-          const double mh = c < 1e-6 ? 1e-6 : c;
-          const double lmh = dlog(mh);
-          const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
-          const double mt = m < 1 ? 1e-6 : (double)m;
-          ll = ((double)m * lmh - mh) - d.lgfact[mi];
-          kl = mt * (d.logm[mi] - lmh);
+        } else {
+          for (int n0 = 0; n0 < N; n0 += 8) {             // 8 independent P loads in flight
+            double pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[j] = Pk[(size_t)K * min(n0 + j, N - 1)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              if (n0 + j < N) {
+                const double p = pv[j] * ae[n0 + j];
+                c = c + p;
+                if (p > 0.0) nl = n0 + j;
+              }
+            }
+          }
+          if (c > 0.0 && m > 0 && nl >= 0) {
+            const double scale = 4294967296.0 / c;
+            double cc = 0.0;
+            for (int n0 = 0; n0 < nthr; n0 += 8) {
+              double pv[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) pv[j] = Pk[(size_t)K * min(n0 + j, N - 1)];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                if (n0 + j < nthr) {
+                  cc = cc + pv[j] * ae[n0 + j];
+                  const double tt = cc * scale;
+                  thr[(size_t)(n0 + j) * KP + kk] = (n0 + j >= nl || tt >= 4294967295.0) ? 0xFFFFFFFFu : (uint32_t)tt;
+                }
+              }
+            }
+            q = (m + 3) >> 2;
+          }
+        }
+        const double dd = c - (double)m;
+        const double mh = c < 1e-6 ? 1e-6 : c;
+        const double lmh = (ablate & 64) ? mh : dlog(mh);
+        const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
+        const double mt = m < 1 ? 1e-6 : (double)m;
+        a_sse = a_sse + dd * dd;                          // canonical: lane l adds rows l, l+64, ...
+        a_ll = a_ll + (((double)m * lmh - mh) - d.lgfact[mi]);
+        a_kl = a_kl + mt * (d.logm[mi] - lmh);
+        mcnt[kk] = q > 0 ? m : 0;
+      }
+      int incl = q;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+      if (kk < K) qoff[kk] = (uint32_t)(carry + incl - q) | ((uint32_t)(nl < 0 ? 0 : nl) << 22);
+      carry += __shfl(incl, 63, 64);
+    }
+    const int Q = carry;
+    if (lane == 0) qoff[K] = (uint32_t)Q;
+    a_sse = wave_tree64(a_sse); a_ll = wave_tree64(a_ll); a_kl = wave_tree64(a_kl);
+    if (lane == 0) { d.colsse[g] = a_sse; d.colll[g] = a_ll; d.colkl[g] = a_kl; }
+    wave_lds_fence();
+    // ---------------- phase 2: lane takes quads [q0, q1), in chunks of <= 63 quads so that the
+    // packed 8-bit per-lane histogram cannot overflow (<= 252 counts per flush)
+    const int per = (Q + 63) >> 6;
+    for (int cbase = 0; cbase < per; cbase += 63) {
+      const int q0 = min(Q, lane * per + cbase);
+      const int q1 = min(Q, min(lane * per + per, q0 + 63));
+      if (q0 < q1 && !(ablate & 2)) {
+        int cell;
+        {  // upper_bound(qoff[0..K] & mask, q0) - 1, branch-free
+          int b = 0, len = K + 1;
+          while (len > 1) { const int half = len >> 1; b = ((int)(qoff[b + half - 1] & 0x3FFFFFu) <= q0) ? b + half : b; len -= half; }
+          cell = b + ((int)(qoff[b] & 0x3FFFFFu) <= q0 ? 1 : 0) - 1;
+        }
+        uint32_t qw = qoff[cell];
+        int cstart = (int)(qw & 0x3FFFFFu), nl = (int)(qw >> 22);
+        int cend = (int)(qoff[cell + 1] & 0x3FFFFFu);
+        int mc = mcnt[cell];
+        for (int qi = q0; qi < q1; ++qi) {
+          if (qi >= cend) {
+            do { ++cell; qw = qoff[cell]; cstart = cend; cend = (int)(qoff[cell + 1] & 0x3FFFFFu); } while (qi >= cend);
+            nl = (int)(qw >> 22);
+            mc = mcnt[cell];
+          }
+          const int j0 = (qi - cstart) << 2;
+          const int nd = mc - j0;                          // >= 1; draws of this quad = min(4, nd)
+          u32x4 w;
+          if (ablate & 16) w = u32x4{(uint32_t)qi * 2654435761u, (uint32_t)qi * 40503u, (uint32_t)qi, ~(uint32_t)qi};
+          else w = philox4x32_10((uint32_t)(j0 >> 2), (uint32_t)(cell + (size_t)K * g), t, BNMF_V_Z, d.k0, d.k1);
+          const uint32_t* col = thr + cell;
+          const uint32_t u0 = min(w.x, 0xFFFFFFFEu), u1 = min(w.y, 0xFFFFFFFEu), u2 = min(w.z, 0xFFFFFFFEu), u3 = min(w.w, 0xFFFFFFFEu);
+          int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+          if (nthr > 0 && !(ablate & 8)) {
+            int len = nthr;
+            while (len > 1) {                             // 4 interleaved branch-free searches
+              const int half = len >> 1, off = half - 1;
+              const uint32_t t0 = col[(b0 + off) * KP], t1 = col[(b1 + off) * KP], t2 = col[(b2 + off) * KP], t3 = col[(b3 + off) * KP];
+              b0 = (t0 <= u0) ? b0 + half : b0;
+              b1 = (t1 <= u1) ? b1 + half : b1;
+              b2 = (t2 <= u2) ? b2 + half : b2;
+              b3 = (t3 <= u3) ? b3 + half : b3;
+              len -= half;
+            }
+            b0 += (col[b0 * KP] <= u0) ? 1 : 0;
+            b1 += (col[b1 * KP] <= u1) ? 1 : 0;
+            b2 += (col[b2 * KP] <= u2) ? 1 : 0;
+            b3 += (col[b3 * KP] <= u3) ? 1 : 0;
+          }
+          uint32_t* zc = ztarget + cell;
+          uint32_t* hl = hist + lane;
+          if (ablate & 4) { if (b0 + b1 + b2 + b3 + nl == -12345) zc[0] = w.x; }
+          else {
+            atomicAdd(&zc[b0 * KP], 1u); atomicAdd(&hl[(b0 >> 2) * ZH], 1u << ((b0 & 3) << 3));
+            if (nd > 1) { atomicAdd(&zc[b1 * KP], 1u); atomicAdd(&hl[(b1 >> 2) * ZH], 1u << ((b1 & 3) << 3)); }
+            if (nd > 2) { atomicAdd(&zc[b2 * KP], 1u); atomicAdd(&hl[(b2 >> 2) * ZH], 1u << ((b2 & 3) << 3)); }
+            if (nd > 3) { atomicAdd(&zc[b3 * KP], 1u); atomicAdd(&hl[(b3 >> 2) * ZH], 1u << ((b3 & 3) << 3)); }
+          }
         }
       }
-      red[tid] = sse; red[ZT + tid] = ll; red[2 * ZT + tid] = kl;
-      mcnt[tid] = q > 0 ? m : 0;
-      nlastA[tid] = nl;
-    }
-    // exclusive scan of q over the 256 lanes -> qoff
-    int incl = q;
+      wave_lds_fence();
+      // flush the packed histograms: lane n sums byte (n&3) of word n>>2 over the 64 lanes
+      if (!(ablate & 256)) {
+        for (int n = lane; n < N; n += 64) {
+          const uint32_t* hr = hist + (n >> 2) * ZH;
+          const int sh = (n & 3) << 3;
+          uint32_t tot = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-    qoff[tid] = base + incl - q;
-    if (tid == ZT - 1) qoff[ZT] = base + incl;
-    __syncthreads();
-    const int Q = qoff[ZT];
-    // ---------------- phase 2: allocate counts
-    for (int qi = tid; qi < Q; qi += ZT) {
-      int lo = 0, len = ZT;                       // upper_bound(qoff[0..ZT), qi) - 1
-      while (len > 0) { const int half = len >> 1; if (qoff[lo + half] <= qi) { lo += half + 1; len -= half + 1; } else len = half; }
-      const int cell = lo - 1;
-      const int cb = cell / K, kk = cell - cb * K, g = g0 + cb;
-      const int j0 = (qi - qoff[cell]) << 2;
-      const int nd = min(4, mcnt[cell] - j0);
-      const u32x4 w = philox4x32_10((uint32_t)(j0 >> 2), (uint32_t)(kk + (size_t)K * g), t, BNMF_V_Z, d.k0, d.k1);
-      const uint32_t* row = thr + (size_t)cell * NP;
-      uint32_t* zrow = zacc + (size_t)cell * NP;
-      const int nl = nlastA[cell];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (j < nd) {
-          const uint32_t u = j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w;
-          int b = 0, bl = N - 1;                  // upper_bound(row[0..N-1), u)
-          while (bl > 0) { const int half = bl >> 1; if (row[b + half] <= u) { b += half + 1; bl -= half + 1; } else bl = half; }
-          if (b > nl) b = nl;
-          atomicAdd(&zrow[b], 1u);
+          for (int l4 = 0; l4 < 64; l4 += 4) {
+            const u4 v = *(const u4*)(hr + l4);
+            tot += ((v.x >> sh) & 0xFFu) + ((v.y >> sh) & 0xFFu) + ((v.z >> sh) & 0xFFu) + ((v.w >> sh) & 0xFFu);
+          }
+          zkt[n] += tot;
         }
+        wave_lds_fence();
+        for (int i = lane; i < HW * ZH; i += 64) hist[i] = 0;
       }
+      wave_lds_fence();
     }
-    __syncthreads();
-    // ---------------- phase 3: ZsumK of this pass's columns (+ Z), canonical metric sums
-    for (int i = tid; i < CB * N; i += ZT) {
-      const int cb = i / N, n = i - cb * N, g = g0 + cb;
-      if (g < G) {
-        int tot = 0;
-        for (int kk = 0; kk < K; ++kk) tot += (int)zacc[(size_t)(cb * K + kk) * NP + n];
-        d.ZsumK[n + (size_t)N * g] = tot - totold[i];
-        totold[i] = tot;
-      }
-    }
+    // ---------------- phase 3: ZsumK[:,g] (and Z[:,:,g])
+    for (int n = lane; n < N; n += 64) { d.ZsumK[n + (size_t)N * g] = (int32_t)zkt[n]; zkt[n] = 0; }
     if (SAVE_Z) {
-      for (int i = tid; i < ncell * N; i += ZT) {       // i = kk + K*(n + N*cb): coalesced Z store
-        const int kk = i % K, r = i / K, n = r % N, cb = r / N, g = g0 + cb;
-        if (g < G) {
-          const size_t a = (size_t)(cb * K + kk) * NP + n;
-          const uint32_t z = zacc[a];
-          d.Z[kk + (size_t)K * (n + (size_t)N * g)] = (int32_t)(z - zprev[a]);
-          zprev[a] = z;
-        }
+      for (int i = lane; i < K * N; i += 64) {            // i = kk + K*n: coalesced Z store
+        const int kk = i % K, n = i / K;
+        const size_t a = (size_t)n * KP + kk;
+        const uint32_t z = zloc[a];
+        d.Z[kk + (size_t)K * (n + (size_t)N * g)] = (int32_t)z;
+        if (z) { atomicAdd(&zacc[a], z); zloc[a] = 0; }
       }
     }
-    for (int job = wave; job < CB * 3; job += ZT / 64) {
-      const int cb = job / 3, mtr = job - cb * 3, g = g0 + cb;
-      if (g < G) {
-        const double* src = red + mtr * ZT + cb * K;
-        double acc = 0.0;
-        for (int kk = lane; kk < K; kk += 64) acc = acc + src[kk];
-        acc = wave_tree64(acc);
-        if (lane == 0) (mtr == 0 ? d.colsse : mtr == 1 ? d.colll : d.colkl)[g] = acc;
-      }
-    }
-    __syncthreads();
+    wave_lds_fence();
   }
-  // flush ZsumG: integer atomics are exact, so the result is order-independent
+  __syncthreads();
   for (int i = tid; i < K * N; i += ZT) {
     const int kk = i % K, n = i / K;
-    uint32_t v = 0;
-    for (int cb = 0; cb < CB; ++cb) v += zacc[(size_t)(cb * K + kk) * NP + n];
-    if (v) atomicAdd(&d.ZsumG[kk + (size_t)K * n], (int32_t)v);
+    const uint32_t v = zacc[(size_t)n * KP + kk];
+    if (v && !(ablate & 1)) atomicAdd(&d.ZsumG[kk + (size_t)K * n], (int32_t)v);
   }
 }
 

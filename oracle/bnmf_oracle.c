@@ -289,8 +289,9 @@ static void sample_E_poisson(orc_handle* o, uint32_t t, int from_prior) {
  * else Multinomial(M[k,g], probs/sum).  Stream spec: the M[k,g] counts of a cell are
  * allocated one by one; count j uses 32-bit word (j&3) of block (j>>2) of stream
  * (V_Z, cell=k+K*g, iter); it lands in the first n whose cumulative threshold
- * thr[n] = floor(cum[n] * 2^32 / sum) exceeds the word (saturating at 2^32-1), clipped to
- * the last n with a positive probability.  The sum of M independent categorical draws is
+ * thr[n] = floor(cum[n] * 2^32 / sum) exceeds the word; the word is clamped to 2^32-2 and
+ * thresholds at or beyond the last n with a positive probability (or that saturate) are
+ * 2^32-1 = "never", so no count can land on a factor of zero probability.  The sum of M independent categorical draws is
  * exactly the multinomial R's rmultinom samples by conditional binomials.
  * The same pass yields Mhat[k,g] = sum (get_Mhat_, R/utils.R:29-49) and the per-cell
  * terms of RMSE / KL / Poisson log-lik (R/utils.R:62-112, :412-471). */
@@ -311,16 +312,16 @@ static void z_cell(const orc_handle* o, long k, long g, uint32_t t, int32_t* zro
   double scale = 4294967296.0 / c;
   for (long n = 0; n < N; ++n) {
     double tt = cum[n] * scale;
-    thr[n] = (tt >= 4294967295.0) ? 0xFFFFFFFFu : (uint32_t)tt;
+    thr[n] = (n >= nlast || tt >= 4294967295.0) ? 0xFFFFFFFFu : (uint32_t)tt;   /* 2^32-1 = "never" */
   }
   orc_stream s = ST(o, V_Z, (uint32_t)(k + K * g), t);
   uint32_t w[4];
   for (int32_t j = 0; j < m; ++j) {
     if ((j & 3) == 0) orc_stream_next(&s, w);
     uint32_t u = w[j & 3];
+    if (u > 0xFFFFFFFEu) u = 0xFFFFFFFEu;
     long b = 0;
     while (b < N - 1 && thr[b] <= u) ++b;
-    if (b > nlast) b = nlast;
     zrow[b]++;
   }
 }
