@@ -21,15 +21,18 @@ static int fail(int code, const char* fmt, ...) {
 }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(BNMF_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
-enum { KN_PSIDE = 0, KN_ESIDE = 1, KN_ZALLOC = 2, KN_FINALIZE = 3, KN_RANK = 4, KN_MH_P = 5, KN_MH_E = 6, KN_OTHER = 7 };
-static const char* k_names[BNMF_NKERNEL] = {"k_pside", "k_eside", "k_zalloc", "k_finalize", "k_rank", "k_mh_p", "k_mh_e", "other"};
+enum { KN_PDRAW = 0, KN_EDRAW = 1, KN_ZALLOC = 2, KN_REDUCE = 3, KN_SIDE = 4, KN_RANK = 5, KN_MH = 6, KN_OTHER = 7 };
+static const char* k_names[BNMF_NKERNEL] = {"k_pdraw", "k_edraw", "k_zalloc", "k_reduce", "k_side", "k_rank", "k_mh", "other"};
 
 struct Arr { double* d = nullptr; size_t n = 0; int stride = 1; bool set = false; std::vector<int> redraw; };
 
 struct bnmf_handle {
   bnmf_config cfg{};
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;        // main stream: draws, k_zalloc, reductions
+  hipStream_t side = nullptr;          // side stream: k_side of the next iteration (overlaps k_zalloc)
+  hipEvent_t ev_draw = nullptr, ev_side = nullptr;
+  bool side_valid = false;             // k_side of iteration iter+1 has been issued
   int iter = 0;
   bool inited = false;
   Dev dev{};
@@ -37,7 +40,7 @@ struct bnmf_handle {
   int32_t *dM = nullptr, *dZsumK = nullptr, *dZsumG = nullptr, *dZ = nullptr;
   int* dR = nullptr; int* dRedraw = nullptr;
   double *dEsum = nullptr, *dPsum = nullptr, *dlpPn = nullptr, *dlpE = nullptr, *dcol = nullptr;
-  double *dLut = nullptr, *dTemp = nullptr, *dMetrics = nullptr;
+  double *dLut = nullptr, *dTemp = nullptr, *dMetrics = nullptr, *dRaw = nullptr;
   size_t metrics_rows = 0;
   int maxM = 0, nblkE = 0;
   int z_grid = 0, z_zw = 8, z_ablate = 0; bool z_reg = false; size_t z_lds = 0; ZGeom zg{};
@@ -63,15 +66,17 @@ static size_t id_len(const bnmf_handle* h, int id) {
   }
 }
 static bool is_hyper(int id) { return id >= 30 && id < 50; }
+static bool is_prior_param(int id) { return id >= BNMF_ALPHA_P && id <= BNMF_LAMBDA_E; }   // 2 slots, slot(t) = t & 1
+static int cur_slot(const bnmf_handle* h) { return (h->iter > 0 ? h->iter : 1) & 1; }
 static bool is_pside(int id) { size_t dummy = 0; (void)dummy; return id == BNMF_P || id == BNMF_ALPHA_P || id == BNMF_BETA_P || id == BNMF_MU_P || id == BNMF_SIGMASQ_P || id == BNMF_LAMBDA_P; }
 
 static int ensure(bnmf_handle* h, int id) {
   Arr& a = h->arr[id];
   if (a.d) return 0;
-  const size_t n = id_len(h, id);
-  HIPCHK(hipMalloc(&a.d, n * sizeof(double)));
-  std::vector<double> nan(n, std::nan(""));
-  HIPCHK(hipMemcpy(a.d, nan.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  const size_t n = id_len(h, id), tot = n * (is_prior_param(id) ? 2 : 1);
+  HIPCHK(hipMalloc(&a.d, tot * sizeof(double)));
+  std::vector<double> nan(tot, std::nan(""));
+  HIPCHK(hipMemcpy(a.d, nan.data(), tot * sizeof(double), hipMemcpyHostToDevice));
   a.n = n; a.stride = 1;
   return 0;
 }
@@ -101,7 +106,8 @@ static void refresh_dev(bnmf_handle* h) {
   d.colsse = h->dcol; d.colll = h->dcol + c.G; d.colkl = h->dcol + 2 * (size_t)c.G;
   d.lgfact = h->dLut; d.logm = h->dLut + (h->maxM + 1);
   d.temperature = h->dTemp; d.n_temperature = c.n_temperature;
-  d.metrics = h->dMetrics;
+  d.metrics = h->dMetrics; d.raw = h->dRaw;
+  d.lenP = (size_t)c.K * c.N; d.lenE = (size_t)c.N * c.G;
 }
 
 extern "C" {
@@ -145,6 +151,9 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
   h->device = cfg->device;
   const size_t K = cfg->K, G = cfg->G, N = cfg->N;
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_draw, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
   HIPCHK(hipMalloc(&h->dM, K * G * sizeof(int32_t)));
   HIPCHK(hipMemcpy(h->dM, M, K * G * sizeof(int32_t), hipMemcpyHostToDevice));
   int mx = 0;
@@ -173,6 +182,7 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
   h->cfg.temperature = nullptr;
   h->metrics_rows = 1024;
   HIPCHK(hipMalloc(&h->dMetrics, h->metrics_rows * BNMF_NMETRIC * sizeof(double)));
+  HIPCHK(hipMalloc(&h->dRaw, h->metrics_rows * 8 * sizeof(double)));
   hipLaunchKernelGGL(k_luts, dim3((mx + 256) / 256), dim3(256), 0, h->stream, h->dLut, h->dLut + (mx + 1), mx);
   HIPCHK(hipGetLastError());
   // k_zalloc geometry: independent waves, one LDS slab per wave, zacc shared per workgroup.
@@ -222,10 +232,12 @@ int bnmf_destroy(bnmf_handle* h) {
   if (!h) return 0;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->side) hipStreamSynchronize(h->side);
   for (auto& a : h->arr) if (a.d) hipFree(a.d);
   hipFree(h->dM); hipFree(h->dZsumK); hipFree(h->dZsumG); if (h->dZ) hipFree(h->dZ);
   hipFree(h->dR); hipFree(h->dRedraw); hipFree(h->dEsum); hipFree(h->dPsum); hipFree(h->dlpPn);
-  hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics);
+  hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics); hipFree(h->dRaw);
+  if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->side) hipStreamDestroy(h->side);
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -238,6 +250,8 @@ int bnmf_set_array(bnmf_handle* h, int id, const double* x, size_t n) {
   if (len == 0) return fail(BNMF_EINVAL, "bnmf_set_array: unknown id %d", id);
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->side));
+  h->side_valid = false;                 // state changed: the pre-issued k_side must be redone
   if (id == BNMF_R) { int r = (int)x[0]; HIPCHK(hipMemcpy(h->dR, &r, sizeof(int), hipMemcpyHostToDevice)); h->arr[BNMF_R].set = true; return 0; }
   if (id == BNMF_ZSUMK || id == BNMF_ZSUMG || id == BNMF_Z) {
     int32_t* dst = id == BNMF_ZSUMK ? h->dZsumK : id == BNMF_ZSUMG ? h->dZsumG : h->dZ;
@@ -258,9 +272,10 @@ int bnmf_set_array(bnmf_handle* h, int id, const double* x, size_t n) {
     return 0;
   }
   if (n != len) return fail(BNMF_ESIZE, "bnmf_set_array: id %d expects %zu values, got %zu", id, len, n);
+  const size_t nslot = is_prior_param(id) ? 2 : 1;
   if (a.d && a.n != len) { HIPCHK(hipFree(a.d)); a.d = nullptr; }
-  if (!a.d) HIPCHK(hipMalloc(&a.d, len * sizeof(double)));
-  HIPCHK(hipMemcpy(a.d, x, len * sizeof(double), hipMemcpyHostToDevice));
+  if (!a.d) HIPCHK(hipMalloc(&a.d, nslot * len * sizeof(double)));
+  HIPCHK(hipMemcpy(a.d + (nslot == 2 ? (size_t)cur_slot(h) * len : 0), x, len * sizeof(double), hipMemcpyHostToDevice));
   a.n = len; a.stride = 1; a.set = true;
   // which columns n (P side) / rows n (E side) carry a missing (NaN) entry
   if (!is_hyper(id) && len >= (size_t)h->cfg.N && id != BNMF_A && id < 30) {
@@ -279,6 +294,7 @@ int bnmf_get_array(bnmf_handle* h, int id, double* out, size_t n) {
   if (len == 0 || n != len) return fail(BNMF_ESIZE, "bnmf_get_array: id %d expects %zu values, got %zu", id, len, n);
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->side));
   if (id == BNMF_R) { int r; HIPCHK(hipMemcpy(&r, h->dR, sizeof(int), hipMemcpyDeviceToHost)); out[0] = r; return 0; }
   if (id == BNMF_ZSUMK || id == BNMF_ZSUMG || id == BNMF_Z) {
     const int32_t* src = id == BNMF_ZSUMK ? h->dZsumK : id == BNMF_ZSUMG ? h->dZsumG : h->dZ;
@@ -291,7 +307,7 @@ int bnmf_get_array(bnmf_handle* h, int id, double* out, size_t n) {
   const Arr& a = h->arr[id];
   if (!a.d) return fail(BNMF_EUNSET, "bnmf_get_array: id %d has no value", id);
   if (a.stride == 0) { double v; HIPCHK(hipMemcpy(&v, a.d, sizeof(double), hipMemcpyDeviceToHost)); for (size_t i = 0; i < n; ++i) out[i] = v; return 0; }
-  HIPCHK(hipMemcpy(out, a.d, n * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, a.d + (is_prior_param(id) ? (size_t)cur_slot(h) * len : 0), n * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -329,20 +345,35 @@ static int ensure_metrics(bnmf_handle* h, size_t rows) {
   HIPCHK(hipFree(h->dMetrics));
   h->metrics_rows = rows;
   HIPCHK(hipMalloc(&h->dMetrics, rows * BNMF_NMETRIC * sizeof(double)));
+  HIPCHK(hipFree(h->dRaw));
+  HIPCHK(hipMalloc(&h->dRaw, rows * 8 * sizeof(double)));
   refresh_dev(h);
   return 0;
 }
-struct Timer {   // optional per-kernel HIP-event bracketing on the handle's own stream
+struct Timer {   // optional per-kernel HIP-event bracketing (serialises the two streams: profile mode only)
   bnmf_handle* h; bool on; double acc[BNMF_NKERNEL]{}; int cnt[BNMF_NKERNEL]{};
-  void begin(int k) { if (on) hipEventRecord(h->ev[2 * k], h->stream); }
-  void end(int k) { if (on) { hipEventRecord(h->ev[2 * k + 1], h->stream); hipEventSynchronize(h->ev[2 * k + 1]); float ms = 0; hipEventElapsedTime(&ms, h->ev[2 * k], h->ev[2 * k + 1]); acc[k] += ms; cnt[k]++; } }
+  void begin(int k, hipStream_t st) { if (on) { hipStreamSynchronize(h->stream); hipStreamSynchronize(h->side); hipEventRecord(h->ev[2 * k], st); } }
+  void end(int k, hipStream_t st) { if (on) { hipEventRecord(h->ev[2 * k + 1], st); hipEventSynchronize(h->ev[2 * k + 1]); float ms = 0; hipEventElapsedTime(&ms, h->ev[2 * k], h->ev[2 * k + 1]); acc[k] += ms; cnt[k]++; } }
 };
-static void launch_pside(bnmf_handle* h, uint32_t t, int from_prior, int do_hyper) {
-  const size_t lds = (PS_T + 2 + 2 * (size_t)h->cfg.K) * sizeof(double);
-  hipLaunchKernelGGL(k_pside, dim3(h->cfg.N), dim3(PS_T), lds, h->stream, h->dev, t, from_prior, do_hyper);
+static void launch_pdraw(bnmf_handle* h, uint32_t t, int from_prior) {
+  const size_t lds = 2 * (size_t)h->cfg.K * sizeof(double);
+  hipLaunchKernelGGL(k_pdraw, dim3(h->cfg.N), dim3(PD_T), lds, h->stream, h->dev, t, from_prior);
 }
-static void launch_eside(bnmf_handle* h, uint32_t t, int from_prior, int do_hyper) {
-  hipLaunchKernelGGL(k_eside, dim3(h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, from_prior, do_hyper);
+static void launch_edraw(bnmf_handle* h, uint32_t t, int from_prior) {
+  hipLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, from_prior);
+}
+// k_side for iteration t (reads P_{t-1}, E_{t-1}): issued on the side stream right after the draws
+// of iteration t-1, so that it overlaps k_zalloc of iteration t-1
+static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm) {
+  const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
+  const int nbE = (int)(((size_t)h->cfg.N * h->cfg.G + RT - 1) / RT);
+  hipEventRecord(h->ev_draw, h->stream);
+  hipStreamWaitEvent(h->side, h->ev_draw, 0);
+  tm.begin(KN_SIDE, h->side);
+  hipLaunchKernelGGL(k_side, dim3(h->cfg.N + nbP + nbE), dim3(RT), 0, h->side, h->dev, t, nbP);
+  tm.end(KN_SIDE, h->side);
+  hipEventRecord(h->ev_side, h->side);
+  h->side_valid = true;
 }
 template <typename KernelT>
 static int launch_z(bnmf_handle* h, uint32_t t, KernelT kern, int zt, bool* attr_done) {
@@ -371,16 +402,19 @@ static int launch_zalloc(bnmf_handle* h, uint32_t t) {
     default: return sz ? launch_zalloc_t<true, 64>(h, t) : launch_zalloc_t<false, 64>(h, t);
   }
 }
-static void launch_finalize(bnmf_handle* h, uint32_t t, int row) {
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(FN_T), 0, h->stream, h->dev, t, row, h->nblkE);
+static void launch_reduce(bnmf_handle* h, int row) {
+  hipLaunchKernelGGL(k_reduce, dim3(4), dim3(RT), 0, h->stream, h->dev, row, h->nblkE);
 }
 static int sweep(bnmf_handle* h, int row, Timer& tm) {
   h->iter += 1;
   const uint32_t t = (uint32_t)h->iter;
-  tm.begin(KN_PSIDE); launch_pside(h, t, 0, 1); tm.end(KN_PSIDE);
-  tm.begin(KN_ESIDE); launch_eside(h, t, 0, 1); tm.end(KN_ESIDE);
-  tm.begin(KN_ZALLOC); launch_zalloc(h, t); tm.end(KN_ZALLOC);
-  tm.begin(KN_FINALIZE); launch_finalize(h, t, row); tm.end(KN_FINALIZE);
+  if (!h->side_valid) launch_side(h, t, tm);               // first sweep after init / set_array
+  hipStreamWaitEvent(h->stream, h->ev_side, 0);            // prior params + Esum of iteration t ready
+  tm.begin(KN_PDRAW, h->stream); launch_pdraw(h, t, 0); tm.end(KN_PDRAW, h->stream);
+  tm.begin(KN_EDRAW, h->stream); launch_edraw(h, t, 0); tm.end(KN_EDRAW, h->stream);
+  launch_side(h, t + 1, tm);                               // overlaps the k_zalloc below
+  tm.begin(KN_ZALLOC, h->stream); if (int rc = launch_zalloc(h, t)) return rc; tm.end(KN_ZALLOC, h->stream);
+  tm.begin(KN_REDUCE, h->stream); launch_reduce(h, row); tm.end(KN_REDUCE, h->stream);
   return 0;
 }
 
@@ -412,8 +446,9 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
     HIPCHK(hipMemcpyAsync(h->dRedraw, redraw.data(), N * sizeof(int), hipMemcpyHostToDevice, h->stream));
     const long len = sp.side ? NG : KN;
     const HRef hs{h->arr[sp.hs].d, h->arr[sp.hs].stride}, hr{h->arr[sp.hr].d, h->arr[sp.hr].stride};
-    if (sp.side) hipLaunchKernelGGL(k_init_gamma<1>, dim3((len + 255) / 256), dim3(256), 0, h->stream, h->dev, a.d, hs, hr, sp.var, h->dRedraw);
-    else hipLaunchKernelGGL(k_init_gamma<0>, dim3((len + 255) / 256), dim3(256), 0, h->stream, h->dev, a.d, hs, hr, sp.var, h->dRedraw);
+    double* slot1 = a.d + (size_t)len;                      // iteration 1 lives in slot 1
+    if (sp.side) hipLaunchKernelGGL(k_init_gamma<1>, dim3((len + 255) / 256), dim3(256), 0, h->stream, h->dev, slot1, hs, hr, sp.var, h->dRedraw);
+    else hipLaunchKernelGGL(k_init_gamma<0>, dim3((len + 255) / 256), dim3(256), 0, h->stream, h->dev, slot1, hs, hr, sp.var, h->dRedraw);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));   // redraw is reused by the next spec
   }
@@ -425,19 +460,17 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
   refresh_dev(h);
   h->iter = 1;
   Timer tm{h, false};
-  if (!haveP) launch_pside(h, 1u, 1, 0);
-  else {
-    // Psum / log-prior of the supplied P are still needed: run the P kernel in "keep" mode is not
-    // possible without drawing, so compute them with a prior-free pass
-    return fail(BNMF_ESTATE, "bnmf_init: user-supplied P/E initial values are not supported yet");
-  }
-  if (!haveE) launch_eside(h, 1u, 1, 0);
-  else return fail(BNMF_ESTATE, "bnmf_init: user-supplied P/E initial values are not supported yet");
-  launch_zalloc(h, 1u);
-  launch_finalize(h, 1u, 0);
+  if (haveP || haveE) return fail(BNMF_ESTATE, "bnmf_init: user-supplied P/E initial values are not supported yet");
+  launch_pdraw(h, 1u, 1);
+  launch_edraw(h, 1u, 1);
+  launch_side(h, 2u, tm);
+  if (int rc = launch_zalloc(h, 1u)) return rc;
+  launch_reduce(h, 0);
+  hipLaunchKernelGGL(k_compose, dim3(1), dim3(64), 0, h->stream, h->dev, 1, 1u);
   HIPCHK(hipGetLastError());
   if (metrics_row1) HIPCHK(hipMemcpyAsync(metrics_row1, h->dMetrics, BNMF_NMETRIC * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->side));
   h->inited = true;
   return 0;
 }
@@ -450,10 +483,13 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
   if (n_iter == 0) return 0;
   HIPCHK(hipSetDevice(h->device));
   if (int rc = ensure_metrics(h, (size_t)n_iter)) return rc;
+  const uint32_t t0 = (uint32_t)h->iter + 1;
   for (int i = 0; i < n_iter; ++i) if (int rc = sweep(h, i, tm)) return rc;
+  hipLaunchKernelGGL(k_compose, dim3((n_iter + 63) / 64), dim3(64), 0, h->stream, h->dev, n_iter, t0);
   HIPCHK(hipGetLastError());
   if (metrics) HIPCHK(hipMemcpyAsync(metrics, h->dMetrics, (size_t)n_iter * BNMF_NMETRIC * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->side));
   return 0;
 }
 int bnmf_run(bnmf_handle* h, int n_iter, int converged, double* metrics) {

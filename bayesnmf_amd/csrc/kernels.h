@@ -1,11 +1,12 @@
 // bayesnmf_amd/csrc/kernels.h — hand-written gfx950 kernels of the Gibbs sweep.
 //
 // One iteration (Poisson likelihood, no MH; R/bayesNMF_sampler.R:273-285) is four launches:
-//   k_pside   grid N       : Esum[n] -> hyper sweep of column n -> P[,n] -> Psum[n], log-prior
-//   k_eside   grid NG/256  : hyper sweep of E elements -> E -> log-prior partials
-//   k_zalloc  grid ~2k     : thresholds in LDS -> categorical allocation of every count ->
+//   k_side    (side stream, overlaps k_zalloc of the previous iteration): Esum, hyper sweep
+//   k_pdraw   grid N       : P[,n] -> Psum[n], log-prior of column n
+//   k_edraw   grid NG/256  : E -> log-prior partials
+//   k_zalloc  one wave per column: thresholds -> categorical allocation of every count ->
 //                            ZsumK, ZsumG (+Z) and the per-column RMSE/KL/log-lik terms
-//   k_finalize grid 1      : canonical reductions -> metrics row
+//   k_reduce  grid 4       : canonical reductions; k_compose once per run -> metrics rows
 // All fp64; all cross-lane sums use the canonical orders of dmath.h so results are bitwise
 // independent of scheduling.  No MFMA: the path is sampling + reductions.
 #pragma once
@@ -32,7 +33,12 @@ struct Dev {
   const double *lgfact, *logm;       // LUTs over m = 0..maxM: lgamma(m+1), log(max(m,1e-6))
   const double* temperature; long n_temperature;
   double* metrics;                   // device rows [row][BNMF_NMETRIC]
+  double* raw;                       // device rows [row][8]: sse, ll, kl, lpE, lpP, sumA (k_reduce -> k_compose)
+  size_t lenP, lenE;                 // K*N, N*G: the prior-parameter arrays hold 2 slots, slot(t) = t & 1
 };
+// prior parameters of iteration t live in slot t&1, so the hyper sweep of iteration t+1 can run
+// (on the side stream) while iteration t's values are still being read
+template <int SIDE> BNMF_DEV double* slot(const Dev& d, double* base, uint32_t t) { return base + (size_t)(t & 1u) * (SIDE ? d.lenE : d.lenP); }
 
 BNMF_DEV double clamp_tiny(double v) { return (v < 1e-300) ? 1e-300 : v; }
 
@@ -45,133 +51,153 @@ BNMF_DEV void hyper_elem(const Dev& d, int e, uint32_t t, double v) {
     double* Al = SIDE ? d.Alpha_e : d.Alpha_p;
     double* Be = SIDE ? d.Beta_e : d.Beta_p;
     Stream s(d.k0, d.k1, SIDE ? BNMF_V_BETA_E : BNMF_V_BETA_P, (uint32_t)e, t);
-    const double al_old = Al[e];
+    const double al_old = slot<SIDE>(d, Al, t - 1)[e];
     const double b = rgamma(s, hy(hA, e) + al_old, hy(hB, e) + v);        // sample_Beta_*  :323-345
-    Be[e] = b;
+    slot<SIDE>(d, Be, t)[e] = b;
     const double tau = (hy(hD, e) - dlog(clamp_tiny(b))) - dlog(clamp_tiny(v));
     Stream s2(d.k0, d.k1, SIDE ? BNMF_V_ALPHA_E : BNMF_V_ALPHA_P, (uint32_t)e, t);
-    Al[e] = ralpha(s2, hy(hC, e), tau, al_old);                             // sample_Alpha_* :356-397
+    slot<SIDE>(d, Al, t)[e] = ralpha(s2, hy(hC, e), tau, al_old);           // sample_Alpha_* :356-397
   } else if (d.prior == BNMF_EXPONENTIAL) {
     const HRef &hA = SIDE ? d.hA_e : d.hA_p, &hB = SIDE ? d.hB_e : d.hB_p;
     double* La = SIDE ? d.Lam_e : d.Lam_p;
     Stream s(d.k0, d.k1, SIDE ? BNMF_V_LAMBDA_E : BNMF_V_LAMBDA_P, (uint32_t)e, t);
-    La[e] = rgamma(s, hy(hA, e) + 1.0, hy(hB, e) + v);                      // sample_Lambda_* :284-308
+    slot<SIDE>(d, La, t)[e] = rgamma(s, hy(hA, e) + 1.0, hy(hB, e) + v);    // sample_Lambda_* :284-308
   } else {
     const HRef &hM = SIDE ? d.hM_e : d.hM_p, &hS = SIDE ? d.hS_e : d.hS_p;
     const HRef &hA = SIDE ? d.hA_e : d.hA_p, &hB = SIDE ? d.hB_e : d.hB_p;
     double* Mu = SIDE ? d.Mu_e : d.Mu_p;
     double* Sg = SIDE ? d.Sig_e : d.Sig_p;
-    const double sg = Sg[e];
+    const double sg = slot<SIDE>(d, Sg, t - 1)[e];
     const double num = hy(hM, e) / hy(hS, e) + v / sg;
     const double den = 1.0 / hy(hS, e) + 1.0 / sg;
     Stream s(d.k0, d.k1, SIDE ? BNMF_V_MU_E : BNMF_V_MU_P, (uint32_t)e, t);
     const double mu = num / den + (1.0 / den) * rnorm_std(s);               // sd = 1/denom (quirk) :214-236
-    Mu[e] = mu;
+    slot<SIDE>(d, Mu, t)[e] = mu;
     const double dl = v - mu;
     const double rate = (SIDE ? hy(hA, e) : hy(hB, e)) + (dl * dl) / 2.0;   // A_e for B_e (quirk) :263-270
     Stream s2(d.k0, d.k1, SIDE ? BNMF_V_SIGSQ_E : BNMF_V_SIGSQ_P, (uint32_t)e, t);
-    Sg[e] = rinvgamma(s2, hy(hA, e) + 0.5, rate);
+    slot<SIDE>(d, Sg, t)[e] = rinvgamma(s2, hy(hA, e) + 0.5, rate);
   }
 }
 // prior draw of an element of P / E: R/sample_Pn.R:12-30, R/sample_En.R:12-30
 template <int SIDE>
 BNMF_DEV double prior_draw(const Dev& d, int e, uint32_t t) {
   Stream s(d.k0, d.k1, SIDE ? BNMF_V_E : BNMF_V_P, (uint32_t)e, t);
-  if (d.prior == BNMF_GAMMA) return rgamma(s, (SIDE ? d.Alpha_e : d.Alpha_p)[e], (SIDE ? d.Beta_e : d.Beta_p)[e]);
-  if (d.prior == BNMF_EXPONENTIAL) return rexp(s, (SIDE ? d.Lam_e : d.Lam_p)[e]);
-  return rtnorm0(s, (SIDE ? d.Mu_e : d.Mu_p)[e], dsqrt((SIDE ? d.Sig_e : d.Sig_p)[e]));
+  if (d.prior == BNMF_GAMMA) return rgamma(s, slot<SIDE>(d, SIDE ? d.Alpha_e : d.Alpha_p, t)[e], slot<SIDE>(d, SIDE ? d.Beta_e : d.Beta_p, t)[e]);
+  if (d.prior == BNMF_EXPONENTIAL) return rexp(s, slot<SIDE>(d, SIDE ? d.Lam_e : d.Lam_p, t)[e]);
+  return rtnorm0(s, slot<SIDE>(d, SIDE ? d.Mu_e : d.Mu_p, t)[e], dsqrt(slot<SIDE>(d, SIDE ? d.Sig_e : d.Sig_p, t)[e]));
 }
-// log prior density of an element: R/utils.R:132-175
+// log prior density of an element under iteration t's prior parameters: R/utils.R:132-175
 template <int SIDE>
-BNMF_DEV double prior_logdens(const Dev& d, int e, double x) {
+BNMF_DEV double prior_logdens(const Dev& d, int e, double x, uint32_t t) {
   if (d.prior == BNMF_GAMMA) {
-    const double al = (SIDE ? d.Alpha_e : d.Alpha_p)[e], be = (SIDE ? d.Beta_e : d.Beta_p)[e];
+    const double al = slot<SIDE>(d, SIDE ? d.Alpha_e : d.Alpha_p, t)[e], be = slot<SIDE>(d, SIDE ? d.Beta_e : d.Beta_p, t)[e];
     return ((al * dlog(be) - dlgamma(al)) + (al - 1.0) * dlog(x)) - be * x;
   }
   if (d.prior == BNMF_EXPONENTIAL) {
-    const double la = (SIDE ? d.Lam_e : d.Lam_p)[e];
+    const double la = slot<SIDE>(d, SIDE ? d.Lam_e : d.Lam_p, t)[e];
     return dlog(la) - la * x;
   }
-  const double mu = (SIDE ? d.Mu_e : d.Mu_p)[e], sg = dsqrt((SIDE ? d.Sig_e : d.Sig_p)[e]);
+  const double mu = slot<SIDE>(d, SIDE ? d.Mu_e : d.Mu_p, t)[e], sg = dsqrt(slot<SIDE>(d, SIDE ? d.Sig_e : d.Sig_p, t)[e]);
   const double zz = (x - mu) / sg;
   return ((-0.91893853320467274178 - dlog(sg)) - 0.5 * (zz * zz)) - dlog_pnorm(mu / sg);
 }
 
-// ---- k_pside: one workgroup of 1024 lanes per factor n ----
-// sample_Pn_poisson R/sample_Pn.R:98-120 (dispatch :11-42) with the P-side hyper sweep fused in.
-constexpr int PS_T = 1024;
-__global__ __launch_bounds__(PS_T) void k_pside(Dev d, uint32_t t, int from_prior, int do_hyper) {
-  // all LDS in one dynamic, 16-byte aligned region: buf[PS_T] | bc[2] | Pn[K] | lp[K]
-  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-  double* buf = (double*)dyn;
-  double* bc = buf + PS_T;
-  const int n = blockIdx.x, tid = threadIdx.x;
-  const int K = d.K, G = d.G, N = d.N;
-  double Esum = 0.0;
-  if (!from_prior) {
-    double acc = 0.0;
-    for (int g = tid; g < G; g += PS_T) acc = acc + d.E[n + (size_t)N * g];
-    const double r = block_tree<PS_T>(acc, buf, tid);
-    if (tid == 0) { bc[0] = r; d.Esum[n] = r; }
-    __syncthreads();
-    Esum = bc[0];
+// canonical W=1024 sum of x[0], x[stride], ... (L terms) by one 256-lane workgroup: lane i owns
+// accumulators i, i+256, i+512, i+768, folds the first two tree levels locally, then a 256-tree.
+constexpr int RT = 256;
+BNMF_DEV double canon1024_by256(const double* x, long L, long stride, double* buf, int tid) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  for (long i = tid; i < L; i += 1024) {
+    a0 = a0 + x[i * stride];
+    if (i + 256 < L) a1 = a1 + x[(i + 256) * stride];
+    if (i + 512 < L) a2 = a2 + x[(i + 512) * stride];
+    if (i + 768 < L) a3 = a3 + x[(i + 768) * stride];
   }
+  a0 = a0 + a2; a1 = a1 + a3;          // tree level h = 512
+  a0 = a0 + a1;                         // tree level h = 256
+  return block_tree<RT>(a0, buf, tid);  // valid on thread 0
+}
+
+// ---- k_side: everything of iteration t that depends only on P_{t-1}, E_{t-1} ----
+// Runs on the side stream concurrently with k_zalloc of iteration t-1.
+//   blocks [0, N)            : Esum[n] = canonical sum_g E[n,g]   (rate of P's Gamma, R/sample_Pn.R:103-106)
+//   blocks [N, N+nbP)        : hyper sweep of the P-side prior parameters (R/sample_priors.R:150-200)
+//   blocks [N+nbP, ...)      : hyper sweep of the E-side prior parameters
+__global__ __launch_bounds__(RT) void k_side(Dev d, uint32_t t, int nbP) {
+  __shared__ double buf[RT];
+  const int tid = threadIdx.x, blk = blockIdx.x;
+  if (blk < d.N) {
+    const double r = canon1024_by256(d.E + blk, d.G, d.N, buf, tid);
+    if (tid == 0) d.Esum[blk] = r;
+  } else if (blk < d.N + nbP) {
+    const long e = (long)(blk - d.N) * RT + tid;
+    if (e < (long)d.lenP) hyper_elem<0>(d, (int)e, t, d.P[e]);
+  } else {
+    const long e = (long)(blk - d.N - nbP) * RT + tid;
+    if (e < (long)d.lenE) hyper_elem<1>(d, (int)e, t, d.E[e]);
+  }
+}
+
+// ---- k_pdraw: one workgroup of 128 lanes per factor n ----
+// sample_Pn_poisson R/sample_Pn.R:98-120 (dispatch :11-42); Psum[n] and the log-prior of column n
+// are reduced canonically (W = 64) over k.
+constexpr int PD_T = 128;
+__global__ __launch_bounds__(PD_T) void k_pdraw(Dev d, uint32_t t, int from_prior) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  double* Pn = (double*)dyn;          // [K]
+  double* lp = Pn + d.K;              // [K]
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int K = d.K;
   const double a_n = d.A[n];
-  // column n of P lives in LDS while Psum / log-prior are reduced canonically over k
-  double* Pn = bc + 2;                // [K]
-  double* lp = Pn + K;                // [K]
-  for (int k = tid; k < K; k += PS_T) {
+  const double Esum = from_prior ? 0.0 : d.Esum[n];
+  for (int k = tid; k < K; k += PD_T) {
     const int e = k + K * n;
-    if (do_hyper) hyper_elem<0>(d, e, t, d.P[e]);
     double x;
     if (from_prior || a_n == 0.0) x = prior_draw<0>(d, e, t);
     else {
       double shape, rate;
-      if (d.prior == BNMF_GAMMA) { shape = d.Alpha_p[e] + (double)d.ZsumG[e]; rate = d.Beta_p[e] + a_n * Esum; }
-      else { shape = 1.0 + (double)d.ZsumG[e]; rate = d.Lam_p[e] + a_n * Esum; }
+      if (d.prior == BNMF_GAMMA) { shape = slot<0>(d, d.Alpha_p, t)[e] + (double)d.ZsumG[e]; rate = slot<0>(d, d.Beta_p, t)[e] + a_n * Esum; }
+      else { shape = 1.0 + (double)d.ZsumG[e]; rate = slot<0>(d, d.Lam_p, t)[e] + a_n * Esum; }
       Stream s(d.k0, d.k1, BNMF_V_P, (uint32_t)e, t);
       x = rgamma(s, shape, rate);
     }
     d.P[e] = x;
     d.ZsumG[e] = 0;                    // consumed; k_zalloc accumulates the next one
     Pn[k] = x;
-    lp[k] = prior_logdens<0>(d, e, x);
+    lp[k] = prior_logdens<0>(d, e, x, t);
   }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;
-  if (wave < 2) {
-    const double* src = wave ? lp : Pn;
-    double acc = 0.0;
-    for (int k = lane; k < K; k += 64) acc = acc + src[k];
-    acc = wave_tree64(acc);
-    if (lane == 0) (wave ? d.lpPn : d.Psum)[n] = acc;
-  }
+  const double* src = wave ? lp : Pn;
+  double acc = 0.0;
+  for (int k = lane; k < K; k += 64) acc = acc + src[k];
+  acc = wave_tree64(acc);
+  if (lane == 0) (wave ? d.lpPn : d.Psum)[n] = acc;
 }
 
-// ---- k_eside: one lane per element (n,g) of E, flat column-major index e = n + N g ----
-// sample_En_poisson R/sample_En.R:97-119 with the E-side hyper sweep fused in.
+// ---- k_edraw: one lane per element (n,g) of E, flat column-major index e = n + N g ----
+// sample_En_poisson R/sample_En.R:97-119; log-prior partial per 256-element block (canonical tree)
 constexpr int ES_T = 256;
-__global__ __launch_bounds__(ES_T) void k_eside(Dev d, uint32_t t, int from_prior, int do_hyper) {
+__global__ __launch_bounds__(ES_T) void k_edraw(Dev d, uint32_t t, int from_prior) {
   __shared__ double buf[ES_T];
   const int tid = threadIdx.x;
-  const long NE = (long)d.N * d.G;
   const long e = (long)blockIdx.x * ES_T + tid;
   double lp = 0.0;
-  if (e < NE) {
+  if (e < (long)d.lenE) {
     const int n = (int)(e % d.N);
     const double a_n = d.A[n];
-    if (do_hyper) hyper_elem<1>(d, (int)e, t, d.E[e]);
     double x;
     if (from_prior || a_n == 0.0) x = prior_draw<1>(d, (int)e, t);
     else {
       double shape, rate;
-      if (d.prior == BNMF_GAMMA) { shape = d.Alpha_e[e] + (double)d.ZsumK[e]; rate = d.Beta_e[e] + a_n * d.Psum[n]; }
-      else { shape = 1.0 + (double)d.ZsumK[e]; rate = d.Lam_e[e] + a_n * d.Psum[n]; }
+      if (d.prior == BNMF_GAMMA) { shape = slot<1>(d, d.Alpha_e, t)[e] + (double)d.ZsumK[e]; rate = slot<1>(d, d.Beta_e, t)[e] + a_n * d.Psum[n]; }
+      else { shape = 1.0 + (double)d.ZsumK[e]; rate = slot<1>(d, d.Lam_e, t)[e] + a_n * d.Psum[n]; }
       Stream s(d.k0, d.k1, BNMF_V_E, (uint32_t)e, t);
       x = rgamma(s, shape, rate);
     }
     d.E[e] = x;
-    lp = prior_logdens<1>(d, (int)e, x);
+    lp = prior_logdens<1>(d, (int)e, x, t);
   }
   const double r = block_tree<ES_T>(lp, buf, tid);
   if (tid == 0) d.lpE_part[blockIdx.x] = r;
@@ -430,47 +456,52 @@ __global__ __launch_bounds__(ZT) void k_zalloc(Dev d, uint32_t t, ZGeom zg, int 
   }
 }
 
-// ---- k_finalize: canonical reductions over columns -> one metrics row ----
-// compute_metrics_ R/utils.R:412-455, update_sample_metrics_ :339-348
-constexpr int FN_T = 1024;
-__global__ __launch_bounds__(FN_T) void k_finalize(Dev d, uint32_t t, int row, int nblkE) {
-  __shared__ double buf[FN_T];
-  __shared__ double res[4];
-  const int tid = threadIdx.x;
-  const double* srcs[4] = {d.colsse, d.colll, d.colkl, d.lpE_part};
-  const int lens[4] = {d.G, d.G, d.G, nblkE};
-  for (int j = 0; j < 4; ++j) {
-    double acc = 0.0;
-    for (int i = tid; i < lens[j]; i += FN_T) acc = acc + srcs[j][i];
-    const double r = block_tree<FN_T>(acc, buf, tid);
-    if (tid == 0) res[j] = r;
-    __syncthreads();
-  }
+// ---- k_reduce: canonical (W = 1024) reductions of one iteration's partial sums ----
+// blocks 0..3 reduce colsse, colll, colkl, lpE_part; block 0 also folds the per-factor log-prior of
+// P and sum(A).  Raw values go to raw[row][8]; k_compose turns them into metrics rows once per run.
+__global__ __launch_bounds__(RT) void k_reduce(Dev d, int row, int nblkE) {
+  __shared__ double buf[RT];
+  const int tid = threadIdx.x, j = blockIdx.x;
+  const double* src = j == 0 ? d.colsse : j == 1 ? d.colll : j == 2 ? d.colkl : d.lpE_part;
+  const long len = j < 3 ? d.G : nblkE;
+  const double r = canon1024_by256(src, len, 1, buf, tid);
   if (tid == 0) {
-    double lpP = 0.0, sumA = 0.0;
-    for (int n = 0; n < d.N; ++n) { lpP = lpP + d.lpPn[n]; sumA = sumA + d.A[n]; }
-    const double sse = res[0], ll = res[1], kl = res[2], lpE = res[3];
-    const double n_params = sumA * (double)(d.G + d.K);
-    double T = 1.0;
-    if (d.n_temperature > 0) {
-      long i = (long)t - 1;
-      if (i < 0) i = 0;
-      if (i >= d.n_temperature) i = d.n_temperature - 1;
-      T = d.temperature[i];
+    double* o = d.raw + (size_t)row * 8;
+    o[j] = r;
+    if (j == 0) {
+      double lpP = 0.0, sumA = 0.0;
+      for (int n = 0; n < d.N; ++n) { lpP = lpP + d.lpPn[n]; sumA = sumA + d.A[n]; }
+      o[4] = lpP; o[5] = sumA;
     }
-    double* o = d.metrics + (size_t)row * BNMF_NMETRIC;
-    o[0] = (double)t;
-    o[1] = dsqrt(sse / ((double)d.K * (double)d.G));
-    o[2] = kl;
-    o[3] = ll;
-    o[4] = ll + (lpP + lpE);
-    o[5] = n_params;
-    o[6] = -2.0 * ll + n_params * dlog((double)d.G);
-    o[7] = sumA;
-    o[8] = T;
-    o[9] = BNMF_NAN;
-    o[10] = BNMF_NAN;
   }
+}
+// compute_metrics_ R/utils.R:412-455, update_sample_metrics_ :339-348: one lane per recorded row
+__global__ void k_compose(Dev d, int nrows, uint32_t t0) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= nrows) return;
+  const double* r = d.raw + (size_t)row * 8;
+  const uint32_t t = t0 + (uint32_t)row;
+  const double sse = r[0], ll = r[1], kl = r[2], lpE = r[3], lpP = r[4], sumA = r[5];
+  const double n_params = sumA * (double)(d.G + d.K);
+  double T = 1.0;
+  if (d.n_temperature > 0) {
+    long i = (long)t - 1;
+    if (i < 0) i = 0;
+    if (i >= d.n_temperature) i = d.n_temperature - 1;
+    T = d.temperature[i];
+  }
+  double* o = d.metrics + (size_t)row * BNMF_NMETRIC;
+  o[0] = (double)t;
+  o[1] = dsqrt(sse / ((double)d.K * (double)d.G));
+  o[2] = kl;
+  o[3] = ll;
+  o[4] = ll + (lpP + lpE);
+  o[5] = n_params;
+  o[6] = -2.0 * ll + n_params * dlog((double)d.G);
+  o[7] = sumA;
+  o[8] = T;
+  o[9] = BNMF_NAN;
+  o[10] = BNMF_NAN;
 }
 
 // ---- constructor draws of the prior parameters from the hyper-priors ----
@@ -484,7 +515,7 @@ __global__ void k_init_gamma(Dev d, double* x, HRef hs, HRef hr, uint32_t var, c
   const int n = SIDE ? (int)(e % d.N) : (int)(e / d.K);
   if (!redraw[n]) return;
   Stream s(d.k0, d.k1, var, (uint32_t)e, 0u);
-  x[e] = rgamma(s, hy(hs, (int)e), hy(hr, (int)e));
+  x[e] = rgamma(s, hy(hs, (int)e), hy(hr, (int)e));   // x already points at slot(1)
 }
 
 // LUTs lgamma(m+1), log(max(m,1e-6)) for m = 0..maxM

@@ -51,7 +51,16 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(Dev d, uint32_t t, ZGeom z
   const int nthr = N - 1;
   uint32_t* ztarget = SAVE_Z ? zloc : zacc;
   const int gw = blockIdx.x * ZW + wave, nw = gridDim.x * ZW;
-  for (int g = gw; g < G; g += nw) {
+  // Phase-synchronised: all waves of the workgroup run phase 1 together and phase 2 together
+  // (ablate bit 512 turns the barriers off).  In phase 2 the SIMD then always has several waves in the
+  // compare/Philox stream, which hides the VALU->VCC hazard slots a lone wave would stall on.
+  const bool psync = !(ablate & 512);
+  const int nround = (G - (int)(blockIdx.x * ZW) + nw - 1) / nw;   // same for every wave of the workgroup
+  for (int rr = 0; rr < nround; ++rr) {
+    const int g = gw + rr * nw;
+    const bool active = g < G;
+    if (!active && !psync) break;
+    if (active) {
     // ---------------- phase 1: one pass over the factors, thresholds written as 128-bit rows
     double a_sse = 0.0, a_ll = 0.0, a_kl = 0.0;
     int carry = 0;
@@ -110,11 +119,14 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(Dev d, uint32_t t, ZGeom z
       if (kk < K) qoff[kk] = (uint32_t)(carry + incl - q) | ((uint32_t)((4 - (m & 3)) & 3) << 30);
       carry += __shfl(incl, 63, 64);
     }
-    const int Q = carry;
-    if (lane == 0) qoff[K] = (uint32_t)Q;
+    if (lane == 0) qoff[K] = (uint32_t)carry;
     a_sse = wave_tree64(a_sse); a_ll = wave_tree64(a_ll); a_kl = wave_tree64(a_kl);
     if (lane == 0) { d.colsse[g] = a_sse; d.colll[g] = a_ll; d.colkl[g] = a_kl; }
     wave_lds_fence();
+    }
+    if (psync) __syncthreads();
+    if (active) {
+    const int Q = (int)qoff[K];
     // ---------------- phase 2: contiguous quad range per lane, thresholds in registers; chunks of
     // <= 63 quads so that the packed 8-bit per-lane histogram cannot overflow
     const int per = (Q + 63) >> 6;
@@ -192,6 +204,8 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(Dev d, uint32_t t, ZGeom z
       }
     }
     wave_lds_fence();
+    }
+    if (psync) __syncthreads();
   }
   __syncthreads();
   for (int i = tid; i < K * N; i += ZT) {
