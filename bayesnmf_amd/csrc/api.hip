@@ -11,6 +11,7 @@
 #include <vector>
 #include "kernels.h"
 #include "zalloc_reg.h"
+#include "rank.h"
 
 using namespace bnmf;
 
@@ -40,7 +41,7 @@ struct bnmf_handle {
   int32_t *dM = nullptr, *dZsumK = nullptr, *dZsumG = nullptr, *dZ = nullptr;
   int* dR = nullptr; int* dRedraw = nullptr;
   double *dEsum = nullptr, *dPsum = nullptr, *dlpPn = nullptr, *dlpE = nullptr, *dcol = nullptr;
-  double *dLut = nullptr, *dTemp = nullptr, *dMetrics = nullptr, *dRaw = nullptr;
+  double *dLut = nullptr, *dTemp = nullptr, *dMetrics = nullptr, *dRaw = nullptr, *dRankCol = nullptr;
   size_t metrics_rows = 0;
   int maxM = 0, nblkE = 0;
   int z_grid = 0, z_zw = 8, z_ablate = 0; bool z_reg = false; size_t z_lds = 0; ZGeom zg{};
@@ -174,6 +175,7 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
   h->nblkE = (int)((N * G + ES_T - 1) / ES_T);
   HIPCHK(hipMalloc(&h->dlpE, h->nblkE * sizeof(double)));
   HIPCHK(hipMalloc(&h->dcol, 3 * G * sizeof(double)));
+  if (cfg->learning_rank) HIPCHK(hipMalloc(&h->dRankCol, 2 * G * sizeof(double)));
   HIPCHK(hipMalloc(&h->dLut, 2 * (size_t)(mx + 1) * sizeof(double)));
   if (cfg->n_temperature > 0 && cfg->temperature) {
     HIPCHK(hipMalloc(&h->dTemp, cfg->n_temperature * sizeof(double)));
@@ -236,7 +238,7 @@ int bnmf_destroy(bnmf_handle* h) {
   for (auto& a : h->arr) if (a.d) hipFree(a.d);
   hipFree(h->dM); hipFree(h->dZsumK); hipFree(h->dZsumG); if (h->dZ) hipFree(h->dZ);
   hipFree(h->dR); hipFree(h->dRedraw); hipFree(h->dEsum); hipFree(h->dPsum); hipFree(h->dlpPn);
-  hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics); hipFree(h->dRaw);
+  hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol);
   if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->side) hipStreamDestroy(h->side);
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -332,7 +334,6 @@ int bnmf_get_iter(bnmf_handle* h, int* iter) { if (!h || !iter) return fail(BNMF
 static int check_model_supported(const bnmf_handle* h) {
   const bnmf_config& c = h->cfg;
   if (c.likelihood != BNMF_POISSON || c.MH) return fail(BNMF_EMODEL, "this build implements the Poisson models without MH (gamma / exponential prior)");
-  if (c.learning_rank) return fail(BNMF_EMODEL, "learned rank is not implemented in this build yet");
   return 0;
 }
 static int need_hyper(bnmf_handle* h, std::initializer_list<int> ids) {
@@ -402,6 +403,17 @@ static int launch_zalloc(bnmf_handle* h, uint32_t t) {
     default: return sz ? launch_zalloc_t<true, 64>(h, t) : launch_zalloc_t<false, 64>(h, t);
   }
 }
+// sample_R then sample_An for n = 1..N (R/sample_params.R:67-74); 2 launches per factor
+static void launch_rank(bnmf_handle* h, uint32_t t) {
+  const int N = h->cfg.N, G = h->cfg.G;
+  hipLaunchKernelGGL(k_rank_R, dim3(1), dim3(64), 0, h->stream, h->dev, t, 0);
+  int grid = (G + 3) / 4; if (grid > 2048) grid = 2048;
+  const size_t lds = 4 * 2 * (size_t)N * sizeof(double);
+  for (int n = 0; n < N; ++n) {
+    hipLaunchKernelGGL(k_rank_ll, dim3(grid), dim3(RK_T), lds, h->stream, h->dev, n, h->dRankCol, h->dRankCol + G);
+    hipLaunchKernelGGL(k_rank_decide, dim3(1), dim3(RT), 0, h->stream, h->dev, t, n, h->dRankCol, h->dRankCol + G);
+  }
+}
 static void launch_reduce(bnmf_handle* h, int row) {
   hipLaunchKernelGGL(k_reduce, dim3(4), dim3(RT), 0, h->stream, h->dev, row, h->nblkE);
 }
@@ -412,7 +424,8 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   hipStreamWaitEvent(h->stream, h->ev_side, 0);            // prior params + Esum of iteration t ready
   tm.begin(KN_PDRAW, h->stream); launch_pdraw(h, t, 0); tm.end(KN_PDRAW, h->stream);
   tm.begin(KN_EDRAW, h->stream); launch_edraw(h, t, 0); tm.end(KN_EDRAW, h->stream);
-  launch_side(h, t + 1, tm);                               // overlaps the k_zalloc below
+  launch_side(h, t + 1, tm);                               // overlaps the rank update / k_zalloc below
+  if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
   tm.begin(KN_ZALLOC, h->stream); if (int rc = launch_zalloc(h, t)) return rc; tm.end(KN_ZALLOC, h->stream);
   tm.begin(KN_REDUCE, h->stream); launch_reduce(h, row); tm.end(KN_REDUCE, h->stream);
   return 0;
@@ -464,6 +477,10 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
   launch_pdraw(h, 1u, 1);
   launch_edraw(h, 1u, 1);
   launch_side(h, 2u, tm);
+  if (!haveA && c.learning_rank) {                            // R ~ Uniform{0..N}, A[n] ~ Bernoulli(pi(R))
+    hipLaunchKernelGGL(k_rank_R, dim3(1), dim3(64), 0, h->stream, h->dev, 1u, 1);
+    hipLaunchKernelGGL(k_rank_Aprior, dim3((N + 63) / 64), dim3(64), 0, h->stream, h->dev, 1u);
+  }
   if (int rc = launch_zalloc(h, 1u)) return rc;
   launch_reduce(h, 0);
   hipLaunchKernelGGL(k_compose, dim3(1), dim3(64), 0, h->stream, h->dev, 1, 1u);

@@ -408,22 +408,13 @@ static void sample_R(orc_handle* o, uint32_t t, int from_prior) {
   for (int r = 0; r <= N; ++r) { cum = cum + w[r]; if (target < cum) { pick = r; break; } }
   o->R = pick;
 }
-/* full Mhat = sum_n (P[k,n]*A[n])*E[n,g], sequential in n (get_Mhat_ R/utils.R:29-49) */
-static void compute_Mhat(orc_handle* o) {
-  const long K = o->cfg.K, G = o->cfg.G, N = o->cfg.N;
-  if (!o->Mhat) o->Mhat = (double*)malloc(8 * K * G);
-#pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
-  for (long g = 0; g < G; ++g)
-    for (long k = 0; k < K; ++k) {
-      double c = 0.0;
-      for (long n = 0; n < N; ++n) c = c + (AR(ID_P)[k + K * n] * AR(ID_A)[n]) * AR(ID_E)[n + N * g];
-      o->Mhat[k + K * g] = c;
-    }
-}
 static double pois_ll_cell(int32_t m, double mhat) {
   double mh = mhat < 1e-6 ? 1e-6 : mhat;
   return ((double)m * orc_log(mh) - mh) - orc_lgamma((double)m + 1.0);
 }
+/* sample_An R/sample_params.R:101-166: for n = 1..N in order, two full Poisson log-likelihoods
+ * (get_loglik(A = A0), get_loglik(A = A1), each with a fresh Mhat = P diag(A^j) E as in
+ * get_Mhat_ R/utils.R:29-49), reduced canonically (64-strided over k, then 1024-strided over g). */
 static void sample_A(orc_handle* o, uint32_t t, int from_prior) {
   const long K = o->cfg.K, G = o->cfg.G, N = o->cfg.N;
   double pi1 = prior_prob_1((double)o->R, (double)N);
@@ -432,7 +423,6 @@ static void sample_A(orc_handle* o, uint32_t t, int from_prior) {
     return;
   }
   double T = temp_at(o, (int)t);
-  compute_Mhat(o);
   double* col0 = (double*)malloc(8 * G * 2);
   double* col1 = col0 + G;
   for (long n = 0; n < N; ++n) {
@@ -441,12 +431,17 @@ static void sample_A(orc_handle* o, uint32_t t, int from_prior) {
     for (long g = 0; g < G; ++g) {
       double l0[4096], l1[4096];
       for (long k = 0; k < K; ++k) {
-        double pe = AR(ID_P)[k + K * n] * AR(ID_E)[n + N * g];
-        double base = (a_old != 0.0) ? o->Mhat[k + K * g] - pe : o->Mhat[k + K * g];
-        double m1 = base + pe;
+        double c0 = 0.0, c1 = 0.0;
+        for (long j = 0; j < N; ++j) {
+          double pe = AR(ID_P)[k + K * j];
+          double e = AR(ID_E)[j + N * g];
+          double a0 = (j == n) ? 0.0 : AR(ID_A)[j], a1 = (j == n) ? 1.0 : AR(ID_A)[j];
+          c0 = c0 + (pe * a0) * e;
+          c1 = c1 + (pe * a1) * e;
+        }
         int32_t m = o->M[k + K * g];
-        l0[k] = pois_ll_cell(m, base);
-        l1[k] = pois_ll_cell(m, m1);
+        l0[k] = pois_ll_cell(m, c0);
+        l1[k] = pois_ll_cell(m, c1);
       }
       col0[g] = orc_canon_sum(l0, K, 1, 64);
       col1[g] = orc_canon_sum(l1, K, 1, 64);
@@ -471,17 +466,7 @@ static void sample_A(orc_handle* o, uint32_t t, int from_prior) {
       else if (lp1 > lp0) p = 1.0; else if (lp1 < lp0) p = 0.0; else p = 0.5;
     }
     orc_stream s = ST(o, V_A, (uint32_t)n, t);
-    double a_new = (orc_runif(&s) < p) ? 1.0 : 0.0;
-    AR(ID_A)[n] = a_new;
-    if (a_new != a_old) {
-#pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
-      for (long g = 0; g < G; ++g)
-        for (long k = 0; k < K; ++k) {
-          double pe = AR(ID_P)[k + K * n] * AR(ID_E)[n + N * g];
-          double base = (a_old != 0.0) ? o->Mhat[k + K * g] - pe : o->Mhat[k + K * g];
-          o->Mhat[k + K * g] = (a_new != 0.0) ? base + pe : base;
-        }
-    }
+    AR(ID_A)[n] = (orc_runif(&s) < p) ? 1.0 : 0.0;
   }
   free(col0);
 }

@@ -137,3 +137,39 @@ def test_headline_size_invariants_stats_mode():
     assert np.array_equal(e.get("ZsumG").sum(1), M.sum(1))
     assert np.all(np.isfinite(met[:, :9]))
     assert met[-1, 1] < met[0, 1]   # RMSE goes down
+
+
+def _temp_schedule(n):
+    return np.concatenate([np.zeros(3), 10.0 ** np.linspace(-6, 0, 40), np.ones(max(0, n - 43))])
+
+
+@pytest.mark.parametrize("method", ["SBFI", "BFI"])
+def test_learned_rank_chain_bitexact(method):
+    """sample_R / sample_An (R/sample_params.R:101-241): A, R, and everything downstream bit-exact
+    against the oracle over a tempered run (config-4 model at a size the oracle finishes in seconds)."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    M, _, _ = synth_counts(96, 120, 3, 20250221)
+    N = 8
+    temp = _temp_schedule(200)
+    o = O.Oracle(M, N, prior="gamma", learning_rank=True, rank_method=method, seed=5, temperature=temp, save_Z=True, nthreads=8)
+    e = Engine(M, N, prior="gamma", learning_rank=True, rank_method=method, seed=5, temperature=temp, save_Z=True)
+    apply_hyperprior_params(o, "gamma", M, N)
+    apply_hyperprior_params(e, "gamma", M, N)
+    r0, r1 = o.init(), e.init()
+    assert np.array_equal(o.get("A"), e.get("A")) and o.get("R")[0] == e.get("R")[0]
+    assert np.array_equal(r0[:9].view(np.uint64), r1[:9].view(np.uint64))
+    ranks = []
+    for step in range(4):
+        mo, me = o.run(15), e.run(15)
+        assert np.array_equal(o.get("A"), e.get("A")), f"A differs at block {step}"
+        assert o.get("R")[0] == e.get("R")[0]
+        assert np.array_equal(o.get("Z").astype(np.int32), e.get("Z"))
+        for nm in ("P", "E", "Alpha_e", "Beta_p"):
+            assert np.array_equal(o.get(nm).view(np.uint64), e.get(nm).view(np.uint64)), nm
+        assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64))
+        ranks.append(me[-1, 7])
+    Z, A = e.get("Z"), e.get("A")[0]
+    assert (Z[:, A == 0, :] == 0).all()          # excluded factors receive no counts (SURVEY §8c(1))
+    assert (Z.sum(1) == M).all() or A.sum() == 0
