@@ -25,7 +25,7 @@ static int fail(int code, const char* fmt, ...) {
 enum { KN_PDRAW = 0, KN_EDRAW = 1, KN_ZALLOC = 2, KN_REDUCE = 3, KN_SIDE = 4, KN_RANK = 5, KN_MH = 6, KN_OTHER = 7 };
 static const char* k_names[BNMF_NKERNEL] = {"k_pdraw", "k_edraw", "k_zalloc", "k_reduce", "k_side", "k_rank", "k_mh", "other"};
 
-struct Arr { double* d = nullptr; size_t n = 0; int stride = 1; bool set = false; std::vector<int> redraw; };
+struct Arr { double* d = nullptr; size_t n = 0; int stride = 1; bool set = false; std::vector<int> redraw; double* ring = nullptr; };
 
 struct bnmf_handle {
   bnmf_config cfg{};
@@ -235,7 +235,7 @@ int bnmf_destroy(bnmf_handle* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->side) hipStreamSynchronize(h->side);
-  for (auto& a : h->arr) if (a.d) hipFree(a.d);
+  for (auto& a : h->arr) { if (a.d) hipFree(a.d); if (a.ring) hipFree(a.ring); }
   hipFree(h->dM); hipFree(h->dZsumK); hipFree(h->dZsumG); if (h->dZ) hipFree(h->dZ);
   hipFree(h->dR); hipFree(h->dRedraw); hipFree(h->dEsum); hipFree(h->dPsum); hipFree(h->dlpPn);
   hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol);
@@ -414,6 +414,35 @@ static void launch_rank(bnmf_handle* h, uint32_t t) {
     hipLaunchKernelGGL(k_rank_decide, dim3(1), dim3(RT), 0, h->stream, h->dev, t, n, h->dRankCol, h->dRankCol + G);
   }
 }
+// ids recorded per iteration (names(self$params) + names(self$prior_params), R/bayesNMF_sampler.R:245-252)
+static std::vector<int> recorded_ids(const bnmf_handle* h) {
+  std::vector<int> ids = {BNMF_P, BNMF_E, BNMF_A, BNMF_R};
+  if (h->cfg.prior == BNMF_GAMMA) ids.insert(ids.end(), {BNMF_ALPHA_P, BNMF_BETA_P, BNMF_ALPHA_E, BNMF_BETA_E});
+  else if (h->cfg.prior == BNMF_EXPONENTIAL) ids.insert(ids.end(), {BNMF_LAMBDA_P, BNMF_LAMBDA_E});
+  else ids.insert(ids.end(), {BNMF_MU_P, BNMF_SIGMASQ_P, BNMF_MU_E, BNMF_SIGMASQ_E});
+  if (h->cfg.MH) ids.insert(ids.end(), {BNMF_ACC_P, BNMF_ACC_E});
+  if (h->cfg.likelihood == BNMF_NORMAL) ids.push_back(BNMF_SIGMASQ);
+  return ids;
+}
+static int launch_record(bnmf_handle* h, uint32_t t) {
+  const int W = h->cfg.window;
+  if (W <= 0) return 0;
+  const size_t slot = (size_t)((t - 1) % (uint32_t)W);
+  RecArgs ra{}; ra.n = 0; ra.R = nullptr; ra.Rdst = nullptr;
+  for (int id : recorded_ids(h)) {
+    Arr& a = h->arr[id];
+    const size_t len = id_len(h, id);
+    if (!a.ring) { HIPCHK(hipMalloc(&a.ring, (size_t)W * len * sizeof(double))); }
+    if (id == BNMF_R) { ra.R = h->dR; ra.Rdst = a.ring + slot; continue; }
+    if (!a.d) continue;
+    ra.src[ra.n] = a.d + (is_prior_param(id) ? (size_t)(t & 1u) * len : 0);
+    ra.dst[ra.n] = a.ring + slot * len;
+    ra.len[ra.n] = len;
+    ra.n++;
+  }
+  hipLaunchKernelGGL(k_record, dim3(512), dim3(256), 0, h->stream, ra);
+  return 0;
+}
 static void launch_reduce(bnmf_handle* h, int row) {
   hipLaunchKernelGGL(k_reduce, dim3(4), dim3(RT), 0, h->stream, h->dev, row, h->nblkE);
 }
@@ -426,6 +455,7 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   tm.begin(KN_EDRAW, h->stream); launch_edraw(h, t, 0); tm.end(KN_EDRAW, h->stream);
   launch_side(h, t + 1, tm);                               // overlaps the rank update / k_zalloc below
   if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
+  tm.begin(KN_OTHER, h->stream); if (int rc = launch_record(h, t)) return rc; tm.end(KN_OTHER, h->stream);
   tm.begin(KN_ZALLOC, h->stream); if (int rc = launch_zalloc(h, t)) return rc; tm.end(KN_ZALLOC, h->stream);
   tm.begin(KN_REDUCE, h->stream); launch_reduce(h, row); tm.end(KN_REDUCE, h->stream);
   return 0;
@@ -481,6 +511,7 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
     hipLaunchKernelGGL(k_rank_R, dim3(1), dim3(64), 0, h->stream, h->dev, 1u, 1);
     hipLaunchKernelGGL(k_rank_Aprior, dim3((N + 63) / 64), dim3(64), 0, h->stream, h->dev, 1u);
   }
+  if (int rc = launch_record(h, 1u)) return rc;
   if (int rc = launch_zalloc(h, 1u)) return rc;
   launch_reduce(h, 0);
   hipLaunchKernelGGL(k_compose, dim3(1), dim3(64), 0, h->stream, h->dev, 1, 1u);
@@ -523,9 +554,21 @@ int bnmf_profile(bnmf_handle* h, int n_iter, int converged, double* out_ms) {
   return 0;
 }
 int bnmf_window(bnmf_handle* h, int id, int last_n, double* out) {
-  (void)id; (void)last_n; (void)out;
-  if (!h) return fail(BNMF_EINVAL, "bnmf_window: null handle");
-  return fail(BNMF_ESTATE, "bnmf_window: sample window not implemented in this build yet");
+  if (!h || !out) return fail(BNMF_EINVAL, "bnmf_window: null argument");
+  const int W = h->cfg.window;
+  if (W <= 0) return fail(BNMF_ESTATE, "bnmf_window: the handle was created with window = 0");
+  if (last_n < 1 || last_n > W || last_n > h->iter) return fail(BNMF_ESIZE, "bnmf_window: last_n = %d but only min(window = %d, iter = %d) samples are kept", last_n, W, h->iter);
+  const Arr& a = h->arr[id];
+  const size_t len = id_len(h, id);
+  if (!a.ring || len == 0) return fail(BNMF_EUNSET, "bnmf_window: id %d is not recorded for this model", id);
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < last_n; ++i) {
+    const int it = h->iter - last_n + 1 + i;                  // oldest first
+    const size_t slot = (size_t)((it - 1) % W);
+    HIPCHK(hipMemcpy(out + (size_t)i * len, a.ring + slot * len, len * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return 0;
 }
 
 // ---- device-side probes for the parity tests ----

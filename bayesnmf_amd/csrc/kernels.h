@@ -504,6 +504,16 @@ __global__ void k_compose(Dev d, int nrows, uint32_t t0) {
   o[10] = BNMF_NAN;
 }
 
+// ---- k_record: record_sample (R/bayesNMF_sampler.R:651-672) into the device ring buffer ----
+// Copies the iteration's P, E, A, R and prior parameters into slot (t-1) % window of each ring.
+struct RecArgs { const double* src[12]; double* dst[12]; size_t len[12]; int n; const int* R; double* Rdst; };
+__global__ void k_record(RecArgs a) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  for (int j = 0; j < a.n; ++j)
+    for (size_t i = tid; i < a.len[j]; i += nth) a.dst[j][i] = a.src[j][i];
+  if (tid == 0 && a.Rdst) *a.Rdst = (double)*a.R;
+}
+
 // ---- constructor draws of the prior parameters from the hyper-priors ----
 // init_prior_params_ R/sample_priors.R:15-141 (all three families are rgamma(shape, rate) draws
 // for the Gamma / Exponential priors).  redraw[n] != 0: column n (P side) / row n (E side) missing.

@@ -99,12 +99,11 @@ def main():
     dt = time.perf_counter() - t0
     barrier()
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    rows = torch.tensor(met[-1], dtype=torch.float64, device="cuda")
     gathered = None
     if dist is not None:
+        from bayesnmf_amd.multichain import gather_rows
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        gathered = [torch.empty_like(rows) for _ in range(world)]
-        dist.all_gather(gathered, rows)            # RCCL: gather the chains' last metrics rows
+        gathered = gather_rows(met[-1:], dist, device="cuda")   # RCCL: gather the chains' last metrics rows
     tmax = float(tmax.item())
 
     # roofline of the dominant kernel (k_zalloc), HIP events on the chain's own stream
@@ -134,7 +133,7 @@ def main():
             "kernel_ms": prof,
         }
         if gathered is not None:
-            out["chains_final_logposterior"] = [float(g[4].item()) for g in gathered]
+            out["chains_final_logposterior"] = [float(g[0][4]) for g in gathered]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(M, N_)
         print(json.dumps(out))

@@ -173,3 +173,82 @@ def test_learned_rank_chain_bitexact(method):
     Z, A = e.get("Z"), e.get("A")[0]
     assert (Z[:, A == 0, :] == 0).all()          # excluded factors receive no counts
     assert (Z.sum(1) == M).all() or A.sum() == 0
+
+
+def test_window_ring_buffer():
+    """record_sample (R/bayesNMF_sampler.R:651-672): the device ring returns the last samples,
+    oldest first, identical to what the chain held at those iterations."""
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    M, _, _ = synth_counts(96, 64, 4, 3)
+    e = Engine(M, 5, prior="gamma", seed=2, window=4)
+    apply_hyperprior_params(e, "gamma", M, 5)
+    e.init()
+    hist = {}
+    for it in range(2, 9):
+        e.run(1)
+        hist[it] = {nm: e.get(nm).copy() for nm in ("P", "E", "Alpha_e", "A")}
+    assert e.iter == 8
+    for nm in ("P", "E", "Alpha_e", "A"):
+        win = e.window(nm, 4)
+        for j, it in enumerate(range(5, 9)):
+            assert np.array_equal(win[j], hist[it][nm]), (nm, it)
+    with pytest.raises(Exception):
+        e.window("P", 5)
+
+
+@pytest.mark.parametrize("name,prior,lr", [("pg_k8_g6_n3", "gamma", False), ("pe_k8_g6_n3", "exponential", False),
+                                           ("pg_sbfi_k12_g10_n4", "gamma", True)])
+def test_engine_matches_golden_vectors(name, prior, lr):
+    """The HIP engine against the committed golden vectors (tests/golden/make_golden.py)."""
+    import os
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import apply_hyperprior_params
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    M, N = g["M"], g["P"].shape[1]
+    e = Engine(M, N, prior=prior, learning_rank=lr, seed=9 if lr else 7, temperature=g["temperature"] if lr else None, save_Z=True)
+    apply_hyperprior_params(e, prior, M, N)
+    rows = [e.init()] + list(e.run(g["metrics"].shape[0] - 1))
+    assert np.array_equal(np.array(rows)[:, :9].view(np.uint64), g["metrics"][:, :9].view(np.uint64))
+    for nm in ("P", "E", "A"):
+        assert np.array_equal(e.get(nm).view(np.uint64), g[nm].view(np.uint64)), nm
+    assert np.array_equal(e.get("ZsumK"), g["ZsumK"].astype(np.int32)) and np.array_equal(e.get("ZsumG"), g["ZsumG"].astype(np.int32))
+    assert np.array_equal(e.get("Z").sum(1), g["Zsum_check"].astype(np.int64))
+
+
+def test_ragged_and_edge_shapes():
+    """Shapes that stress the lane/row mapping: K not a multiple of 64, K < 64, N = 1, N = 25 (largest
+    register-path N), N = 26 (LDS path), G smaller than the number of waves, zero rows/columns."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import apply_hyperprior_params
+    rng = np.random.default_rng(8)
+    for (K, G, N) in [(5, 3, 1), (70, 9, 2), (130, 40, 25), (33, 17, 26), (200, 5, 7)]:
+        M = rng.poisson(rng.gamma(0.5, 20.0, size=(K, G))).astype(np.int32)
+        M[:, G // 2] = 0
+        M[K // 2, :] = 0
+        o = O.Oracle(M, N, prior="gamma", seed=4, save_Z=True, nthreads=4)
+        e = Engine(M, N, prior="gamma", seed=4, save_Z=True)
+        apply_hyperprior_params(o, "gamma", M, N)
+        apply_hyperprior_params(e, "gamma", M, N)
+        o.init(); e.init()
+        mo, me = o.run(6), e.run(6)
+        assert np.array_equal(o.get("Z").astype(np.int32), e.get("Z")), (K, G, N)
+        assert np.array_equal(o.get("E").view(np.uint64), e.get("E").view(np.uint64)), (K, G, N)
+        assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), (K, G, N)
+
+
+def test_bayesNMF_end_to_end_gpu(tmp_path):
+    """bayesNMF() on the engine: fixed-rank Poisson-Gamma recovers the generating signatures."""
+    from bayesnmf_amd.sampler import bayesNMF
+    from bayesnmf_amd.convergence import new_convergence_control
+    from bayesnmf_amd.setup import synth_counts
+    M, Pt, _ = synth_counts(96, 64, 4, 12)
+    cc = new_convergence_control(MAP_over=200, MAP_every=100, miniters=300, maxiters=800)
+    s = bayesNMF(M, 4, prior="gamma", convergence_control=cc, output_dir=str(tmp_path / "o"), periodic_save=False,
+                 save_all_samples=False)
+    P = s.MAP["P"] / np.linalg.norm(s.MAP["P"], axis=0)
+    cos = (P.T @ (Pt / np.linalg.norm(Pt, axis=0))).max(0)
+    assert (cos > 0.95).all(), cos
+    assert len(s.samples["P"]) == 200
+    s.close()

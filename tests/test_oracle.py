@@ -1,0 +1,180 @@
+"""CPU tests of the oracle: primitives pinned against mpmath / scipy, samplers against their analytic
+laws (fixed-seed KS), the sweep against exact integer invariants and numpy/scipy metrics, and the
+committed golden vectors.  (The reference has no tests or fixtures of its own: SURVEY.md §4.)"""
+import os
+
+import numpy as np
+import pytest
+import scipy.special as sp
+import scipy.stats as st
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_philox_known_answers(oracle_lib):
+    O = oracle_lib   # Random123 kat_vectors, philox4x32-10
+    assert O.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert O.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_math_accuracy(oracle_lib):
+    import mpmath as mp
+    O = oracle_lib
+    rng = np.random.default_rng(0)
+    x = np.concatenate([10 ** rng.uniform(-300, 300, 300), rng.uniform(0.5, 2, 300), [1.0, 2.0, 1e-320]])
+    assert np.max(np.abs(O.vec("log", x) - np.log(x)) / np.maximum(np.abs(np.log(x)), 1e-300)) < 4e-16
+    assert O.vec("log", [1.0])[0] == 0.0
+    x = np.concatenate([rng.uniform(-745, 709, 400), rng.uniform(-1, 1, 200), [0.0]])
+    assert np.max(np.abs(O.vec("exp", x) / np.exp(x) - 1)) < 4e-16
+    x = np.concatenate([10 ** rng.uniform(-3, 7, 200), rng.uniform(0.001, 20, 200), [1, 2, 8, 7.9999, 1e-3, 1e4]])
+    ref = np.array([float(mp.loggamma(mp.mpf(float(v)))) for v in x])
+    assert np.max(np.abs(O.vec("lgamma", x) - ref) / np.maximum(1, np.abs(ref))) < 1e-14
+    ref = np.array([float(mp.digamma(mp.mpf(float(v)))) for v in x])
+    assert np.max(np.abs(O.vec("digamma", x) - ref) / np.maximum(1, np.abs(ref))) < 1e-14
+    p = np.concatenate([rng.uniform(0, 1, 400), 10 ** rng.uniform(-300, -1, 200), 1 - 10 ** rng.uniform(-16, -1, 100)])
+    p = p[(p > 0) & (p < 1)]
+    assert np.max(np.abs(O.vec("qnorm", p) - sp.ndtri(p)) / np.maximum(np.abs(sp.ndtri(p)), 1e-300)) < 5e-15
+    z = rng.uniform(-38, 10, 500)
+    assert np.max(np.abs(O.vec("log_pnorm", z) - sp.log_ndtr(z)) / np.abs(sp.log_ndtr(z))) < 1e-14
+
+
+def test_canonical_sum(oracle_lib):
+    O = oracle_lib
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(5000) * 10 ** rng.uniform(-3, 3, 5000)
+    for W in (64, 256, 1024):
+        s = O.canon_sum(x, W)
+        assert abs(s - np.sum(x.astype(np.longdouble))) < 1e-9 * np.sum(np.abs(x))
+    acc = [sum(x[i::64][j] for j in range(len(x[i::64]))) for i in range(64)]   # python floats: same order
+    a = [0.0 + 0.0] * 64
+    for i in range(64):
+        s_ = 0.0
+        for v in x[i::64]:
+            s_ = s_ + v
+        a[i] = s_
+    h = 32
+    while h >= 1:
+        for i in range(h):
+            a[i] = a[i] + a[i + h]
+        h //= 2
+    assert O.canon_sum(x, 64) == a[0]
+
+
+@pytest.mark.parametrize("a,r", [(0.05, 2.0), (0.7, 1.0), (6.5, 10.0), (65.0, 10.0), (4000.0, 0.5)])
+def test_rgamma_law(oracle_lib, a, r):   # stats::rgamma(shape, rate)
+    x = oracle_lib.rgamma(np.full(20000, a), r, it=3)
+    assert st.kstest(x, st.gamma(a, scale=1 / r).cdf).pvalue > 1e-3
+
+
+@pytest.mark.parametrize("mu,sd", [(-3.0, 1.0), (-0.4, 1.0), (0.5, 2.0), (5.0, 1.0), (-30.0, 2.0)])
+def test_rtnorm_law(oracle_lib, mu, sd):   # truncnorm::rtruncnorm(a = 0, b = Inf)
+    x = oracle_lib.rtnorm0(np.full(20000, mu), sd, it=4)
+    assert x.min() >= 0
+    assert st.kstest(x, st.truncnorm((0 - mu) / sd, np.inf, loc=mu, scale=sd).cdf).pvalue > 1e-3
+
+
+@pytest.mark.parametrize("c,tau,xp", [(65.0, 6.0, 6.5), (65.0, 6.0, 5000.0), (1.0, 0.5, 1.0), (0.3, 2.0, 1.0),
+                                      (200.0, -1.0, 10.0), (65.0, -8.5, 100.0), (2.0, 700.0, 1.0), (3000.0, 0.1, 1.0)])
+def test_ralpha_law(oracle_lib, c, tau, xp):
+    """The armspp::arms target of R/sample_priors.R:356-397 on [1e-3, 1e4], against its numerical CDF."""
+    x, att = oracle_lib.ralpha(np.full(20000, c), tau, xp, it=5)
+    xs = np.concatenate([np.linspace(1e-3, 1, 100001), np.linspace(1, 50, 200001)[1:], np.linspace(50, 1e4, 400001)[1:]])
+    h = (c - 1) * np.log(xs) - tau * xs - sp.gammaln(xs)
+    f = np.exp(h - h.max())
+    cdf = np.concatenate([[0], np.cumsum(0.5 * (f[1:] + f[:-1]) * np.diff(xs))])
+    cdf /= cdf[-1]
+    assert st.kstest(x, lambda v: np.interp(v, xs, cdf)).pvalue > 1e-3
+    assert att.mean() < 1.4 and att.max() < 40     # 3-tangent hull: acceptance ~ 0.886
+
+
+def test_ralpha_robust_grid(oracle_lib):
+    rng = np.random.default_rng(1)
+    n = 20000
+    x, att = oracle_lib.ralpha(10 ** rng.uniform(-2, 3.5, n), rng.uniform(-9, 50, n), 10 ** rng.uniform(-3, 4, n), it=6)
+    assert np.isfinite(x).all() and (x >= 1e-3).all() and (x <= 1e4).all()
+    assert att.max() < 60
+
+
+def _chain(oracle_lib, prior, **kw):
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    M, Pt, Et = synth_counts(96, 100, 5, 20250219)
+    o = oracle_lib.Oracle(M, 5, prior=prior, seed=1, save_Z=True, nthreads=4, **kw)
+    apply_hyperprior_params(o, prior, M, 5)
+    return M, Pt, o
+
+
+@pytest.mark.parametrize("prior", ["gamma", "exponential"])
+def test_sweep_invariants_and_metrics(oracle_lib, prior):
+    """Config 1 (K=96, G=100, N=5): exact integer invariants of sample_Zkg and the metrics row
+    of compute_metrics_ against numpy/scipy."""
+    M, Pt, o = _chain(oracle_lib, prior)
+    o.init()
+    met = o.run(120)
+    Z = o.get("Z")
+    assert (Z >= 0).all() and (Z.sum(1) == M).all()
+    assert np.array_equal(o.get("ZsumK"), Z.sum(0)) and np.array_equal(o.get("ZsumG"), Z.sum(2))
+    P, E = o.get("P"), o.get("E")
+    Mh = P @ E
+    row = met[-1]
+    assert np.isclose(row[1], np.sqrt(((Mh - M) ** 2).mean()), rtol=1e-12)
+    assert np.isclose(row[3], st.poisson.logpmf(M, np.maximum(Mh, 1e-6)).sum(), rtol=1e-12)
+    Mt = np.maximum(M, 1e-6)
+    assert np.isclose(row[2], (Mt * np.log(Mt / np.maximum(Mh, 1e-6))).sum(), rtol=1e-10)
+    if prior == "gamma":
+        lp = st.gamma.logpdf(P, o.get("Alpha_p"), scale=1 / o.get("Beta_p")).sum() + \
+            st.gamma.logpdf(E, o.get("Alpha_e"), scale=1 / o.get("Beta_e")).sum()
+    else:
+        lp = st.expon.logpdf(P, scale=1 / o.get("Lambda_p")).sum() + st.expon.logpdf(E, scale=1 / o.get("Lambda_e")).sum()
+    assert np.isclose(row[4], row[3] + lp, rtol=1e-12)
+    assert row[5] == 5 * (100 + 96) and np.isclose(row[6], -2 * row[3] + row[5] * np.log(100))
+    # signatures are recovered (cosine to the generating P)
+    Pn = P / np.linalg.norm(P, axis=0)
+    cos = (Pn.T @ (Pt / np.linalg.norm(Pt, axis=0))).max(0)
+    assert (cos > 0.95).all()
+
+
+def test_zero_and_degenerate_cells(oracle_lib):
+    """Empty counts, all-zero columns, and A with zeros: Z = 0 wherever A[n] = 0 (R/sample_params.R:257-261)."""
+    from bayesnmf_amd.setup import apply_hyperprior_params
+    rng = np.random.default_rng(5)
+    M = rng.poisson(3.0, size=(7, 9)).astype(np.int32)
+    M[:, 2] = 0
+    M[3, :] = 0
+    o = oracle_lib.Oracle(M, 4, prior="gamma", seed=3, save_Z=True)
+    apply_hyperprior_params(o, "gamma", M, 4)
+    o.set("A", [1.0, 0.0, 1.0, 0.0])
+    o.init()
+    o.run(5)
+    Z = o.get("Z")
+    assert (Z[:, 1, :] == 0).all() and (Z[:, 3, :] == 0).all()
+    assert (Z.sum(1) == M).all()
+
+
+@pytest.mark.parametrize("name,prior,lr", [("pg_k8_g6_n3", "gamma", False), ("pe_k8_g6_n3", "exponential", False),
+                                           ("pg_sbfi_k12_g10_n4", "gamma", True)])
+def test_golden_chain(oracle_lib, name, prior, lr):
+    from bayesnmf_amd.setup import apply_hyperprior_params
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    M = g["M"]
+    N = g["P"].shape[1]
+    temp = g["temperature"] if lr else None
+    seed = 9 if lr else 7
+    o = oracle_lib.Oracle(M, N, prior=prior, learning_rank=lr, seed=seed, temperature=temp, save_Z=True)
+    apply_hyperprior_params(o, prior, M, N)
+    rows = [o.init()] + list(o.run(g["metrics"].shape[0] - 1))
+    assert np.array_equal(np.array(rows)[:, :9].view(np.uint64), g["metrics"][:, :9].view(np.uint64))
+    for nm in ("P", "E", "A", "ZsumK", "ZsumG"):
+        assert np.array_equal(o.get(nm), g[nm]), nm
+
+
+def test_golden_math_kat(oracle_lib):
+    O = oracle_lib
+    g = np.load(os.path.join(GOLD, "math_kat.npz"))
+    for fn, xin in (("log", "x"), ("lgamma", "x"), ("digamma", "x"), ("qnorm", "p")):
+        assert np.array_equal(O.vec(fn, g[xin]).view(np.uint64), g[fn].view(np.uint64)), fn
+    assert np.array_equal(O.vec("exp", g["xin_exp"]).view(np.uint64), g["exp"].view(np.uint64))
+    assert np.array_equal(O.rgamma(np.full(16, 6.5), 10.0, var=2, it=3), g["rgamma"])
+    assert np.array_equal(O.rtnorm0(np.linspace(-3, 3, 16), 1.0, var=3, it=4), g["rtnorm0"])
+    assert np.array_equal(O.ralpha(np.full(16, 65.0), 6.0, 6.5, var=5, it=5)[0], g["ralpha"])
