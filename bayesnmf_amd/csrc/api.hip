@@ -12,6 +12,7 @@
 #include "kernels.h"
 #include "zalloc_reg.h"
 #include "rank.h"
+#include "mh.h"
 
 using namespace bnmf;
 
@@ -42,6 +43,7 @@ struct bnmf_handle {
   int* dR = nullptr; int* dRedraw = nullptr;
   double *dEsum = nullptr, *dPsum = nullptr, *dlpPn = nullptr, *dlpE = nullptr, *dcol = nullptr;
   double *dLut = nullptr, *dTemp = nullptr, *dMetrics = nullptr, *dRaw = nullptr, *dRankCol = nullptr;
+  double *dProp = nullptr, *dPart = nullptr, *dAccPn = nullptr, *dAccEpart = nullptr; int* dNzE = nullptr; int mh_S = 1;
   size_t metrics_rows = 0;
   int maxM = 0, nblkE = 0;
   int z_grid = 0, z_zw = 8, z_ablate = 0; bool z_reg = false; size_t z_lds = 0; ZGeom zg{};
@@ -176,6 +178,14 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
   HIPCHK(hipMalloc(&h->dlpE, h->nblkE * sizeof(double)));
   HIPCHK(hipMalloc(&h->dcol, 3 * G * sizeof(double)));
   if (cfg->learning_rank) HIPCHK(hipMalloc(&h->dRankCol, 2 * G * sizeof(double)));
+  if (cfg->MH) {
+    h->mh_S = (int)((G + MH_SEG - 1) / MH_SEG);
+    HIPCHK(hipMalloc(&h->dProp, K * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dPart, K * (size_t)h->mh_S * 4 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dAccPn, N * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dAccEpart, (size_t)h->nblkE * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dNzE, N * sizeof(int)));
+  }
   HIPCHK(hipMalloc(&h->dLut, 2 * (size_t)(mx + 1) * sizeof(double)));
   if (cfg->n_temperature > 0 && cfg->temperature) {
     HIPCHK(hipMalloc(&h->dTemp, cfg->n_temperature * sizeof(double)));
@@ -239,6 +249,7 @@ int bnmf_destroy(bnmf_handle* h) {
   hipFree(h->dM); hipFree(h->dZsumK); hipFree(h->dZsumG); if (h->dZ) hipFree(h->dZ);
   hipFree(h->dR); hipFree(h->dRedraw); hipFree(h->dEsum); hipFree(h->dPsum); hipFree(h->dlpPn);
   hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol);
+  if (h->dProp) { hipFree(h->dProp); hipFree(h->dPart); hipFree(h->dAccPn); hipFree(h->dAccEpart); hipFree(h->dNzE); }
   if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->side) hipStreamDestroy(h->side);
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -333,7 +344,7 @@ int bnmf_get_iter(bnmf_handle* h, int* iter) { if (!h || !iter) return fail(BNMF
 // ------------------------------------------------------------------ launch helpers
 static int check_model_supported(const bnmf_handle* h) {
   const bnmf_config& c = h->cfg;
-  if (c.likelihood != BNMF_POISSON || c.MH) return fail(BNMF_EMODEL, "this build implements the Poisson models without MH (gamma / exponential prior)");
+  if (c.likelihood != BNMF_POISSON) return fail(BNMF_EMODEL, "this build implements the Poisson-likelihood models (Normal likelihood: next round)");
   return 0;
 }
 static int need_hyper(bnmf_handle* h, std::initializer_list<int> ids) {
@@ -444,7 +455,48 @@ static int launch_record(bnmf_handle* h, uint32_t t) {
   return 0;
 }
 static void launch_reduce(bnmf_handle* h, int row) {
-  hipLaunchKernelGGL(k_reduce, dim3(4), dim3(RT), 0, h->stream, h->dev, row, h->nblkE);
+  hipLaunchKernelGGL(k_reduce, dim3(h->cfg.MH ? 5 : 4), dim3(RT), 0, h->stream, h->dev, row, h->nblkE, (const double*)h->dAccPn, (const double*)h->dAccEpart);
+}
+// P and E updates of the MH models (R/sample_params.R:56-64 with sample_Pn/_En -> *_normal -> MH_*_poisson)
+static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged) {
+  const int K = h->cfg.K, N = h->cfg.N, G = h->cfg.G, S = h->mh_S;
+  hipMemsetAsync(h->dNzE, 0, N * sizeof(int), h->stream);
+  hipLaunchKernelGGL(k_mh_nz, dim3(N), dim3(256), 0, h->stream, h->dev, h->dNzE);
+  const int nb = (K * S + 3) / 4;
+  const size_t lds = 4 * (size_t)N * sizeof(double);
+  double* accP = h->arr[BNMF_ACC_P].d; double* accE = h->arr[BNMF_ACC_E].d;
+  for (int n = 0; n < N; ++n) {
+    hipLaunchKernelGGL(k_mh_prow_partial<0>, dim3(nb), dim3(MHP_T), lds, h->stream, h->dev, n, S, (const double*)h->dProp, (const int*)h->dNzE, h->dPart);
+    hipLaunchKernelGGL(k_mh_prow_finish<0>, dim3((K + 63) / 64), dim3(64), 0, h->stream, h->dev, t, n, S, converged, h->dProp, (const int*)h->dNzE, (const double*)h->dPart, accP);
+    if (converged) {
+      hipLaunchKernelGGL(k_mh_prow_partial<1>, dim3(nb), dim3(MHP_T), lds, h->stream, h->dev, n, S, (const double*)h->dProp, (const int*)h->dNzE, h->dPart);
+      hipLaunchKernelGGL(k_mh_prow_finish<1>, dim3((K + 63) / 64), dim3(64), 0, h->stream, h->dev, t, n, S, converged, h->dProp, (const int*)h->dNzE, (const double*)h->dPart, accP);
+    }
+  }
+  int grid = (G + 3) / 4; if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(k_mh_ecol<false>, dim3(grid), dim3(MHE_T), 4 * 2 * (size_t)N * sizeof(double), h->stream, h->dev, t, converged, accE);
+}
+static void launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells) {
+  const int N = h->cfg.N, G = h->cfg.G;
+  if (cells) {
+    int grid = (G + 3) / 4; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_mh_ecol<true>, dim3(grid), dim3(MHE_T), 4 * 2 * (size_t)N * sizeof(double), h->stream, h->dev, t, 0, h->arr[BNMF_ACC_E].d);
+  }
+  hipLaunchKernelGGL(k_lp_p, dim3(N), dim3(64), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_P].d, h->dAccPn);
+  hipLaunchKernelGGL(k_lp_e, dim3(h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_E].d, h->dAccEpart);
+}
+static int sweep_mh(bnmf_handle* h, int row, int converged, Timer& tm) {
+  h->iter += 1;
+  const uint32_t t = (uint32_t)h->iter;
+  if (!h->side_valid) launch_side(h, t, tm);
+  hipStreamWaitEvent(h->stream, h->ev_side, 0);
+  tm.begin(KN_MH, h->stream); launch_mh_PE(h, t, converged); tm.end(KN_MH, h->stream);
+  launch_side(h, t + 1, tm);
+  if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
+  if (int rc = launch_record(h, t)) return rc;
+  tm.begin(KN_OTHER, h->stream); launch_mh_metrics(h, t, h->cfg.learning_rank != 0); tm.end(KN_OTHER, h->stream);
+  tm.begin(KN_REDUCE, h->stream); launch_reduce(h, row); tm.end(KN_REDUCE, h->stream);
+  return 0;
 }
 static int sweep(bnmf_handle* h, int row, Timer& tm) {
   h->iter += 1;
@@ -495,10 +547,30 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));   // redraw is reused by the next spec
   }
+  if (c.prior == BNMF_TRUNCNORMAL) {
+    if (int rc = need_hyper(h, {BNMF_HM_P, BNMF_HS_P, BNMF_HA_P, BNMF_HB_P, BNMF_HM_E, BNMF_HS_E, BNMF_HA_E, BNMF_HB_E})) return rc;
+    struct TS { int id; uint32_t var; int side, is_mu; };
+    const TS ts[4] = {{BNMF_MU_P, BNMF_V_MU_P, 0, 1}, {BNMF_SIGMASQ_P, BNMF_V_SIGSQ_P, 0, 0}, {BNMF_MU_E, BNMF_V_MU_E, 1, 1}, {BNMF_SIGMASQ_E, BNMF_V_SIGSQ_E, 1, 0}};
+    for (const TS& sp : ts) {
+      Arr& a = h->arr[sp.id];
+      std::vector<int> redraw(N, 1);
+      if (a.set) redraw = a.redraw.empty() ? std::vector<int>(N, 0) : a.redraw;
+      if (int rc = ensure(h, sp.id)) return rc;
+      refresh_dev(h);
+      HIPCHK(hipMemcpyAsync(h->dRedraw, redraw.data(), N * sizeof(int), hipMemcpyHostToDevice, h->stream));
+      const long len = sp.side ? NG : KN;
+      double* slot1 = a.d + (size_t)len;
+      if (sp.side) hipLaunchKernelGGL(k_init_tn<1>, dim3((len + 255) / 256), dim3(256), 0, h->stream, h->dev, slot1, sp.is_mu, sp.var, h->dRedraw);
+      else hipLaunchKernelGGL(k_init_tn<0>, dim3((len + 255) / 256), dim3(256), 0, h->stream, h->dev, slot1, sp.is_mu, sp.var, h->dRedraw);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(h->stream));
+    }
+  }
   const bool haveP = h->arr[BNMF_P].set, haveE = h->arr[BNMF_E].set, haveA = h->arr[BNMF_A].set;
   if (int rc = ensure(h, BNMF_P)) return rc;
   if (int rc = ensure(h, BNMF_E)) return rc;
   if (int rc = ensure(h, BNMF_A)) return rc;
+  if (c.MH) { if (int rc = ensure(h, BNMF_ACC_P)) return rc; if (int rc = ensure(h, BNMF_ACC_E)) return rc; }
   if (!haveA) { std::vector<double> ones(N, 1.0); HIPCHK(hipMemcpy(h->arr[BNMF_A].d, ones.data(), N * sizeof(double), hipMemcpyHostToDevice)); }
   refresh_dev(h);
   h->iter = 1;
@@ -512,7 +584,8 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
     hipLaunchKernelGGL(k_rank_Aprior, dim3((N + 63) / 64), dim3(64), 0, h->stream, h->dev, 1u);
   }
   if (int rc = launch_record(h, 1u)) return rc;
-  if (int rc = launch_zalloc(h, 1u)) return rc;
+  if (c.MH) launch_mh_metrics(h, 1u, true);
+  else if (int rc = launch_zalloc(h, 1u)) return rc;
   launch_reduce(h, 0);
   hipLaunchKernelGGL(k_compose, dim3(1), dim3(64), 0, h->stream, h->dev, 1, 1u);
   HIPCHK(hipGetLastError());
@@ -524,7 +597,6 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
 }
 
 static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, Timer& tm) {
-  (void)converged;
   if (!h) return fail(BNMF_EINVAL, "bnmf_run: null handle");
   if (!h->inited) return fail(BNMF_ESTATE, "bnmf_run: call bnmf_init first");
   if (n_iter < 0) return fail(BNMF_EINVAL, "bnmf_run: n_iter < 0");
@@ -532,7 +604,7 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
   HIPCHK(hipSetDevice(h->device));
   if (int rc = ensure_metrics(h, (size_t)n_iter)) return rc;
   const uint32_t t0 = (uint32_t)h->iter + 1;
-  for (int i = 0; i < n_iter; ++i) if (int rc = sweep(h, i, tm)) return rc;
+  for (int i = 0; i < n_iter; ++i) if (int rc = (h->cfg.MH ? sweep_mh(h, i, converged, tm) : sweep(h, i, tm))) return rc;
   hipLaunchKernelGGL(k_compose, dim3((n_iter + 63) / 64), dim3(64), 0, h->stream, h->dev, n_iter, t0);
   HIPCHK(hipGetLastError());
   if (metrics) HIPCHK(hipMemcpyAsync(metrics, h->dMetrics, (size_t)n_iter * BNMF_NMETRIC * sizeof(double), hipMemcpyDeviceToHost, h->stream));

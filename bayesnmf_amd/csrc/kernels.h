@@ -459,19 +459,20 @@ __global__ __launch_bounds__(ZT) void k_zalloc(Dev d, uint32_t t, ZGeom zg, int 
 // ---- k_reduce: canonical (W = 1024) reductions of one iteration's partial sums ----
 // blocks 0..3 reduce colsse, colll, colkl, lpE_part; block 0 also folds the per-factor log-prior of
 // P and sum(A).  Raw values go to raw[row][8]; k_compose turns them into metrics rows once per run.
-__global__ __launch_bounds__(RT) void k_reduce(Dev d, int row, int nblkE) {
+__global__ __launch_bounds__(RT) void k_reduce(Dev d, int row, int nblkE, const double* accPn, const double* accE_part) {
   __shared__ double buf[RT];
   const int tid = threadIdx.x, j = blockIdx.x;
-  const double* src = j == 0 ? d.colsse : j == 1 ? d.colll : j == 2 ? d.colkl : d.lpE_part;
+  const double* src = j == 0 ? d.colsse : j == 1 ? d.colll : j == 2 ? d.colkl : j == 3 ? d.lpE_part : accE_part;
   const long len = j < 3 ? d.G : nblkE;
   const double r = canon1024_by256(src, len, 1, buf, tid);
   if (tid == 0) {
     double* o = d.raw + (size_t)row * 8;
-    o[j] = r;
+    o[j < 4 ? j : 6] = r;
     if (j == 0) {
       double lpP = 0.0, sumA = 0.0;
       for (int n = 0; n < d.N; ++n) { lpP = lpP + d.lpPn[n]; sumA = sumA + d.A[n]; }
       o[4] = lpP; o[5] = sumA;
+      if (accPn) { double sp = 0.0; for (int n = 0; n < d.N; ++n) if (d.A[n] == 1.0) sp = sp + accPn[n]; o[7] = sp; }
     }
   }
 }
@@ -500,8 +501,8 @@ __global__ void k_compose(Dev d, int nrows, uint32_t t0) {
   o[6] = -2.0 * ll + n_params * dlog((double)d.G);
   o[7] = sumA;
   o[8] = T;
-  o[9] = BNMF_NAN;
-  o[10] = BNMF_NAN;
+  o[9] = d.MH ? r[7] / ((double)d.K * sumA) : BNMF_NAN;    // mean acceptance over active factors (R/utils.R:444-452)
+  o[10] = d.MH ? r[6] / ((double)d.G * sumA) : BNMF_NAN;
 }
 
 // ---- k_record: record_sample (R/bayesNMF_sampler.R:651-672) into the device ring buffer ----

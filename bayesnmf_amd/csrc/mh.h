@@ -1,0 +1,261 @@
+// bayesnmf_amd/csrc/mh.h — Poisson likelihood with Metropolis-Hastings (truncnormal / exponential prior).
+//
+// sample_Pn -> sample_Pn_normal(as_proposal = TRUE) -> MH_Pn_poisson (R/sample_Pn.R:11-42, :54-87,
+// :132-187, :199-248) and the E mirror (R/sample_En.R).  Factors are updated for n = 1..N in order and
+// every evaluation uses a FRESH Mhat = P diag(A) E of the current state (as get_Mhat() does), so no
+// K x G matrix is kept.
+//   P side: the conditional of row k needs sums over all columns g -> k_mh_prow_partial (one wave per
+//           (row, 512-column segment), lanes 64-strided over g) + k_mh_prow_finish (one lane per row:
+//           segments added in ascending order, draw / accept).  2 launches per factor before
+//           convergence, 4 after.
+//   E side: the conditional of E[n,g] needs sums over k only -> ONE launch, one wave per column doing
+//           all N sequential updates locally (k_mh_ecol), followed by the column's metric terms.
+// All sums follow the canonical orders of the stream spec, so proposals and accept/reject masks are
+// bit-identical to the oracle.
+#pragma once
+
+namespace bnmf {
+
+constexpr int MH_SEG = 512;
+
+BNMF_DEV double dpois_log(int m, double lam, double lgf) {      // get_loglik_ poisson branch R/utils.R:98-106
+  const double mh = lam < 1e-6 ? 1e-6 : lam;
+  return ((double)m * dlog(mh) - mh) - lgf;
+}
+BNMF_DEV double dnorm_log(double x, double mean, double var) { // dnorm(x, mean, sqrt(var), log = TRUE)
+  const double sd = dsqrt(var);
+  const double z = (x - mean) / sd;
+  return (-0.91893853320467274178 - dlog(sd)) - 0.5 * (z * z);
+}
+// proposal from the Normal full conditional (or the prior): get_mu_sigmasq_*_normal :132-187
+template <int SIDE>
+BNMF_DEV double mh_prior_or_cond(const Dev& d, int e, uint32_t t, bool use_prior, double num1, double den) {
+  if (use_prior) return prior_draw<SIDE>(d, e, t);
+  double mu, var;
+  if (d.prior == BNMF_EXPONENTIAL) {
+    const double la = slot<SIDE>(d, SIDE ? d.Lam_e : d.Lam_p, t)[e];
+    mu = (num1 - la) / den; var = 1.0 / den;
+  } else {
+    const double mp = slot<SIDE>(d, SIDE ? d.Mu_e : d.Mu_p, t)[e], sg = slot<SIDE>(d, SIDE ? d.Sig_e : d.Sig_p, t)[e];
+    const double den2 = den + 1.0 / sg;
+    mu = (num1 + mp / sg) / den2; var = 1.0 / den2;
+  }
+  Stream s(d.k0, d.k1, SIDE ? BNMF_V_E : BNMF_V_P, (uint32_t)e, t);
+  return rtnorm0(s, mu, dsqrt(var));
+}
+
+// nzE[n] = number of non-zero entries in row n of E (all(E[n,] == 0) test of sample_Pn_normal :56)
+__global__ void k_mh_nz(Dev d, int* nzE) {
+  const int n = blockIdx.x;
+  int c = 0;
+  for (int g = threadIdx.x; g < d.G; g += blockDim.x) c += d.E[n + (size_t)d.N * g] != 0.0 ? 1 : 0;
+  if (c) atomicAdd(&nzE[n], c);
+}
+
+// MODE 0: partial sums of num1, den for the proposal of column n;  MODE 1: partial sums of the four
+// log-likelihood rows of the MH ratio (needs prop[k]).  One wave per (row k, segment s).
+constexpr int MHP_T = 256;
+template <int MODE>
+__global__ __launch_bounds__(MHP_T) void k_mh_prow_partial(Dev d, int n, int S, const double* prop, const int* nzE, double* part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = d.K, G = d.G, N = d.N;
+  const int item = blockIdx.x * (MHP_T / 64) + wave;
+  if (item >= K * S) return;
+  const double a_n = d.A[n];
+  if (a_n == 0.0 || (MODE == 0 && nzE[n] == 0)) return;  // prior draw: no sums needed
+  const int k = item / S, s = item - k * S;
+  double* pa = (double*)smem + (size_t)wave * N;       // [N] P[k,j] * A[j] of this row
+  for (int j = lane; j < N; j += 64) pa[j] = d.P[k + (size_t)K * j] * d.A[j];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const double pn_prop = MODE == 1 ? prop[k] * a_n : 0.0;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  const int gbeg = s * MH_SEG, gend = min(G, gbeg + MH_SEG);
+  for (int g = gbeg + lane; g < gend; g += 64) {
+    const double* Eg = d.E + (size_t)N * g;
+    const int m = d.M[k + (size_t)K * g];
+    if (MODE == 0) {
+      double mh = 0.0, mno = 0.0;
+      for (int j = 0; j < N; ++j) { const double term = pa[j] * Eg[j]; mh = mh + term; mno = mno + (j == n ? 0.0 * Eg[j] : term); }
+      const double en = Eg[n];
+      a0 = a0 + en * (((double)m - mno) / mh);          // :155-161
+      a1 = a1 + (a_n * (en * en)) * (1.0 / mh);          // :163-169
+    } else {
+      double m0 = 0.0, m1 = 0.0;
+      for (int j = 0; j < N; ++j) { const double e = Eg[j]; m0 = m0 + pa[j] * e; m1 = m1 + (j == n ? pn_prop : pa[j]) * e; }
+      const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
+      const double lgf = d.lgfact[mi];
+      a0 = a0 + dpois_log(m, m1, lgf);                                  // loglik_poisson_new :216-218
+      a1 = a1 + dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);         // loglik_normal_old  :219-224
+      a2 = a2 + dpois_log(m, m0, lgf);                                  // loglik_poisson_old :213-215
+      a3 = a3 + dnorm_log((double)m, m1, m0 < 1.0 ? 1.0 : m0);         // loglik_normal_new  :225-231
+    }
+  }
+  a0 = wave_tree64(a0); a1 = wave_tree64(a1);
+  if (MODE == 1) { a2 = wave_tree64(a2); a3 = wave_tree64(a3); }
+  if (lane == 0) { double* o = part + ((size_t)k * S + s) * 4; o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; }
+}
+template <int MODE>
+__global__ void k_mh_prow_finish(Dev d, uint32_t t, int n, int S, int converged, double* prop, const int* nzE, const double* part, double* accP) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= d.K) return;
+  const int e = k + d.K * n;
+  const double a_n = d.A[n];
+  if (MODE == 0) {
+    if (a_n == 0.0) { d.P[e] = prior_draw<0>(d, e, t); return; }        // sample_Pn :12
+    const bool allzero = nzE[n] == 0;
+    double num1 = 0.0, den = 0.0;
+    if (!allzero) for (int s = 0; s < S; ++s) { num1 = num1 + part[((size_t)k * S + s) * 4]; den = den + part[((size_t)k * S + s) * 4 + 1]; }
+    const double pr = mh_prior_or_cond<0>(d, e, t, allzero, num1, den);
+    prop[k] = pr;
+    if (!converged) { d.P[e] = pr; accP[e] = 1.0; }                       // MH_Pn_poisson :201-204
+  } else {
+    if (a_n == 0.0) return;
+    double A_ = 0.0, B_ = 0.0, C_ = 0.0, D_ = 0.0;
+    for (int s = 0; s < S; ++s) { const double* q = part + ((size_t)k * S + s) * 4; A_ = A_ + q[0]; B_ = B_ + q[1]; C_ = C_ + q[2]; D_ = D_ + q[3]; }
+    double ratio = dexp((A_ + B_) - (C_ + D_));
+    if (ratio > 1.0) ratio = 1.0;                                         // pmin(accept_ratio, 1) :239
+    accP[e] = ratio;
+    Stream s(d.k0, d.k1, BNMF_V_MHU_P, (uint32_t)e, t);
+    const double u = runif(s);
+    if (u < ratio) d.P[e] = prop[k];
+  }
+}
+
+// E side: one wave per column, all factors in order; METRICS_ONLY skips the updates (iteration 1).
+constexpr int MHE_T = 256;
+template <bool METRICS_ONLY>
+__global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int converged, double* accE) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = d.K, G = d.G, N = d.N;
+  const int KR = (K + 63) >> 6;
+  double* ec = (double*)smem + (size_t)wave * 2 * N;     // [N] current column of E
+  double* av = ec + N;                                     // [N] A
+  const int gw = blockIdx.x * (MHE_T / 64) + wave, nw = gridDim.x * (MHE_T / 64);
+  for (int g = gw; g < G; g += nw) {
+    for (int j = lane; j < N; j += 64) { ec[j] = d.E[j + (size_t)N * g]; av[j] = d.A[j]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (!METRICS_ONLY) {
+      for (int n = 0; n < N; ++n) {
+        const int e = n + N * g;
+        const double a_n = av[n];
+        double enew;
+        if (a_n == 0.0) enew = prior_draw<1>(d, e, t);                    // sample_En :12
+        else {
+          double s1 = 0.0, s2 = 0.0;
+          bool anynz = false;
+          for (int r = 0; r < KR; ++r) {
+            const int kk = (r << 6) + lane;
+            if (kk < K) {
+              const double pn = d.P[kk + (size_t)K * n];
+              anynz = anynz || (pn != 0.0);
+              double mh = 0.0, mno = 0.0;
+              for (int j = 0; j < N; ++j) { const double term = (d.P[kk + (size_t)K * j] * av[j]) * ec[j]; mh = mh + term; mno = mno + (j == n ? (d.P[kk + (size_t)K * j] * 0.0) * ec[j] : term); }
+              const int m = d.M[kk + (size_t)K * g];
+              s1 = s1 + pn * (((double)m - mno) / mh);
+              s2 = s2 + (a_n * (pn * pn)) * (1.0 / mh);
+            }
+          }
+          const bool allzero = __ballot(anynz) == 0ull;
+          s1 = __shfl(wave_tree64(s1), 0, 64); s2 = __shfl(wave_tree64(s2), 0, 64);
+          const double pr = mh_prior_or_cond<1>(d, e, t, allzero, allzero ? 0.0 : s1, allzero ? 0.0 : s2);
+          if (!converged) { enew = pr; if (lane == 0) accE[e] = 1.0; }
+          else {
+            const double eold = ec[n];
+            double A_ = 0.0, B_ = 0.0, C_ = 0.0, D_ = 0.0;
+            for (int r = 0; r < KR; ++r) {
+              const int kk = (r << 6) + lane;
+              if (kk < K) {
+                double m0 = 0.0, m1 = 0.0;
+                for (int j = 0; j < N; ++j) { const double pa = d.P[kk + (size_t)K * j] * av[j]; m0 = m0 + pa * ec[j]; m1 = m1 + pa * (j == n ? pr : ec[j]); }
+                const int m = d.M[kk + (size_t)K * g];
+                const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
+                const double lgf = d.lgfact[mi];
+                A_ = A_ + dpois_log(m, m1, lgf);
+                B_ = B_ + dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);
+                C_ = C_ + dpois_log(m, m0, lgf);
+                D_ = D_ + dnorm_log((double)m, m1, m0 < 1.0 ? 1.0 : m0);
+              }
+            }
+            A_ = __shfl(wave_tree64(A_), 0, 64); B_ = __shfl(wave_tree64(B_), 0, 64);
+            C_ = __shfl(wave_tree64(C_), 0, 64); D_ = __shfl(wave_tree64(D_), 0, 64);
+            double ratio = dexp((A_ + B_) - (C_ + D_));
+            if (ratio > 1.0) ratio = 1.0;
+            if (lane == 0) accE[e] = ratio;
+            Stream s(d.k0, d.k1, BNMF_V_MHU_E, (uint32_t)e, t);
+            const double u = runif(s);
+            enew = (u < ratio) ? pr : eold;
+          }
+        }
+        if (lane == 0) { ec[n] = enew; d.E[e] = enew; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    // metric terms of the column with the fresh Mhat (R/utils.R:412-471)
+    double a_sse = 0.0, a_ll = 0.0, a_kl = 0.0;
+    for (int r = 0; r < KR; ++r) {
+      const int kk = (r << 6) + lane;
+      if (kk < K) {
+        double c = 0.0;
+        for (int j = 0; j < N; ++j) c = c + (d.P[kk + (size_t)K * j] * av[j]) * ec[j];
+        const int m = d.M[kk + (size_t)K * g];
+        const double dd = c - (double)m;
+        const double mh = c < 1e-6 ? 1e-6 : c;
+        const double lmh = dlog(mh);
+        const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
+        const double mt = m < 1 ? 1e-6 : (double)m;
+        a_sse = a_sse + dd * dd;
+        a_ll = a_ll + (((double)m * lmh - mh) - d.lgfact[mi]);
+        a_kl = a_kl + mt * (d.logm[mi] - lmh);
+      }
+    }
+    a_sse = wave_tree64(a_sse); a_ll = wave_tree64(a_ll); a_kl = wave_tree64(a_kl);
+    if (lane == 0) { d.colsse[g] = a_sse; d.colll[g] = a_ll; d.colkl[g] = a_kl; }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// log-prior and mean-acceptance partial sums for the models whose P/E are not drawn by k_pdraw/k_edraw
+__global__ void k_lp_p(Dev d, uint32_t t, const double* accP, double* accPn) {
+  const int n = blockIdx.x, lane = threadIdx.x;      // 64 lanes
+  double a = 0.0, b = 0.0;
+  for (int k = lane; k < d.K; k += 64) { const int e = k + d.K * n; a = a + prior_logdens<0>(d, e, d.P[e], t); if (accP) b = b + accP[e]; }
+  a = wave_tree64(a); b = wave_tree64(b);
+  if (lane == 0) { d.lpPn[n] = a; if (accPn) accPn[n] = b; }
+}
+__global__ __launch_bounds__(ES_T) void k_lp_e(Dev d, uint32_t t, const double* accE, double* accE_part) {
+  __shared__ double buf[ES_T];
+  const int tid = threadIdx.x;
+  const long e = (long)blockIdx.x * ES_T + tid;
+  double lp = 0.0, ac = 0.0;
+  if (e < (long)d.lenE) {
+    lp = prior_logdens<1>(d, (int)e, d.E[e], t);
+    if (accE) ac = (d.A[e % d.N] == 1.0) ? accE[e] : 0.0;
+  }
+  const double r = block_tree<ES_T>(lp, buf, tid);
+  if (tid == 0) d.lpE_part[blockIdx.x] = r;
+  if (accE) {
+    __syncthreads();
+    const double r2 = block_tree<ES_T>(ac, buf, tid);
+    if (tid == 0) accE_part[blockIdx.x] = r2;
+  }
+}
+
+// constructor draws of the truncated-normal prior parameters (R/sample_priors.R:32-61)
+template <int SIDE>
+__global__ void k_init_tn(Dev d, double* x, int is_mu, uint32_t var, const int* redraw) {
+  const long len = SIDE ? (long)d.lenE : (long)d.lenP;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= len) return;
+  const int n = SIDE ? (int)(e % d.N) : (int)(e / d.K);
+  if (!redraw[n]) return;
+  Stream s(d.k0, d.k1, var, (uint32_t)e, 0u);
+  if (is_mu) x[e] = hy(SIDE ? d.hM_e : d.hM_p, (int)e) + dsqrt(hy(SIDE ? d.hS_e : d.hS_p, (int)e)) * rnorm_std(s);
+  else x[e] = rinvgamma(s, hy(SIDE ? d.hA_e : d.hA_p, (int)e), hy(SIDE ? d.hB_e : d.hB_p, (int)e));
+}
+
+}  // namespace bnmf

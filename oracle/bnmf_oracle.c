@@ -471,6 +471,176 @@ static void sample_A(orc_handle* o, uint32_t t, int from_prior) {
   free(col0);
 }
 
+/* ================= Poisson likelihood with Metropolis-Hastings (truncnormal / exponential prior) =====
+ * sample_Pn -> sample_Pn_normal(as_proposal = TRUE) -> MH_Pn_poisson (R/sample_Pn.R:11-42, :54-87,
+ * :132-187, :199-248) and the E mirror (R/sample_En.R).  Columns/rows are updated for n = 1..N in order;
+ * every evaluation uses a FRESH Mhat = P diag(A) E of the current state, as get_Mhat() does.
+ * Canonical sums: over k (column sums) 64-strided + tree; over g (row sums) segments of 512 columns,
+ * each 64-strided + tree, segments added in ascending order. */
+#define ORC_SEG 512
+static double canon_rowsum(const double* x /* G values */, long G) {
+  double acc = 0.0;
+  for (long s0 = 0; s0 < G; s0 += ORC_SEG) {
+    long len = G - s0 < ORC_SEG ? G - s0 : ORC_SEG;
+    acc = acc + orc_canon_sum(x + s0, len, 1, 64);
+  }
+  return acc;
+}
+static inline double mhat_cell(const orc_handle* o, long k, long g, long skip /* -1: none */, const double* Prow_override, long n_over) {
+  const long K = o->cfg.K, N = o->cfg.N;
+  double c = 0.0;
+  for (long j = 0; j < N; ++j) {
+    double a = (j == skip) ? 0.0 : o->a[ID_A].p[j];
+    double pkj = (Prow_override && j == n_over) ? *Prow_override : o->a[ID_P].p[k + K * j];
+    c = c + (pkj * a) * o->a[ID_E].p[j + N * g];
+  }
+  return c;
+}
+static inline double dpois_log(int32_t m, double lam) {   /* get_loglik_ poisson branch R/utils.R:98-106 */
+  double mh = lam < 1e-6 ? 1e-6 : lam;
+  return ((double)m * orc_log(mh) - mh) - orc_lgamma((double)m + 1.0);
+}
+static inline double dnorm_log(double x, double mean, double var) {   /* dnorm(x, mean, sqrt(var), log = TRUE) */
+  double sd = sqrt(var);
+  double z = (x - mean) / sd;
+  return (-0.91893853320467274178 - orc_log(sd)) - 0.5 * (z * z);
+}
+static void mh_prior_or_cond(orc_handle* o, int side, long e, uint32_t t, int use_prior, double num1, double den, double* out) {
+  if (use_prior) { *out = prior_draw(o, side, e, t); return; }
+  double mu, var;
+  if (o->cfg.prior == PRIOR_EXPONENTIAL) {
+    double la = (side ? AR(ID_LAMBDA_E) : AR(ID_LAMBDA_P))[e];
+    mu = (num1 - la) / den; var = 1.0 / den;
+  } else {
+    double mp = (side ? AR(ID_MU_E) : AR(ID_MU_P))[e], sg = (side ? AR(ID_SIGSQ_E) : AR(ID_SIGSQ_P))[e];
+    double den2 = den + 1.0 / sg;
+    mu = (num1 + mp / sg) / den2; var = 1.0 / den2;
+  }
+  orc_stream s = ST(o, side ? V_E : V_P, (uint32_t)e, t);
+  *out = orc_rtnorm0(&s, mu, sqrt(var));
+}
+static void sample_P_mh(orc_handle* o, uint32_t t) {
+  const long K = o->cfg.K, G = o->cfg.G, N = o->cfg.N;
+  double* P = AR(ID_P);
+  double* acc = ensure(o, ID_ACC_P);
+  double* tmp = (double*)malloc(8 * G * 6 * (size_t)(o->cfg.nthreads > 0 ? o->cfg.nthreads : 1));
+  double* prop = (double*)malloc(8 * K);
+  for (long n = 0; n < N; ++n) {
+    double a_n = AR(ID_A)[n];
+    if (a_n == 0.0) { for (long k = 0; k < K; ++k) P[k + K * n] = prior_draw(o, 0, k + K * n, t); continue; }   /* sample_Pn :12 */
+    int allzero = 1;
+    for (long g = 0; g < G; ++g) if (AR(ID_E)[n + N * g] != 0.0) { allzero = 0; break; }
+#pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
+    for (long k = 0; k < K; ++k) {
+      int tid = 0;
+#ifdef _OPENMP
+      tid = omp_get_thread_num();
+#endif
+      double* x1 = tmp + (size_t)tid * 6 * G; double* x2 = x1 + G;
+      double num1 = 0.0, den = 0.0;
+      if (!allzero) {
+        for (long g = 0; g < G; ++g) {
+          double mh = mhat_cell(o, k, g, -1, NULL, 0), mno = mhat_cell(o, k, g, n, NULL, 0);
+          double en = AR(ID_E)[n + N * g];
+          x1[g] = en * (((double)o->M[k + K * g] - mno) / mh);        /* :155-161 */
+          x2[g] = (a_n * (en * en)) * (1.0 / mh);                      /* :163-169 */
+        }
+        num1 = canon_rowsum(x1, G); den = canon_rowsum(x2, G);
+      }
+      mh_prior_or_cond(o, 0, k + K * n, t, allzero, num1, den, &prop[k]);
+    }
+    if (!o->converged) {                                               /* MH_Pn_poisson :201-204 */
+      for (long k = 0; k < K; ++k) { P[k + K * n] = prop[k]; acc[k + K * n] = 1.0; }
+      continue;
+    }
+#pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
+    for (long k = 0; k < K; ++k) {
+      int tid = 0;
+#ifdef _OPENMP
+      tid = omp_get_thread_num();
+#endif
+      double* y = tmp + (size_t)tid * 6 * G;
+      for (long g = 0; g < G; ++g) {
+        double m0 = mhat_cell(o, k, g, -1, NULL, 0), m1 = mhat_cell(o, k, g, -1, &prop[k], n);
+        int32_t m = o->M[k + K * g];
+        y[g] = dpois_log(m, m1);                                       /* loglik_poisson_new :216-218 */
+        y[G + g] = dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);     /* loglik_normal_old :219-224 */
+        y[2 * G + g] = dpois_log(m, m0);                               /* loglik_poisson_old :213-215 */
+        y[3 * G + g] = dnorm_log((double)m, m1, m0 < 1.0 ? 1.0 : m0); /* loglik_normal_new :225-231 */
+      }
+      double A_ = canon_rowsum(y, G), B_ = canon_rowsum(y + G, G), C_ = canon_rowsum(y + 2 * G, G), D_ = canon_rowsum(y + 3 * G, G);
+      double ratio = orc_exp((A_ + B_) - (C_ + D_));
+      if (ratio > 1.0) ratio = 1.0;                                    /* pmin(accept_ratio, 1) :239 */
+      acc[k + K * n] = ratio;
+      orc_stream s = ST(o, V_MHU_P, (uint32_t)(k + K * n), t);
+      double u = orc_runif(&s);
+      prop[k] = (u < ratio) ? prop[k] : P[k + K * n];
+    }
+    for (long k = 0; k < K; ++k) P[k + K * n] = prop[k];
+  }
+  free(tmp); free(prop);
+}
+static void sample_E_mh(orc_handle* o, uint32_t t) {
+  const long K = o->cfg.K, G = o->cfg.G, N = o->cfg.N;
+  double* E = AR(ID_E);
+  double* acc = ensure(o, ID_ACC_E);
+  for (long n = 0; n < N; ++n) {
+    double a_n = AR(ID_A)[n];
+    int allzero = 1;
+    for (long k = 0; k < K; ++k) if (AR(ID_P)[k + K * n] != 0.0) { allzero = 0; break; }
+#pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
+    for (long g = 0; g < G; ++g) {
+      long e = n + N * g;
+      if (a_n == 0.0) { E[e] = prior_draw(o, 1, e, t); continue; }     /* sample_En :12 */
+      double x1[4096], x2[4096], y[4 * 4096];
+      double num1 = 0.0, den = 0.0;
+      if (!allzero) {
+        for (long k = 0; k < K; ++k) {
+          double mh = mhat_cell(o, k, g, -1, NULL, 0), mno = mhat_cell(o, k, g, n, NULL, 0);
+          double pn = AR(ID_P)[k + K * n];
+          x1[k] = pn * (((double)o->M[k + K * g] - mno) / mh);
+          x2[k] = (a_n * (pn * pn)) * (1.0 / mh);
+        }
+        num1 = orc_canon_sum(x1, K, 1, 64); den = orc_canon_sum(x2, K, 1, 64);
+      }
+      double prop;
+      mh_prior_or_cond(o, 1, e, t, allzero, num1, den, &prop);
+      if (!o->converged) { E[e] = prop; acc[e] = 1.0; continue; }
+      double eold = E[e];
+      for (long k = 0; k < K; ++k) {
+        double m0 = mhat_cell(o, k, g, -1, NULL, 0);
+        E[e] = prop;
+        double m1 = mhat_cell(o, k, g, -1, NULL, 0);
+        E[e] = eold;
+        int32_t m = o->M[k + K * g];
+        y[k] = dpois_log(m, m1);
+        y[K + k] = dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);
+        y[2 * K + k] = dpois_log(m, m0);
+        y[3 * K + k] = dnorm_log((double)m, m1, m0 < 1.0 ? 1.0 : m0);
+      }
+      double A_ = orc_canon_sum(y, K, 1, 64), B_ = orc_canon_sum(y + K, K, 1, 64), C_ = orc_canon_sum(y + 2 * K, K, 1, 64), D_ = orc_canon_sum(y + 3 * K, K, 1, 64);
+      double ratio = orc_exp((A_ + B_) - (C_ + D_));
+      if (ratio > 1.0) ratio = 1.0;
+      acc[e] = ratio;
+      orc_stream s = ST(o, V_MHU_E, (uint32_t)e, t);
+      double u = orc_runif(&s);
+      E[e] = (u < ratio) ? prop : eold;
+    }
+  }
+}
+/* per-cell metric terms for the models without Z (fresh Mhat) */
+static void metrics_cells_mh(orc_handle* o) {
+  const long K = o->cfg.K, G = o->cfg.G;
+#pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
+  for (long g = 0; g < G; ++g) {
+    double a[4096], b[4096], c[4096];
+    for (long k = 0; k < K; ++k) cell_terms(o, o->M[k + K * g], mhat_cell(o, k, g, -1, NULL, 0), &a[k], &b[k], &c[k]);
+    o->colsse[g] = orc_canon_sum(a, K, 1, 64);
+    o->colll[g] = orc_canon_sum(b, K, 1, 64);
+    o->colkl[g] = orc_canon_sum(c, K, 1, 64);
+  }
+}
+
 /* ---- metrics row: compute_metrics_ R/utils.R:412-455, update_sample_metrics_ :339-348 ---- */
 static void metrics_row(orc_handle* o, double* row) {
   const long K = o->cfg.K, G = o->cfg.G, N = o->cfg.N;
@@ -506,6 +676,22 @@ static void metrics_row(orc_handle* o, double* row) {
   row[7] = sumA;
   row[8] = temp_at(o, o->iter);
   row[9] = NAN; row[10] = NAN;
+  if (o->cfg.MH) {
+    /* mean of the acceptance matrices over active factors (R/utils.R:444-452) */
+    double sp = 0.0;
+    for (long n = 0; n < N; ++n) if (AR(ID_A)[n] == 1.0) sp = sp + orc_canon_sum(AR(ID_ACC_P) + K * n, K, 1, 64);
+    double* part2 = (double*)malloc(8 * nblk);
+    for (long b = 0; b < nblk; ++b) {
+      double tmpv[256];
+      long len = NE - b * 256 < 256 ? NE - b * 256 : 256;
+      for (long i = 0; i < len; ++i) { long e = b * 256 + i; tmpv[i] = (AR(ID_A)[e % N] == 1.0) ? AR(ID_ACC_E)[e] : 0.0; }
+      part2[b] = orc_canon_sum(tmpv, len, 1, 256);
+    }
+    double se = orc_canon_sum(part2, nblk, 1, 1024);
+    free(part2);
+    row[9] = sp / ((double)K * sumA);
+    row[10] = se / ((double)G * sumA);
+  }
 }
 
 /* ---- constructor part: init_prior_params_ R/sample_priors.R:15-141 then
@@ -518,7 +704,7 @@ static int col_has_nan(const double* x, long n, long stride) {
 int orc_init(orc_handle* o, double* metrics_row1) {
   const long K = o->cfg.K, G = o->cfg.G, N = o->cfg.N;
   const int pr = o->cfg.prior;
-  if (o->cfg.likelihood != LIK_POISSON || o->cfg.MH) { snprintf(o->err, 256, "oracle: model not implemented"); return -10; }
+  if (o->cfg.likelihood != LIK_POISSON) { snprintf(o->err, 256, "oracle: normal likelihood not implemented"); return -10; }
   /* prior params: redraw column n (P side) / row n (E side) when any entry is missing (NaN) */
   struct ispec { int id, var, side; int hs, hr; } spec[4]; int nspec = 0;
   if (pr == PRIOR_GAMMA) {
@@ -529,6 +715,26 @@ int orc_init(orc_handle* o, double* metrics_row1) {
   } else if (pr == PRIOR_EXPONENTIAL) {
     spec[nspec++] = (struct ispec){ID_LAMBDA_P, V_LAMBDA_P, 0, ID_HA_P, ID_HB_P};
     spec[nspec++] = (struct ispec){ID_LAMBDA_E, V_LAMBDA_E, 1, ID_HA_E, ID_HB_E};
+  }
+  if (pr == PRIOR_TRUNCNORMAL) {
+    /* Mu ~ N(M, sqrt(S)), Sigmasq ~ InvGamma(A, B)  (R/sample_priors.R:32-61) */
+    int ids[4] = {ID_MU_P, ID_SIGSQ_P, ID_MU_E, ID_SIGSQ_E};
+    for (int i = 0; i < 4; ++i) {
+      int side = i >= 2, is_mu = (i % 2) == 0;
+      double* x = ensure(o, ids[i]);
+      for (long n = 0; n < N; ++n) {
+        int redraw = side ? col_has_nan(x + n, G, N) : col_has_nan(x + K * n, K, 1);
+        if (!redraw) continue;
+        long cnt = side ? G : K;
+        for (long j = 0; j < cnt; ++j) {
+          long e = side ? n + N * j : j + K * n;
+          if (is_mu) { orc_stream s = ST(o, side ? V_MU_E : V_MU_P, (uint32_t)e, 0);
+            x[e] = HY(side ? ID_HM_E : ID_HM_P, e) + sqrt(HY(side ? ID_HS_E : ID_HS_P, e)) * orc_rnorm_std(&s); }
+          else { orc_stream s = ST(o, side ? V_SIGSQ_E : V_SIGSQ_P, (uint32_t)e, 0);
+            x[e] = orc_rinvgamma(&s, HY(side ? ID_HA_E : ID_HA_P, e), HY(side ? ID_HB_E : ID_HB_P, e)); }
+        }
+      }
+    }
   }
   for (int i = 0; i < nspec; ++i) {
     double* x = ensure(o, spec[i].id);
@@ -550,9 +756,10 @@ int orc_init(orc_handle* o, double* metrics_row1) {
   if (!haveA) for (long n = 0; n < N; ++n) AR(ID_A)[n] = 1.0;
   if (!haveP) sample_P_poisson(o, 1, 1);
   if (!haveE) sample_E_poisson(o, 1, 1);
+  if (o->cfg.MH) { double* ap = ensure(o, ID_ACC_P); double* ae_ = ensure(o, ID_ACC_E); (void)ap; (void)ae_; }
   if (!haveA && o->cfg.learning_rank) { sample_R(o, 1, 1); sample_A(o, 1, 1); }
   else if (!o->a[ID_R].set) o->R = (int)N;
-  sample_Z_and_metrics(o, 1);
+  if (o->cfg.MH) metrics_cells_mh(o); else sample_Z_and_metrics(o, 1);
   if (metrics_row1) metrics_row(o, metrics_row1);
   return 0;
 }
@@ -565,10 +772,10 @@ static void sweep(orc_handle* o) {
   for (long e = 0; e < K * N; ++e) hyper_elem(o, 0, e, t);
 #pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
   for (long e = 0; e < N * G; ++e) hyper_elem(o, 1, e, t);
-  sample_P_poisson(o, t, 0);
-  sample_E_poisson(o, t, 0);
+  if (o->cfg.MH) { sample_P_mh(o, t); sample_E_mh(o, t); }
+  else { sample_P_poisson(o, t, 0); sample_E_poisson(o, t, 0); }
   if (o->cfg.learning_rank) { sample_R(o, t, 0); sample_A(o, t, 0); }
-  sample_Z_and_metrics(o, t);
+  if (o->cfg.MH) metrics_cells_mh(o); else sample_Z_and_metrics(o, t);
 }
 int orc_run(orc_handle* o, int n_iter, int converged, double* metrics /* n_iter x ORC_NMETRIC row-major */) {
   o->converged = converged;

@@ -252,3 +252,52 @@ def test_bayesNMF_end_to_end_gpu(tmp_path):
     assert (cos > 0.95).all(), cos
     assert len(s.samples["P"]) == 200
     s.close()
+
+
+@pytest.mark.parametrize("prior,G", [("truncnormal", 70), ("exponential", 70), ("truncnormal", 600)])
+def test_mh_chain_bitexact(prior, G):
+    """Poisson + MH (config-3 model): proposals from the Normal full conditional, accept-all before
+    convergence, true accept/reject after (R/sample_Pn.R:199-248, R/sample_En.R:196-241).  P, E, prior
+    parameters, acceptance matrices and metrics bit-exact against the oracle; G = 600 spans two
+    512-column segments of the canonical row sums."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    M, _, _ = synth_counts(96, G, 4, 20250222)
+    N = 6
+    o = O.Oracle(M, N, prior=prior, MH=True, seed=2, nthreads=8)
+    e = Engine(M, N, prior=prior, MH=True, seed=2)
+    apply_hyperprior_params(o, prior, M, N)
+    apply_hyperprior_params(e, prior, M, N)
+    r0, r1 = o.init(), e.init()
+    assert np.array_equal(r0[:9].view(np.uint64), r1[:9].view(np.uint64))
+    pp = ["Mu_p", "Sigmasq_p", "Mu_e", "Sigmasq_e"] if prior == "truncnormal" else ["Lambda_p", "Lambda_e"]
+    for conv in (False, True):
+        for step in range(2):
+            mo, me = o.run(6, converged=conv), e.run(6, converged=conv)
+            for nm in ["P", "E", "P_acceptance_rate", "E_acceptance_rate"] + pp:
+                a, b = o.get(nm), e.get(nm)
+                assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), f"{nm}: {np.sum(a != b)} of {a.size} differ (converged={conv})"
+            assert np.array_equal(mo.view(np.uint64), me.view(np.uint64)), "metrics rows (incl. mean acceptance) differ"
+    acc = e.get("P_acceptance_rate")
+    assert (acc >= 0).all() and (acc <= 1).all() and acc.mean() > 0.5
+
+
+def test_mh_learned_rank_bitexact():
+    """The reference's default model: Poisson-TruncNormal + MH with SBFI rank learning."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    M, _, _ = synth_counts(96, 64, 3, 20250223)
+    N = 6
+    temp = _temp_schedule(120)
+    o = O.Oracle(M, N, prior="truncnormal", MH=True, learning_rank=True, seed=3, temperature=temp, nthreads=8)
+    e = Engine(M, N, prior="truncnormal", MH=True, learning_rank=True, seed=3, temperature=temp)
+    apply_hyperprior_params(o, "truncnormal", M, N)
+    apply_hyperprior_params(e, "truncnormal", M, N)
+    o.init(); e.init()
+    for step in range(4):
+        mo, me = o.run(15), e.run(15)
+        assert np.array_equal(o.get("A"), e.get("A")), step
+        assert np.array_equal(o.get("E").view(np.uint64), e.get("E").view(np.uint64)), step
+        assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), step
