@@ -1,0 +1,107 @@
+# r/bayesNMF_hip.R — reference-side binding: how bayesNMF_sampler is switched to the HIP engine.
+#
+# A subclass of the reference's R6 class that keeps every public field and method and replaces only the
+# four private methods the loop body calls (R/bayesNMF_sampler.R:273-285: sample_prior_params,
+# sample_params, record_sample, update_sample_metrics) by ONE `.Call` per block of iterations.
+# Everything else (get_MAP, check_convergence, logging, save_object, summary/plot) is the reference's
+# own code operating on fields that are refreshed from the device at block boundaries.
+# (Not runnable in this repository's container: no R.  The Python mirror bayesnmf_amd/sampler.py is the
+#  tested equivalent.)
+
+.bnmf_ids <- c(P = 0L, E = 1L, A = 2L, R = 3L, Z = 4L, sigmasq = 7L,
+               Alpha_p = 10L, Beta_p = 11L, Alpha_e = 12L, Beta_e = 13L, Mu_p = 14L, Sigmasq_p = 15L,
+               Mu_e = 16L, Sigmasq_e = 17L, Lambda_p = 18L, Lambda_e = 19L,
+               A_p = 30L, B_p = 31L, C_p = 32L, D_p = 33L, M_p = 34L, S_p = 35L,
+               A_e = 40L, B_e = 41L, C_e = 42L, D_e = 43L, M_e = 44L, S_e = 45L,
+               P_acceptance_rate = 50L, E_acceptance_rate = 51L)
+.bnmf_metric_names <- c("iter", "RMSE", "KL", "loglikelihood", "logposterior", "n_params", "BIC", "rank", "temp",
+                        "P_mean_acceptance_rate", "E_mean_acceptance_rate")
+
+bayesNMF_sampler_hip <- R6::R6Class(
+  "bayesNMF_sampler", inherit = bayesNMF::bayesNMF_sampler,
+  public = list(
+    handle = NULL,
+    initialize = function(..., seed = 1, chain_id = 0L, device = 0L, save_Z = FALSE) {
+      private$hip <- list(seed = seed, chain_id = chain_id, device = device, save_Z = save_Z)
+      super$initialize(...)     # runs the reference constructor; its prior draws are redirected below
+    },
+    run_gibbs_sampler = function() {
+      cc <- self$specs$convergence_control
+      start_time <- Sys.time()
+      while (!self$state$converged & self$state$iter < cc$maxiters) {
+        nxt <- (self$state$iter %/% cc$MAP_every + 1) * cc$MAP_every
+        private$run_block(min(nxt, cc$maxiters) - self$state$iter, converged = FALSE)
+        it <- self$state$iter
+        if ((it %% cc$MAP_every == 0 & it >= max(cc$MAP_over, cc$MAP_every)) | it >= cc$maxiters) {
+          private$pull_window()
+          self$get_MAP()
+          msg <- private$check_convergence(); self$log(msg, verbosity = 1)
+          if (self$specs$periodic_save) self$save_object()
+        }
+      }
+      if (self$specs$MH) {
+        done <- 0
+        while (done < self$specs$post_warmup) {
+          n <- min(cc$MAP_every, self$specs$post_warmup - done)
+          private$run_block(n, converged = TRUE); done <- done + n
+          private$pull_window(); self$get_MAP(final = done == self$specs$post_warmup)
+          private$check_convergence(final = done == self$specs$post_warmup)
+        }
+      } else { private$pull_window(); self$get_MAP(final = TRUE) }
+      self$time$total <- difftime(Sys.time(), start_time, units = "mins")
+      self$time$per_iter <- self$time$total / self$state$iter
+      self$save_object()
+    }
+  ),
+  private = list(
+    hip = NULL,
+    # the constructor's sample_params(from_prior = TRUE) + record_sample + update_sample_metrics
+    sample_params = function(skip = c(), from_prior = FALSE) {
+      if (!from_prior) stop("per-iteration sampling goes through run_block()")
+      lk <- c(poisson = 0L, normal = 1L); pr <- c(truncnormal = 0L, exponential = 1L, gamma = 2L)
+      spec <- c(lk[[self$specs$likelihood]], pr[[self$specs$prior]], as.integer(self$specs$MH),
+                as.integer(self$specs$learning_rank),
+                if (isTRUE(self$specs$rank_method == "BFI")) 1L else 0L, as.integer(private$hip$save_Z),
+                as.integer(if (self$specs$save_all_samples) length(self$temperature_schedule)
+                           else self$specs$convergence_control$MAP_over))
+      storage.mode(self$data) <- "integer"
+      self$handle <- .Call("C_bnmf_create", self$data, c(self$dims$K, self$dims$G, self$dims$N), spec,
+                           as.double(self$temperature_schedule), as.double(private$hip$seed),
+                           as.integer(private$hip$chain_id), as.integer(private$hip$device))
+      for (nm in names(self$hyperprior_params)) if (nm %in% names(.bnmf_ids) && is.matrix(self$hyperprior_params[[nm]]))
+        .Call("C_bnmf_set_array", self$handle, .bnmf_ids[[nm]], as.double(self$hyperprior_params[[nm]]))
+      for (nm in skip) .Call("C_bnmf_set_array", self$handle, .bnmf_ids[[nm]], as.double(self$params[[nm]]))
+      row <- .Call("C_bnmf_init", self$handle)
+      private$pull_state(); private$bind_metrics(matrix(row, ncol = 1))
+    },
+    record_sample = function() invisible(NULL),          # recorded on the device (bnmf_window)
+    update_sample_metrics = function(update_trace = FALSE) invisible(NULL),
+    run_block = function(n, converged) {
+      met <- .Call("C_bnmf_run", self$handle, as.integer(n), as.logical(converged))
+      self$state$iter <- self$state$iter + n
+      private$bind_metrics(met); private$pull_state()
+    },
+    bind_metrics = function(met) {
+      df <- as.data.frame(t(met)); names(df) <- .bnmf_metric_names
+      self$state$sample_metrics <- rbind(self$state$sample_metrics, df[, names(self$state$sample_metrics)])
+    },
+    pull_state = function() {
+      get <- function(nm, dim) { x <- .Call("C_bnmf_get_array", self$handle, .bnmf_ids[[nm]], as.double(prod(dim))); dim(x) <- dim; x }
+      K <- self$dims$K; N <- self$dims$N; G <- self$dims$G
+      self$params$P <- get("P", c(K, N)); self$params$E <- get("E", c(N, G)); self$params$A <- get("A", c(1, N))
+      self$params$R <- get("R", 1)
+      for (nm in names(self$prior_params)) if (nm %in% names(.bnmf_ids))
+        self$prior_params[[nm]] <- get(nm, if (grepl("_p$", nm)) c(K, N) else c(N, G))
+    },
+    pull_window = function() {
+      n <- min(self$specs$convergence_control$MAP_over, self$state$iter)
+      K <- self$dims$K; N <- self$dims$N; G <- self$dims$G
+      for (nm in c("P", "E", "A")) {
+        d <- switch(nm, P = c(K, N), E = c(N, G), A = c(1, N))
+        w <- .Call("C_bnmf_window", self$handle, .bnmf_ids[[nm]], as.integer(n), as.double(prod(d)))
+        self$samples[[nm]] <- lapply(seq_len(n), function(i) array(w[, i], dim = d))
+      }
+      self$state$MAP_idx <- seq_len(n)
+    }
+  )
+)
