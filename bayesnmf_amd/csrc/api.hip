@@ -33,7 +33,7 @@ struct bnmf_handle {
   int device = 0;
   hipStream_t stream = nullptr;        // main stream: draws, k_zalloc, reductions
   hipStream_t side = nullptr;          // side stream: k_side of the next iteration (overlaps k_zalloc)
-  hipEvent_t ev_draw = nullptr, ev_side = nullptr;
+  hipEvent_t ev_draw = nullptr, ev_side = nullptr, ev_z = nullptr;
   bool side_valid = false;             // k_side of iteration iter+1 has been issued
   int iter = 0;
   bool inited = false;
@@ -157,6 +157,7 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
   HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&h->ev_draw, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_z, hipEventDisableTiming));
   HIPCHK(hipMalloc(&h->dM, K * G * sizeof(int32_t)));
   HIPCHK(hipMemcpy(h->dM, M, K * G * sizeof(int32_t), hipMemcpyHostToDevice));
   int mx = 0;
@@ -173,17 +174,17 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
   HIPCHK(hipMalloc(&h->dRedraw, N * sizeof(int)));
   HIPCHK(hipMalloc(&h->dEsum, N * sizeof(double)));
   HIPCHK(hipMalloc(&h->dPsum, N * sizeof(double)));
-  HIPCHK(hipMalloc(&h->dlpPn, N * sizeof(double)));
+  HIPCHK(hipMalloc(&h->dlpPn, 2 * N * sizeof(double)));
   h->nblkE = (int)((N * G + ES_T - 1) / ES_T);
-  HIPCHK(hipMalloc(&h->dlpE, h->nblkE * sizeof(double)));
-  HIPCHK(hipMalloc(&h->dcol, 3 * G * sizeof(double)));
+  HIPCHK(hipMalloc(&h->dlpE, 2 * (size_t)h->nblkE * sizeof(double)));
+  HIPCHK(hipMalloc(&h->dcol, 2 * 3 * G * sizeof(double)));   // per-column partials, 2 slots (t & 1)
   if (cfg->learning_rank) HIPCHK(hipMalloc(&h->dRankCol, 2 * G * sizeof(double)));
   if (cfg->MH) {
     h->mh_S = (int)((G + MH_SEG - 1) / MH_SEG);
     HIPCHK(hipMalloc(&h->dProp, K * sizeof(double)));
     HIPCHK(hipMalloc(&h->dPart, K * (size_t)h->mh_S * 4 * sizeof(double)));
-    HIPCHK(hipMalloc(&h->dAccPn, N * sizeof(double)));
-    HIPCHK(hipMalloc(&h->dAccEpart, (size_t)h->nblkE * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dAccPn, 2 * N * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dAccEpart, 2 * (size_t)h->nblkE * sizeof(double)));
     HIPCHK(hipMalloc(&h->dNzE, N * sizeof(int)));
   }
   HIPCHK(hipMalloc(&h->dLut, 2 * (size_t)(mx + 1) * sizeof(double)));
@@ -250,7 +251,7 @@ int bnmf_destroy(bnmf_handle* h) {
   hipFree(h->dR); hipFree(h->dRedraw); hipFree(h->dEsum); hipFree(h->dPsum); hipFree(h->dlpPn);
   hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol);
   if (h->dProp) { hipFree(h->dProp); hipFree(h->dPart); hipFree(h->dAccPn); hipFree(h->dAccEpart); hipFree(h->dNzE); }
-  if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->side) hipStreamDestroy(h->side);
+  if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->side) hipStreamDestroy(h->side);
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -362,6 +363,18 @@ static int ensure_metrics(bnmf_handle* h, size_t rows) {
   refresh_dev(h);
   return 0;
 }
+// The per-iteration partial sums (per-column metric terms, log-prior partials, acceptance partials) live
+// in two slots selected by t & 1, so that k_reduce of iteration t can run on the side stream while the
+// main stream already writes iteration t+1's partials.
+static void use_slot(bnmf_handle* h, uint32_t t) {
+  const size_t sl = t & 1u, G = h->cfg.G, N = h->cfg.N;
+  Dev& d = h->dev;
+  d.colsse = h->dcol + sl * 3 * G; d.colll = d.colsse + G; d.colkl = d.colsse + 2 * G;
+  d.lpE_part = h->dlpE + sl * (size_t)h->nblkE;
+  d.lpPn = h->dlpPn + sl * N;
+}
+static double* accPn_slot(bnmf_handle* h, uint32_t t) { return h->dAccPn ? h->dAccPn + (size_t)(t & 1u) * h->cfg.N : nullptr; }
+static double* accEp_slot(bnmf_handle* h, uint32_t t) { return h->dAccEpart ? h->dAccEpart + (size_t)(t & 1u) * h->nblkE : nullptr; }
 struct Timer {   // optional per-kernel HIP-event bracketing (serialises the two streams: profile mode only)
   bnmf_handle* h; bool on; double acc[BNMF_NKERNEL]{}; int cnt[BNMF_NKERNEL]{};
   void begin(int k, hipStream_t st) { if (on) { hipStreamSynchronize(h->stream); hipStreamSynchronize(h->side); hipEventRecord(h->ev[2 * k], st); } }
@@ -387,21 +400,26 @@ static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm) {
   hipEventRecord(h->ev_side, h->side);
   h->side_valid = true;
 }
-template <typename KernelT>
-static int launch_z(bnmf_handle* h, uint32_t t, KernelT kern, int zt, bool* attr_done) {
+template <typename KernelT, typename ArgT>
+static int launch_z(bnmf_handle* h, uint32_t t, KernelT kern, const ArgT& arg, int zt, bool* attr_done) {
   if (!*attr_done) { HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); *attr_done = true; }
-  hipLaunchKernelGGL(kern, dim3(h->z_grid), dim3(zt), h->z_lds, h->stream, h->dev, t, h->zg, h->z_ablate);
+  hipLaunchKernelGGL(kern, dim3(h->z_grid), dim3(zt), h->z_lds, h->stream, arg, t, h->zg, h->z_ablate);
   return 0;
+}
+static ZArgs zargs(const bnmf_handle* h) {
+  const Dev& d = h->dev;
+  return ZArgs{d.K, d.G, d.N, d.maxM, d.k0, d.k1, d.M, d.P, d.E, d.A, d.ZsumK, d.ZsumG, d.Z, d.colsse, d.colll, d.colkl, d.lgfact, d.logm};
 }
 template <bool SZ, int ZT_>
 static int launch_zalloc_t(bnmf_handle* h, uint32_t t) {
   static bool done[5] = {false, false, false, false, false};
-  if (!h->z_reg) return launch_z(h, t, k_zalloc<SZ, ZT_, 0>, ZT_, &done[0]);
+  if (!h->z_reg) return launch_z(h, t, k_zalloc<SZ, ZT_, 0>, h->dev, ZT_, &done[0]);
+  const ZArgs za = zargs(h);
   switch (h->zg.TR) {
-    case 8: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 8>, ZT_, &done[1]);
-    case 16: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 16>, ZT_, &done[2]);
-    case 20: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 20>, ZT_, &done[3]);
-    default: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 24>, ZT_, &done[4]);
+    case 8: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 8>, za, ZT_, &done[1]);
+    case 16: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 16>, za, ZT_, &done[2]);
+    case 20: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 20>, za, ZT_, &done[3]);
+    default: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 24>, za, ZT_, &done[4]);
   }
 }
 static int launch_zalloc(bnmf_handle* h, uint32_t t) {
@@ -454,8 +472,14 @@ static int launch_record(bnmf_handle* h, uint32_t t) {
   hipLaunchKernelGGL(k_record, dim3(512), dim3(256), 0, h->stream, ra);
   return 0;
 }
-static void launch_reduce(bnmf_handle* h, int row) {
-  hipLaunchKernelGGL(k_reduce, dim3(h->cfg.MH ? 5 : 4), dim3(RT), 0, h->stream, h->dev, row, h->nblkE, (const double*)h->dAccPn, (const double*)h->dAccEpart);
+// k_reduce of iteration t: on the side stream, after the main stream has finished k_zalloc / metrics of t
+static void launch_reduce(bnmf_handle* h, uint32_t t, int row, Timer& tm) {
+  if (h->cfg.learning_rank) hipLaunchKernelGGL(k_sumA, dim3(1), dim3(64), 0, h->stream, h->dev, row, (const double*)accPn_slot(h, t));
+  hipEventRecord(h->ev_z, h->stream);
+  hipStreamWaitEvent(h->side, h->ev_z, 0);
+  tm.begin(KN_REDUCE, h->side);
+  hipLaunchKernelGGL(k_reduce, dim3(h->cfg.MH ? 5 : 4), dim3(RT), 0, h->side, h->dev, row, h->nblkE, (const double*)accPn_slot(h, t), (const double*)accEp_slot(h, t));
+  tm.end(KN_REDUCE, h->side);
 }
 // P and E updates of the MH models (R/sample_params.R:56-64 with sample_Pn/_En -> *_normal -> MH_*_poisson)
 static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged) {
@@ -482,12 +506,13 @@ static void launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells) {
     int grid = (G + 3) / 4; if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(k_mh_ecol<true>, dim3(grid), dim3(MHE_T), 4 * 2 * (size_t)N * sizeof(double), h->stream, h->dev, t, 0, h->arr[BNMF_ACC_E].d);
   }
-  hipLaunchKernelGGL(k_lp_p, dim3(N), dim3(64), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_P].d, h->dAccPn);
-  hipLaunchKernelGGL(k_lp_e, dim3(h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_E].d, h->dAccEpart);
+  hipLaunchKernelGGL(k_lp_p, dim3(N), dim3(64), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_P].d, accPn_slot(h, t));
+  hipLaunchKernelGGL(k_lp_e, dim3(h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_E].d, accEp_slot(h, t));
 }
 static int sweep_mh(bnmf_handle* h, int row, int converged, Timer& tm) {
   h->iter += 1;
   const uint32_t t = (uint32_t)h->iter;
+  use_slot(h, t);
   if (!h->side_valid) launch_side(h, t, tm);
   hipStreamWaitEvent(h->stream, h->ev_side, 0);
   tm.begin(KN_MH, h->stream); launch_mh_PE(h, t, converged); tm.end(KN_MH, h->stream);
@@ -495,12 +520,13 @@ static int sweep_mh(bnmf_handle* h, int row, int converged, Timer& tm) {
   if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
   if (int rc = launch_record(h, t)) return rc;
   tm.begin(KN_OTHER, h->stream); launch_mh_metrics(h, t, h->cfg.learning_rank != 0); tm.end(KN_OTHER, h->stream);
-  tm.begin(KN_REDUCE, h->stream); launch_reduce(h, row); tm.end(KN_REDUCE, h->stream);
+  launch_reduce(h, t, row, tm);
   return 0;
 }
 static int sweep(bnmf_handle* h, int row, Timer& tm) {
   h->iter += 1;
   const uint32_t t = (uint32_t)h->iter;
+  use_slot(h, t);
   if (!h->side_valid) launch_side(h, t, tm);               // first sweep after init / set_array
   hipStreamWaitEvent(h->stream, h->ev_side, 0);            // prior params + Esum of iteration t ready
   tm.begin(KN_PDRAW, h->stream); launch_pdraw(h, t, 0); tm.end(KN_PDRAW, h->stream);
@@ -509,7 +535,7 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
   tm.begin(KN_OTHER, h->stream); if (int rc = launch_record(h, t)) return rc; tm.end(KN_OTHER, h->stream);
   tm.begin(KN_ZALLOC, h->stream); if (int rc = launch_zalloc(h, t)) return rc; tm.end(KN_ZALLOC, h->stream);
-  tm.begin(KN_REDUCE, h->stream); launch_reduce(h, row); tm.end(KN_REDUCE, h->stream);
+  launch_reduce(h, t, row, tm);
   return 0;
 }
 
@@ -575,6 +601,7 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
   refresh_dev(h);
   h->iter = 1;
   Timer tm{h, false};
+  use_slot(h, 1u);
   if (haveP || haveE) return fail(BNMF_ESTATE, "bnmf_init: user-supplied P/E initial values are not supported yet");
   launch_pdraw(h, 1u, 1);
   launch_edraw(h, 1u, 1);
@@ -586,7 +613,8 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
   if (int rc = launch_record(h, 1u)) return rc;
   if (c.MH) launch_mh_metrics(h, 1u, true);
   else if (int rc = launch_zalloc(h, 1u)) return rc;
-  launch_reduce(h, 0);
+  launch_reduce(h, 1u, 0, tm);
+  hipEventRecord(h->ev_z, h->side); hipStreamWaitEvent(h->stream, h->ev_z, 0);
   hipLaunchKernelGGL(k_compose, dim3(1), dim3(64), 0, h->stream, h->dev, 1, 1u);
   HIPCHK(hipGetLastError());
   if (metrics_row1) HIPCHK(hipMemcpyAsync(metrics_row1, h->dMetrics, BNMF_NMETRIC * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -605,6 +633,7 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
   if (int rc = ensure_metrics(h, (size_t)n_iter)) return rc;
   const uint32_t t0 = (uint32_t)h->iter + 1;
   for (int i = 0; i < n_iter; ++i) if (int rc = (h->cfg.MH ? sweep_mh(h, i, converged, tm) : sweep(h, i, tm))) return rc;
+  hipEventRecord(h->ev_z, h->side); hipStreamWaitEvent(h->stream, h->ev_z, 0);   // last k_reduce done
   hipLaunchKernelGGL(k_compose, dim3((n_iter + 63) / 64), dim3(64), 0, h->stream, h->dev, n_iter, t0);
   HIPCHK(hipGetLastError());
   if (metrics) HIPCHK(hipMemcpyAsync(metrics, h->dMetrics, (size_t)n_iter * BNMF_NMETRIC * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -469,12 +469,26 @@ __global__ __launch_bounds__(RT) void k_reduce(Dev d, int row, int nblkE, const 
     double* o = d.raw + (size_t)row * 8;
     o[j < 4 ? j : 6] = r;
     if (j == 0) {
-      double lpP = 0.0, sumA = 0.0;
-      for (int n = 0; n < d.N; ++n) { lpP = lpP + d.lpPn[n]; sumA = sumA + d.A[n]; }
-      o[4] = lpP; o[5] = sumA;
-      if (accPn) { double sp = 0.0; for (int n = 0; n < d.N; ++n) if (d.A[n] == 1.0) sp = sp + accPn[n]; o[7] = sp; }
+      double lpP = 0.0;
+      for (int n = 0; n < d.N; ++n) lpP = lpP + d.lpPn[n];
+      o[4] = lpP;
+      if (!d.learning_rank) {             // with rank learning A changes on the main stream: k_sumA writes these
+        double sumA = 0.0;
+        for (int n = 0; n < d.N; ++n) sumA = sumA + d.A[n];
+        o[5] = sumA;
+        if (accPn) { double sp = 0.0; for (int n = 0; n < d.N; ++n) if (d.A[n] == 1.0) sp = sp + accPn[n]; o[7] = sp; }
+      }
     }
   }
+}
+// sum(A) (and the A-masked acceptance sum) of the iteration, on the main stream right after the rank update
+__global__ void k_sumA(Dev d, int row, const double* accPn) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double* o = d.raw + (size_t)row * 8;
+  double sumA = 0.0;
+  for (int n = 0; n < d.N; ++n) sumA = sumA + d.A[n];
+  o[5] = sumA;
+  if (accPn) { double sp = 0.0; for (int n = 0; n < d.N; ++n) if (d.A[n] == 1.0) sp = sp + accPn[n]; o[7] = sp; }
 }
 // compute_metrics_ R/utils.R:412-455, update_sample_metrics_ :339-348: one lane per recorded row
 __global__ void k_compose(Dev d, int nrows, uint32_t t0) {

@@ -2,11 +2,11 @@
 // kernel for N <= 25 (the metric configuration has N = 20).
 //
 // Same stream spec and bit-identical results as k_zalloc (kernels.h), different machine mapping:
-// the per-count bucket search does not touch LDS.  A lane keeps the threshold row of the cell it
-// is working on in registers (reloaded with 128-bit LDS reads when its contiguous quad range
-// crosses into the next cell); the bucket of a count is b = #{n : thr_n <= u}, computed with one
-// full-rate v_cmp + v_addc pair per threshold, all independent (no LDS round trips, no
-// dependent chain).  Each count then costs two LDS atomics: zacc[n][k] (bank = k, so lanes on
+// the bucket of a count is found with a two-level search: the pivots of the cell's threshold row
+// (every 4th threshold) live in registers (reloaded when the lane's contiguous quad range crosses
+// into the next cell), compare+add-carry pairs pick the 4-block, ONE 128-bit LDS read fetches it and
+// four more compares finish: half the VALU of a full register compare, one LDS read per count
+// instead of the six dependent reads of a binary search.  Each count then costs two LDS atomics: zacc[n][k] (bank = k, so lanes on
 // different cells never collide) and the lane's private packed 8-bit histogram used for ZsumK.
 // (sample_Zkg R/sample_params.R:253-265; metrics R/utils.R:412-471)
 #pragma once
@@ -26,8 +26,18 @@ BNMF_DEV void cmp_acc4(uint32_t T, uint32_t u0, uint32_t u1, uint32_t u2, uint32
   b3 += (T <= u3) ? 1u : 0u;
 }
 
+// only what this kernel needs (the full Dev by value costs ~60 SGPRs and made the hot loop spill SGPRs)
+struct ZArgs {
+  int K, G, N, maxM;
+  uint32_t k0, k1;
+  const int32_t* M;
+  const double *P, *E, *A;
+  int32_t *ZsumK, *ZsumG, *Z;
+  double *colsse, *colll, *colkl;
+  const double *lgfact, *logm;
+};
 template <bool SAVE_Z, int ZT, int TRC /* threshold registers: multiple of 4, >= N-1 */>
-__global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(Dev d, uint32_t t, ZGeom zg, int ablate) {
+__global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(ZArgs d, uint32_t t, ZGeom zg, int ablate) {
   constexpr int ZW = ZT / 64;
   constexpr int NC = TRC + 1;                            // factors covered by this instantiation
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -54,7 +64,7 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(Dev d, uint32_t t, ZGeom z
   // Phase-synchronised: all waves of the workgroup run phase 1 together and phase 2 together
   // (ablate bit 512 turns the barriers off).  In phase 2 the SIMD then always has several waves in the
   // compare/Philox stream, which hides the VALU->VCC hazard slots a lone wave would stall on.
-  const bool psync = !(ablate & 512);
+  const bool psync = (ablate & 512) != 0;      // measured: no gain, off by default
   const int nround = (G - (int)(blockIdx.x * ZW) + nw - 1) / nw;   // same for every wave of the workgroup
   for (int rr = 0; rr < nround; ++rr) {
     const int g = gw + rr * nw;
@@ -141,7 +151,9 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(Dev d, uint32_t t, ZGeom z
           cell = b + ((int)(qoff[b] & 0x3FFFFFFFu) <= q0 ? 1 : 0) - 1;
         }
         int cstart = 0, cend = -1, mc = 0;
-        uint32_t T[TRC];
+        constexpr int NPV = TRC / 4 - 1;                  // pivots: last threshold of every 4-block but the last
+        uint32_t PV[NPV > 0 ? NPV : 1];
+        const uint32_t* row = thr;
         --cell;
         uint32_t* hl = hist + lane;
         for (int qi = q0; qi < q1; ++qi) {
@@ -150,9 +162,9 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(Dev d, uint32_t t, ZGeom z
             do { ++cell; qa = qoff[cell]; qb = qoff[cell + 1]; cend = (int)(qb & 0x3FFFFFFFu); } while (qi >= cend);
             cstart = (int)(qa & 0x3FFFFFFFu);
             mc = ((cend - cstart) << 2) - (int)(qa >> 30);
-            const u4* row = (const u4*)(thr + (size_t)cell * TRC);
+            row = thr + (size_t)cell * TRC;
 #pragma unroll
-            for (int j = 0; j < TRC / 4; ++j) { const u4 v = row[j]; T[4 * j] = v.x; T[4 * j + 1] = v.y; T[4 * j + 2] = v.z; T[4 * j + 3] = v.w; }
+            for (int j = 0; j < NPV; ++j) PV[j] = row[4 * j + 3];
           }
           const int j0 = (qi - cstart) << 2;
           const int nd = mc - j0;                          // >= 1; counts of this quad = min(4, nd)
@@ -162,8 +174,16 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(Dev d, uint32_t t, ZGeom z
           const uint32_t u0 = min(w.x, 0xFFFFFFFEu), u1 = min(w.y, 0xFFFFFFFEu), u2 = min(w.z, 0xFFFFFFFEu), u3 = min(w.w, 0xFFFFFFFEu);
           uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
           if (!(ablate & 8)) {
+            // two-level search: pivots in registers pick the 4-block, one 128-bit LDS read fetches it
+            uint32_t j0b = 0, j1b = 0, j2b = 0, j3b = 0;
 #pragma unroll
-            for (int n = 0; n < TRC; ++n) cmp_acc4(T[n], u0, u1, u2, u3, b0, b1, b2, b3);
+            for (int j = 0; j < NPV; ++j) cmp_acc4(PV[j], u0, u1, u2, u3, j0b, j1b, j2b, j3b);
+            const u4 k0 = *(const u4*)(row + 4 * j0b), k1 = *(const u4*)(row + 4 * j1b);
+            const u4 k2 = *(const u4*)(row + 4 * j2b), k3 = *(const u4*)(row + 4 * j3b);
+            b0 = 4 * j0b + (k0.x <= u0) + (k0.y <= u0) + (k0.z <= u0) + (k0.w <= u0);
+            b1 = 4 * j1b + (k1.x <= u1) + (k1.y <= u1) + (k1.z <= u1) + (k1.w <= u1);
+            b2 = 4 * j2b + (k2.x <= u2) + (k2.y <= u2) + (k2.z <= u2) + (k2.w <= u2);
+            b3 = 4 * j3b + (k3.x <= u3) + (k3.y <= u3) + (k3.z <= u3) + (k3.w <= u3);
           }
           uint32_t* zc = ztarget + cell;
           if (ablate & 4) { if (b0 + b1 + b2 + b3 == 0xFFFFFFF0u) zc[0] = w.x; }

@@ -11,8 +11,8 @@ def mk(env):
     os.environ.update(env)
     e = Engine(M, 20, prior="gamma", seed=1); apply_hyperprior_params(e, "gamma", M, 20); e.init(); e.run(20, metrics=False)
     return e
-variants = [("reg", {}), ("lds rowmajor", {"BNMF_ZREG": "0"}), ("lds nophase2", {"BNMF_ZREG": "0", "BNMF_ABLATE": "2"}), ("lds nosearch", {"BNMF_ZREG": "0", "BNMF_ABLATE": "8"}),
-            ("lds nophilox", {"BNMF_ZREG": "0", "BNMF_ABLATE": "16"}), ("lds noatomic", {"BNMF_ZREG": "0", "BNMF_ABLATE": "4"}), ("lds none", {"BNMF_ZREG": "0", "BNMF_ABLATE": "28"})]
+variants = [("reg hybrid", {"BNMF_ABLATE": "512"}), ("nophase2", {"BNMF_ABLATE": "514"}), ("nosearch", {"BNMF_ABLATE": "520"}),
+            ("nophilox", {"BNMF_ABLATE": "528"}), ("noatomic", {"BNMF_ABLATE": "516"}), ("none", {"BNMF_ABLATE": "540"}), ("psync", {})]
 if len(sys.argv) > 1:
     variants = [v for v in variants if v[0] in sys.argv[1:]] or variants
 eng = [(n, mk(env)) for n, env in variants]
