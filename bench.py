@@ -33,6 +33,29 @@ def z_bytes(K, G, N, save_Z):
     return b
 
 
+def pmc_traffic(save_Z):
+    """HBM bytes per k_zalloc launch from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
+    rocprofv3 --pmc passes by tools_pmc2.sh, gfx950-corrected; committed under profiles/).  None if absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        return d["k_zalloc_full" if save_Z else "k_zalloc_stats"]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def roofline_of(chain, K, G, N, save_Z, total_counts, n_iter):
+    prof = chain.profile(n_iter)
+    zb = z_bytes(K, G, N, save_Z)
+    z_ms = prof["k_zalloc"]
+    achieved = zb / (z_ms * 1e-3) / 1e9 if z_ms > 0 else 0.0
+    return prof, {"bound": "hbm", "kernel": "k_zalloc_reg" + ("<save_Z>" if save_Z else ""), "achieved": achieved,
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(save_Z),
+                  "algorithmic_bytes_per_launch": zb, "avg_launch_ms": z_ms,
+                  "draws_per_s": total_counts / (z_ms * 1e-3) if z_ms > 0 else 0.0,
+                  "note": "stats mode moves 6.3 MB per 40 M categorical draws: the kernel is VALU/Philox-bound, not HBM-bound (DESIGN.md 5)"
+                          if not save_Z else "full mode: Z (K x N x G int32) written every iteration"}
+
+
 def make_chain(M, N, seed, chain_id, device, save_Z=False):
     from bayesnmf_amd import Engine
     from bayesnmf_amd.setup import apply_hyperprior_params
@@ -107,13 +130,10 @@ def main():
     tmax = float(tmax.item())
 
     # roofline of the dominant kernel (k_zalloc), HIP events on the chain's own stream
-    prof = chain.profile(min(200, max(20, args.steps // 10)))
+    total_counts = int(M.sum())
+    prof, roof = roofline_of(chain, K_, args.G, N_, args.save_z, total_counts, min(200, max(20, args.steps // 10)))
     out = None
     if rank == 0:
-        zb = z_bytes(K_, args.G, N_, args.save_z)
-        z_ms = prof["k_zalloc"]
-        achieved = zb / (z_ms * 1e-3) / 1e9 if z_ms > 0 else 0.0
-        total_counts = int(M.sum())
         out = {
             "metric": "Gibbs iters/sec at K=96, G=10k, N=20; per-chain scaling at 1/2/4/8 GPUs",
             "value": world * args.steps / tmax,
@@ -126,12 +146,15 @@ def main():
                                    f"one chain per GPU, {'full (save_Z)' if args.save_z else 'stats'} mode, "
                                    f"metrics every iteration",
                        "chains": world, "seed": 1, "sum_M": total_counts},
-            "roofline": {"bound": "hbm", "kernel": "k_zalloc", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": zb, "avg_launch_ms": z_ms,
-                         "draws_per_s": total_counts / (z_ms * 1e-3) if z_ms > 0 else 0.0},
+            "roofline": roof,
             "kernel_ms": prof,
         }
+        if world == 1 and not args.save_z:
+            # the same kernel in full mode (Z materialised): the only mode in which HBM traffic is substantial
+            cz = make_chain(M, N_, seed=1, chain_id=0, device=local_rank, save_Z=True)
+            cz.run(50, metrics=False)
+            _, out["roofline_save_Z"] = roofline_of(cz, K_, args.G, N_, True, total_counts, 100)
+            cz.close()
         if gathered is not None:
             out["chains_final_logposterior"] = [float(g[0][4]) for g in gathered]
         if world == 1 and not args.no_cpu_baseline:
