@@ -68,7 +68,7 @@ static size_t id_len(const bnmf_handle* h, int id) {
     default: return 0;
   }
 }
-static bool is_hyper(int id) { return id >= 30 && id < 50; }
+static bool is_hyper(int id) { return (id >= 30 && id < 50) || id == BNMF_ALPHA || id == BNMF_BETA; }
 static bool is_prior_param(int id) { return id >= BNMF_ALPHA_P && id <= BNMF_LAMBDA_E; }   // 2 slots, slot(t) = t & 1
 static int cur_slot(const bnmf_handle* h) { return (h->iter > 0 ? h->iter : 1) & 1; }
 static bool is_pside(int id) { size_t dummy = 0; (void)dummy; return id == BNMF_P || id == BNMF_ALPHA_P || id == BNMF_BETA_P || id == BNMF_MU_P || id == BNMF_SIGMASQ_P || id == BNMF_LAMBDA_P; }
@@ -105,6 +105,7 @@ static void refresh_dev(bnmf_handle* h) {
   d.hM_p = hr(BNMF_HM_P); d.hS_p = hr(BNMF_HS_P);
   d.hA_e = hr(BNMF_HA_E); d.hB_e = hr(BNMF_HB_E); d.hC_e = hr(BNMF_HC_E); d.hD_e = hr(BNMF_HD_E);
   d.hM_e = hr(BNMF_HM_E); d.hS_e = hr(BNMF_HS_E);
+  d.sigmasq = h->arr[BNMF_SIGMASQ].d; d.hAlphaS = hr(BNMF_ALPHA); d.hBetaS = hr(BNMF_BETA);
   d.Esum = h->dEsum; d.Psum = h->dPsum; d.lpPn = h->dlpPn; d.lpE_part = h->dlpE;
   d.colsse = h->dcol; d.colll = h->dcol + c.G; d.colkl = h->dcol + 2 * (size_t)c.G;
   d.lgfact = h->dLut; d.logm = h->dLut + (h->maxM + 1);
@@ -179,7 +180,7 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
   HIPCHK(hipMalloc(&h->dlpE, 2 * (size_t)h->nblkE * sizeof(double)));
   HIPCHK(hipMalloc(&h->dcol, 2 * 3 * G * sizeof(double)));   // per-column partials, 2 slots (t & 1)
   if (cfg->learning_rank) HIPCHK(hipMalloc(&h->dRankCol, 2 * G * sizeof(double)));
-  if (cfg->MH) {
+  if (cfg->MH || cfg->likelihood == BNMF_NORMAL) {
     h->mh_S = (int)((G + MH_SEG - 1) / MH_SEG);
     HIPCHK(hipMalloc(&h->dProp, K * sizeof(double)));
     HIPCHK(hipMalloc(&h->dPart, K * (size_t)h->mh_S * 4 * sizeof(double)));
@@ -345,7 +346,6 @@ int bnmf_get_iter(bnmf_handle* h, int* iter) { if (!h || !iter) return fail(BNMF
 // ------------------------------------------------------------------ launch helpers
 static int check_model_supported(const bnmf_handle* h) {
   const bnmf_config& c = h->cfg;
-  if (c.likelihood != BNMF_POISSON) return fail(BNMF_EMODEL, "this build implements the Poisson-likelihood models (Normal likelihood: next round)");
   return 0;
 }
 static int need_hyper(bnmf_handle* h, std::initializer_list<int> ids) {
@@ -498,13 +498,15 @@ static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged) {
     }
   }
   int grid = (G + 3) / 4; if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(k_mh_ecol<false>, dim3(grid), dim3(MHE_T), 4 * 2 * (size_t)N * sizeof(double), h->stream, h->dev, t, converged, accE);
+  hipLaunchKernelGGL(k_mh_ecol<false>, dim3(grid), dim3(MHE_T), 4 * 2 * (size_t)N * sizeof(double), h->stream, h->dev, t, converged, accE, 0);
 }
 static void launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells) {
+  const int draw_sig = h->cfg.likelihood == BNMF_NORMAL ? 1 : 0;
+  if (draw_sig) cells = true;                 // sigmasq is drawn after R, A (R/sample_params.R:86-88) in the metrics pass
   const int N = h->cfg.N, G = h->cfg.G;
   if (cells) {
     int grid = (G + 3) / 4; if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(k_mh_ecol<true>, dim3(grid), dim3(MHE_T), 4 * 2 * (size_t)N * sizeof(double), h->stream, h->dev, t, 0, h->arr[BNMF_ACC_E].d);
+    hipLaunchKernelGGL(k_mh_ecol<true>, dim3(grid), dim3(MHE_T), 4 * 2 * (size_t)N * sizeof(double), h->stream, h->dev, t, 0, h->arr[BNMF_ACC_E].d, draw_sig);
   }
   hipLaunchKernelGGL(k_lp_p, dim3(N), dim3(64), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_P].d, accPn_slot(h, t));
   hipLaunchKernelGGL(k_lp_e, dim3(h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_E].d, accEp_slot(h, t));
@@ -597,6 +599,12 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
   if (int rc = ensure(h, BNMF_E)) return rc;
   if (int rc = ensure(h, BNMF_A)) return rc;
   if (c.MH) { if (int rc = ensure(h, BNMF_ACC_P)) return rc; if (int rc = ensure(h, BNMF_ACC_E)) return rc; }
+  if (c.likelihood == BNMF_NORMAL) {
+    const double three = 3.0;                                   // alpha = beta = 3 (R/bayesNMF_sampler.R:222-230)
+    if (!h->arr[BNMF_ALPHA].d) if (int rc = bnmf_set_array(h, BNMF_ALPHA, &three, 1)) return rc;
+    if (!h->arr[BNMF_BETA].d) if (int rc = bnmf_set_array(h, BNMF_BETA, &three, 1)) return rc;
+    if (int rc = ensure(h, BNMF_SIGMASQ)) return rc;
+  }
   if (!haveA) { std::vector<double> ones(N, 1.0); HIPCHK(hipMemcpy(h->arr[BNMF_A].d, ones.data(), N * sizeof(double), hipMemcpyHostToDevice)); }
   refresh_dev(h);
   h->iter = 1;
@@ -611,7 +619,7 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
     hipLaunchKernelGGL(k_rank_Aprior, dim3((N + 63) / 64), dim3(64), 0, h->stream, h->dev, 1u);
   }
   if (int rc = launch_record(h, 1u)) return rc;
-  if (c.MH) launch_mh_metrics(h, 1u, true);
+  if (c.MH || c.likelihood == BNMF_NORMAL) launch_mh_metrics(h, 1u, true);
   else if (int rc = launch_zalloc(h, 1u)) return rc;
   launch_reduce(h, 1u, 0, tm);
   hipEventRecord(h->ev_z, h->side); hipStreamWaitEvent(h->stream, h->ev_z, 0);
@@ -632,7 +640,7 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
   HIPCHK(hipSetDevice(h->device));
   if (int rc = ensure_metrics(h, (size_t)n_iter)) return rc;
   const uint32_t t0 = (uint32_t)h->iter + 1;
-  for (int i = 0; i < n_iter; ++i) if (int rc = (h->cfg.MH ? sweep_mh(h, i, converged, tm) : sweep(h, i, tm))) return rc;
+  for (int i = 0; i < n_iter; ++i) if (int rc = ((h->cfg.MH || h->cfg.likelihood == BNMF_NORMAL) ? sweep_mh(h, i, h->cfg.MH ? converged : 0, tm) : sweep(h, i, tm))) return rc;
   hipEventRecord(h->ev_z, h->side); hipStreamWaitEvent(h->stream, h->ev_z, 0);   // last k_reduce done
   hipLaunchKernelGGL(k_compose, dim3((n_iter + 63) / 64), dim3(64), 0, h->stream, h->dev, n_iter, t0);
   HIPCHK(hipGetLastError());

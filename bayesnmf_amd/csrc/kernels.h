@@ -29,6 +29,7 @@ struct Dev {
   int32_t *ZsumK, *ZsumG, *Z;
   double *Alpha_p, *Beta_p, *Alpha_e, *Beta_e, *Mu_p, *Sig_p, *Mu_e, *Sig_e, *Lam_p, *Lam_e;
   HRef hA_p, hB_p, hC_p, hD_p, hM_p, hS_p, hA_e, hB_e, hC_e, hD_e, hM_e, hS_e;
+  double* sigmasq; HRef hAlphaS, hBetaS;   // Normal likelihood: sigmasq_g ~ InvGamma(Alpha_g + K/2, Beta_g + ss/2)
   double *Esum, *Psum, *lpPn, *lpE_part, *colsse, *colll, *colkl;
   const double *lgfact, *logm;       // LUTs over m = 0..maxM: lgamma(m+1), log(max(m,1e-6))
   const double* temperature; long n_temperature;

@@ -79,8 +79,9 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow_partial(Dev d, int n, int S, 
       double mh = 0.0, mno = 0.0;
       for (int j = 0; j < N; ++j) { const double term = pa[j] * Eg[j]; mh = mh + term; mno = mno + (j == n ? 0.0 * Eg[j] : term); }
       const double en = Eg[n];
-      a0 = a0 + en * (((double)m - mno) / mh);          // :155-161
-      a1 = a1 + (a_n * (en * en)) * (1.0 / mh);          // :163-169
+      const double V = d.likelihood == BNMF_NORMAL ? d.sigmasq[g] : mh;   // sigmasq_kg: Mhat (proposal) or sigmasq_g :137-147
+      a0 = a0 + en * (((double)m - mno) / V);           // :155-161
+      a1 = a1 + (a_n * (en * en)) * (1.0 / V);           // :163-169
     } else {
       double m0 = 0.0, m1 = 0.0;
       for (int j = 0; j < N; ++j) { const double e = Eg[j]; m0 = m0 + pa[j] * e; m1 = m1 + (j == n ? pn_prop : pa[j]) * e; }
@@ -109,7 +110,7 @@ __global__ void k_mh_prow_finish(Dev d, uint32_t t, int n, int S, int converged,
     if (!allzero) for (int s = 0; s < S; ++s) { num1 = num1 + part[((size_t)k * S + s) * 4]; den = den + part[((size_t)k * S + s) * 4 + 1]; }
     const double pr = mh_prior_or_cond<0>(d, e, t, allzero, num1, den);
     prop[k] = pr;
-    if (!converged) { d.P[e] = pr; accP[e] = 1.0; }                       // MH_Pn_poisson :201-204
+    if (!converged) { d.P[e] = pr; if (accP) accP[e] = 1.0; }            // MH_Pn_poisson :201-204 (plain Gibbs for the Normal likelihood)
   } else {
     if (a_n == 0.0) return;
     double A_ = 0.0, B_ = 0.0, C_ = 0.0, D_ = 0.0;
@@ -126,7 +127,7 @@ __global__ void k_mh_prow_finish(Dev d, uint32_t t, int n, int S, int converged,
 // E side: one wave per column, all factors in order; METRICS_ONLY skips the updates (iteration 1).
 constexpr int MHE_T = 256;
 template <bool METRICS_ONLY>
-__global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int converged, double* accE) {
+__global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int converged, double* accE, int draw_sig) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = d.K, G = d.G, N = d.N;
@@ -138,6 +139,8 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int conver
     for (int j = lane; j < N; j += 64) { ec[j] = d.E[j + (size_t)N * g]; av[j] = d.A[j]; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    const bool normal = d.likelihood == BNMF_NORMAL;
+    double sg_col = normal ? d.sigmasq[g] : 1.0;
     if (!METRICS_ONLY) {
       for (int n = 0; n < N; ++n) {
         const int e = n + N * g;
@@ -155,14 +158,15 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int conver
               double mh = 0.0, mno = 0.0;
               for (int j = 0; j < N; ++j) { const double term = (d.P[kk + (size_t)K * j] * av[j]) * ec[j]; mh = mh + term; mno = mno + (j == n ? (d.P[kk + (size_t)K * j] * 0.0) * ec[j] : term); }
               const int m = d.M[kk + (size_t)K * g];
-              s1 = s1 + pn * (((double)m - mno) / mh);
-              s2 = s2 + (a_n * (pn * pn)) * (1.0 / mh);
+              const double V = normal ? sg_col : mh;
+              s1 = s1 + pn * (((double)m - mno) / V);
+              s2 = s2 + (a_n * (pn * pn)) * (1.0 / V);
             }
           }
           const bool allzero = __ballot(anynz) == 0ull;
           s1 = __shfl(wave_tree64(s1), 0, 64); s2 = __shfl(wave_tree64(s2), 0, 64);
           const double pr = mh_prior_or_cond<1>(d, e, t, allzero, allzero ? 0.0 : s1, allzero ? 0.0 : s2);
-          if (!converged) { enew = pr; if (lane == 0) accE[e] = 1.0; }
+          if (!converged) { enew = pr; if (lane == 0 && accE) accE[e] = 1.0; }
           else {
             const double eold = ec[n];
             double A_ = 0.0, B_ = 0.0, C_ = 0.0, D_ = 0.0;
@@ -195,6 +199,23 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int conver
         __builtin_amdgcn_wave_barrier();
       }
     }
+    if (normal && draw_sig) {
+      // sample_sigmasq R/sample_params.R:275-286: sigmasq_g ~ InvGamma(Alpha_g + K/2, Beta_g + sum_k resid^2 / 2)
+      double ss = 0.0;
+      for (int r = 0; r < KR; ++r) {
+        const int kk = (r << 6) + lane;
+        if (kk < K) {
+          double c = 0.0;
+          for (int j = 0; j < N; ++j) c = c + (d.P[kk + (size_t)K * j] * av[j]) * ec[j];
+          const double rr = (double)d.M[kk + (size_t)K * g] - c;
+          ss = ss + rr * rr;
+        }
+      }
+      ss = __shfl(wave_tree64(ss), 0, 64);
+      Stream s(d.k0, d.k1, BNMF_V_SIGMASQ, (uint32_t)g, t);
+      sg_col = rinvgamma(s, hy(d.hAlphaS, g) + (double)K / 2.0, hy(d.hBetaS, g) + 0.5 * ss);
+      if (lane == 0) d.sigmasq[g] = sg_col;
+    }
     // metric terms of the column with the fresh Mhat (R/utils.R:412-471)
     double a_sse = 0.0, a_ll = 0.0, a_kl = 0.0;
     for (int r = 0; r < KR; ++r) {
@@ -209,7 +230,8 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int conver
         const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
         const double mt = m < 1 ? 1e-6 : (double)m;
         a_sse = a_sse + dd * dd;
-        a_ll = a_ll + (((double)m * lmh - mh) - d.lgfact[mi]);
+        if (normal) a_ll = a_ll + dnorm_log((double)m, c, sg_col);           // get_loglik_ normal branch R/utils.R:72-97
+        else a_ll = a_ll + (((double)m * lmh - mh) - d.lgfact[mi]);
         a_kl = a_kl + mt * (d.logm[mi] - lmh);
       }
     }

@@ -87,8 +87,15 @@ __global__ __launch_bounds__(RK_T) void k_rank_ll(Dev d, int n, double* col0, do
         const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
         const double lg = d.lgfact[mi];
         const double h0 = c0 < 1e-6 ? 1e-6 : c0, h1 = c1 < 1e-6 ? 1e-6 : c1;
-        s0 = s0 + (((double)m * dlog(h0) - h0) - lg);    // canonical: lane l adds rows l, l+64, ...
-        s1 = s1 + (((double)m * dlog(h1) - h1) - lg);
+        if (d.likelihood == BNMF_NORMAL) {
+          const double sd = dsqrt(d.sigmasq[g]);
+          const double z0 = ((double)m - c0) / sd, z1 = ((double)m - c1) / sd;
+          s0 = s0 + ((-0.91893853320467274178 - dlog(sd)) - 0.5 * (z0 * z0));
+          s1 = s1 + ((-0.91893853320467274178 - dlog(sd)) - 0.5 * (z1 * z1));
+        } else {
+          s0 = s0 + (((double)m * dlog(h0) - h0) - lg);    // canonical: lane l adds rows l, l+64, ...
+          s1 = s1 + (((double)m * dlog(h1) - h1) - lg);
+        }
       }
     }
     s0 = wave_tree64(s0); s1 = wave_tree64(s1);

@@ -90,7 +90,7 @@ static long id_len(const orc_handle* o, int id) {
     default: return -1;
   }
 }
-static int is_hyper(int id) { return id >= 30 && id < 50; }
+static int is_hyper(int id) { return (id >= 30 && id < 50) || id == ID_ALPHA_S || id == ID_BETA_S; }
 #define AR(id) (o->a[id].p)
 #define HY(id, e) (o->a[id].p[(e) * o->a[id].stride])
 
@@ -408,6 +408,11 @@ static void sample_R(orc_handle* o, uint32_t t, int from_prior) {
   for (int r = 0; r <= N; ++r) { cum = cum + w[r]; if (target < cum) { pick = r; break; } }
   o->R = pick;
 }
+static double dnorm_log_fwd(double x, double mean, double var) {   /* dnorm(x, mean, sqrt(var), log = TRUE) */
+  double sd = sqrt(var);
+  double z = (x - mean) / sd;
+  return (-0.91893853320467274178 - orc_log(sd)) - 0.5 * (z * z);
+}
 static double pois_ll_cell(int32_t m, double mhat) {
   double mh = mhat < 1e-6 ? 1e-6 : mhat;
   return ((double)m * orc_log(mh) - mh) - orc_lgamma((double)m + 1.0);
@@ -440,8 +445,8 @@ static void sample_A(orc_handle* o, uint32_t t, int from_prior) {
           c1 = c1 + (pe * a1) * e;
         }
         int32_t m = o->M[k + K * g];
-        l0[k] = pois_ll_cell(m, c0);
-        l1[k] = pois_ll_cell(m, c1);
+        if (o->cfg.likelihood == LIK_NORMAL) { double sg = AR(ID_SIGMASQ)[g]; l0[k] = dnorm_log_fwd((double)m, c0, sg); l1[k] = dnorm_log_fwd((double)m, c1, sg); }
+        else { l0[k] = pois_ll_cell(m, c0); l1[k] = pois_ll_cell(m, c1); }
       }
       col0[g] = orc_canon_sum(l0, K, 1, 64);
       col1[g] = orc_canon_sum(l1, K, 1, 64);
@@ -641,6 +646,101 @@ static void metrics_cells_mh(orc_handle* o) {
   }
 }
 
+/* ================= Normal likelihood (priors truncnormal / exponential), plain Gibbs =================
+ * sample_Pn_normal(as_proposal = FALSE) R/sample_Pn.R:54-87 with sigmasq_kg = sigmasq_g (:140-147),
+ * the E mirror R/sample_En.R:54-86, and sample_sigmasq R/sample_params.R:275-286. */
+static void sample_P_normal(orc_handle* o, uint32_t t) {
+  const long K = o->cfg.K, G = o->cfg.G, N = o->cfg.N;
+  double* P = AR(ID_P);
+  double* tmp = (double*)malloc(8 * G * 2 * (size_t)(o->cfg.nthreads > 0 ? o->cfg.nthreads : 1));
+  for (long n = 0; n < N; ++n) {
+    double a_n = AR(ID_A)[n];
+    if (a_n == 0.0) { for (long k = 0; k < K; ++k) P[k + K * n] = prior_draw(o, 0, k + K * n, t); continue; }
+    int allzero = 1;
+    for (long g = 0; g < G; ++g) if (AR(ID_E)[n + N * g] != 0.0) { allzero = 0; break; }
+    double* newcol = (double*)malloc(8 * K);
+#pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
+    for (long k = 0; k < K; ++k) {
+      int tid = 0;
+#ifdef _OPENMP
+      tid = omp_get_thread_num();
+#endif
+      double* x1 = tmp + (size_t)tid * 2 * G; double* x2 = x1 + G;
+      double num1 = 0.0, den = 0.0;
+      if (!allzero) {
+        for (long g = 0; g < G; ++g) {
+          double mno = mhat_cell(o, k, g, n, NULL, 0), sg = AR(ID_SIGMASQ)[g];
+          double en = AR(ID_E)[n + N * g];
+          x1[g] = en * (((double)o->M[k + K * g] - mno) / sg);
+          x2[g] = (a_n * (en * en)) * (1.0 / sg);
+        }
+        num1 = canon_rowsum(x1, G); den = canon_rowsum(x2, G);
+      }
+      mh_prior_or_cond(o, 0, k + K * n, t, allzero, num1, den, &newcol[k]);
+    }
+    for (long k = 0; k < K; ++k) P[k + K * n] = newcol[k];
+    free(newcol);
+  }
+  free(tmp);
+}
+static void sample_E_normal(orc_handle* o, uint32_t t) {
+  const long K = o->cfg.K, G = o->cfg.G, N = o->cfg.N;
+  double* E = AR(ID_E);
+  for (long n = 0; n < N; ++n) {
+    double a_n = AR(ID_A)[n];
+    int allzero = 1;
+    for (long k = 0; k < K; ++k) if (AR(ID_P)[k + K * n] != 0.0) { allzero = 0; break; }
+#pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
+    for (long g = 0; g < G; ++g) {
+      long e = n + N * g;
+      if (a_n == 0.0) { E[e] = prior_draw(o, 1, e, t); continue; }
+      double x1[4096], x2[4096];
+      double num1 = 0.0, den = 0.0;
+      if (!allzero) {
+        double sg = AR(ID_SIGMASQ)[g];
+        for (long k = 0; k < K; ++k) {
+          double mno = mhat_cell(o, k, g, n, NULL, 0);
+          double pn = AR(ID_P)[k + K * n];
+          x1[k] = pn * (((double)o->M[k + K * g] - mno) / sg);
+          x2[k] = (a_n * (pn * pn)) * (1.0 / sg);
+        }
+        num1 = orc_canon_sum(x1, K, 1, 64); den = orc_canon_sum(x2, K, 1, 64);
+      }
+      double v;
+      mh_prior_or_cond(o, 1, e, t, allzero, num1, den, &v);
+      E[e] = v;
+    }
+  }
+}
+static void sample_sigmasq(orc_handle* o, uint32_t t) {
+  const long K = o->cfg.K, G = o->cfg.G;
+#pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
+  for (long g = 0; g < G; ++g) {
+    double r2[4096];
+    for (long k = 0; k < K; ++k) { double r = (double)o->M[k + K * g] - mhat_cell(o, k, g, -1, NULL, 0); r2[k] = r * r; }
+    double ss = orc_canon_sum(r2, K, 1, 64);
+    orc_stream s = ST(o, V_SIGMASQ, (uint32_t)g, t);
+    AR(ID_SIGMASQ)[g] = orc_rinvgamma(&s, HY(ID_ALPHA_S, g) + (double)K / 2.0, HY(ID_BETA_S, g) + 0.5 * ss);
+  }
+}
+/* per-cell metric terms, Normal log-likelihood (get_loglik_ normal branch R/utils.R:72-97) */
+static void metrics_cells_normal(orc_handle* o) {
+  const long K = o->cfg.K, G = o->cfg.G;
+#pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
+  for (long g = 0; g < G; ++g) {
+    double a[4096], b[4096], c[4096];
+    double sg = AR(ID_SIGMASQ)[g];
+    for (long k = 0; k < K; ++k) {
+      double mh = mhat_cell(o, k, g, -1, NULL, 0), dummy;
+      cell_terms(o, o->M[k + K * g], mh, &a[k], &dummy, &c[k]);
+      b[k] = dnorm_log((double)o->M[k + K * g], mh, sg);
+    }
+    o->colsse[g] = orc_canon_sum(a, K, 1, 64);
+    o->colll[g] = orc_canon_sum(b, K, 1, 64);
+    o->colkl[g] = orc_canon_sum(c, K, 1, 64);
+  }
+}
+
 /* ---- metrics row: compute_metrics_ R/utils.R:412-455, update_sample_metrics_ :339-348 ---- */
 static void metrics_row(orc_handle* o, double* row) {
   const long K = o->cfg.K, G = o->cfg.G, N = o->cfg.N;
@@ -704,7 +804,6 @@ static int col_has_nan(const double* x, long n, long stride) {
 int orc_init(orc_handle* o, double* metrics_row1) {
   const long K = o->cfg.K, G = o->cfg.G, N = o->cfg.N;
   const int pr = o->cfg.prior;
-  if (o->cfg.likelihood != LIK_POISSON) { snprintf(o->err, 256, "oracle: normal likelihood not implemented"); return -10; }
   /* prior params: redraw column n (P side) / row n (E side) when any entry is missing (NaN) */
   struct ispec { int id, var, side; int hs, hr; } spec[4]; int nspec = 0;
   if (pr == PRIOR_GAMMA) {
@@ -759,7 +858,12 @@ int orc_init(orc_handle* o, double* metrics_row1) {
   if (o->cfg.MH) { double* ap = ensure(o, ID_ACC_P); double* ae_ = ensure(o, ID_ACC_E); (void)ap; (void)ae_; }
   if (!haveA && o->cfg.learning_rank) { sample_R(o, 1, 1); sample_A(o, 1, 1); }
   else if (!o->a[ID_R].set) o->R = (int)N;
-  if (o->cfg.MH) metrics_cells_mh(o); else sample_Z_and_metrics(o, 1);
+  if (o->cfg.likelihood == LIK_NORMAL) {
+    if (!o->a[ID_ALPHA_S].p) { double three = 3.0; orc_set_array(o, ID_ALPHA_S, &three, 1); }
+    if (!o->a[ID_BETA_S].p) { double three = 3.0; orc_set_array(o, ID_BETA_S, &three, 1); }
+    if (!o->a[ID_SIGMASQ].set) { ensure(o, ID_SIGMASQ); sample_sigmasq(o, 1); }
+    metrics_cells_normal(o);
+  } else if (o->cfg.MH) metrics_cells_mh(o); else sample_Z_and_metrics(o, 1);
   if (metrics_row1) metrics_row(o, metrics_row1);
   return 0;
 }
@@ -772,10 +876,12 @@ static void sweep(orc_handle* o) {
   for (long e = 0; e < K * N; ++e) hyper_elem(o, 0, e, t);
 #pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
   for (long e = 0; e < N * G; ++e) hyper_elem(o, 1, e, t);
-  if (o->cfg.MH) { sample_P_mh(o, t); sample_E_mh(o, t); }
+  if (o->cfg.likelihood == LIK_NORMAL) { sample_P_normal(o, t); sample_E_normal(o, t); }
+  else if (o->cfg.MH) { sample_P_mh(o, t); sample_E_mh(o, t); }
   else { sample_P_poisson(o, t, 0); sample_E_poisson(o, t, 0); }
   if (o->cfg.learning_rank) { sample_R(o, t, 0); sample_A(o, t, 0); }
-  if (o->cfg.MH) metrics_cells_mh(o); else sample_Z_and_metrics(o, t);
+  if (o->cfg.likelihood == LIK_NORMAL) { sample_sigmasq(o, t); metrics_cells_normal(o); }
+  else if (o->cfg.MH) metrics_cells_mh(o); else sample_Z_and_metrics(o, t);
 }
 int orc_run(orc_handle* o, int n_iter, int converged, double* metrics /* n_iter x ORC_NMETRIC row-major */) {
   o->converged = converged;

@@ -301,3 +301,29 @@ def test_mh_learned_rank_bitexact():
         assert np.array_equal(o.get("A"), e.get("A")), step
         assert np.array_equal(o.get("E").view(np.uint64), e.get("E").view(np.uint64)), step
         assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), step
+
+
+@pytest.mark.parametrize("prior,lr", [("truncnormal", False), ("exponential", False), ("truncnormal", True)])
+def test_normal_likelihood_chain_bitexact(prior, lr):
+    """Normal likelihood (R/sample_Pn.R:54-87 non-proposal branch, sample_sigmasq R/sample_params.R:275-286),
+    optionally with rank learning on the Normal log-likelihood."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    M, _, _ = synth_counts(96, 600 if not lr else 64, 3, 20250224)
+    N = 5
+    temp = _temp_schedule(100) if lr else None
+    kw = dict(likelihood="normal", prior=prior, MH=False, learning_rank=lr, seed=6, temperature=temp)
+    o = O.Oracle(M, N, nthreads=8, **kw)
+    e = Engine(M, N, **kw)
+    apply_hyperprior_params(o, prior, M, N)
+    apply_hyperprior_params(e, prior, M, N)
+    r0, r1 = o.init(), e.init()
+    assert np.array_equal(r0[:9].view(np.uint64), r1[:9].view(np.uint64))
+    for step in range(3):
+        mo, me = o.run(10), e.run(10)
+        for nm in ("P", "E", "sigmasq", "A"):
+            a, b = o.get(nm), e.get(nm)
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), f"{nm} differs at block {step}"
+        assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64))
+    assert (e.get("sigmasq") > 0).all()
