@@ -610,9 +610,8 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
   h->iter = 1;
   Timer tm{h, false};
   use_slot(h, 1u);
-  if (haveP || haveE) return fail(BNMF_ESTATE, "bnmf_init: user-supplied P/E initial values are not supported yet");
-  launch_pdraw(h, 1u, 1);
-  launch_edraw(h, 1u, 1);
+  launch_pdraw(h, 1u, haveP ? 2 : 1);                       // skip = names(init_params): supplied P / E kept verbatim
+  launch_edraw(h, 1u, haveE ? 2 : 1);
   launch_side(h, 2u, tm);
   if (!haveA && c.learning_rank) {                            // R ~ Uniform{0..N}, A[n] ~ Bernoulli(pi(R))
     hipLaunchKernelGGL(k_rank_R, dim3(1), dim3(64), 0, h->stream, h->dev, 1u, 1);

@@ -155,7 +155,8 @@ __global__ __launch_bounds__(PD_T) void k_pdraw(Dev d, uint32_t t, int from_prio
   for (int k = tid; k < K; k += PD_T) {
     const int e = k + K * n;
     double x;
-    if (from_prior || a_n == 0.0) x = prior_draw<0>(d, e, t);
+    if (from_prior == 2) x = d.P[e];                    // user-supplied initial value kept verbatim
+    else if (from_prior || a_n == 0.0) x = prior_draw<0>(d, e, t);
     else {
       double shape, rate;
       if (d.prior == BNMF_GAMMA) { shape = slot<0>(d, d.Alpha_p, t)[e] + (double)d.ZsumG[e]; rate = slot<0>(d, d.Beta_p, t)[e] + a_n * Esum; }
@@ -189,7 +190,8 @@ __global__ __launch_bounds__(ES_T) void k_edraw(Dev d, uint32_t t, int from_prio
     const int n = (int)(e % d.N);
     const double a_n = d.A[n];
     double x;
-    if (from_prior || a_n == 0.0) x = prior_draw<1>(d, (int)e, t);
+    if (from_prior == 2) x = d.E[e];                    // user-supplied initial value kept verbatim
+    else if (from_prior || a_n == 0.0) x = prior_draw<1>(d, (int)e, t);
     else {
       double shape, rate;
       if (d.prior == BNMF_GAMMA) { shape = slot<1>(d, d.Alpha_e, t)[e] + (double)d.ZsumK[e]; rate = slot<1>(d, d.Beta_e, t)[e] + a_n * d.Psum[n]; }

@@ -327,3 +327,34 @@ def test_normal_likelihood_chain_bitexact(prior, lr):
             assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), f"{nm} differs at block {step}"
         assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64))
     assert (e.get("sigmasq") > 0).all()
+
+
+def test_user_supplied_initial_values():
+    """init_params / init_prior_params are kept verbatim in samples[[1]] (the only executable checks of the
+    reference: vignettes/advanced.qmd:181-185, :245-249, :315-319), NaN columns are re-drawn."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    rng = np.random.default_rng(4)
+    M, _, _ = synth_counts(96, 40, 3, 31)
+    N = 4
+    P0 = rng.gamma(2.0, 0.01, size=(96, N))
+    E0 = rng.gamma(2.0, 500.0, size=(N, 40))
+    Ap = rng.gamma(5.0, 1.0, size=(96, N))
+    Ap[:, 2] = np.nan                       # column 3 missing -> re-drawn from the hyper-prior
+    for fac in (lambda **kw: O.Oracle(M, N, nthreads=4, **kw), lambda **kw: Engine(M, N, window=2, **kw)):
+        pass
+    o = O.Oracle(M, N, prior="gamma", seed=8, save_Z=True, nthreads=4)
+    e = Engine(M, N, prior="gamma", seed=8, save_Z=True, window=2)
+    for c in (o, e):
+        apply_hyperprior_params(c, "gamma", M, N)
+        c.set("P", P0); c.set("E", E0); c.set("Alpha_p", Ap)
+    r0, r1 = o.init(), e.init()
+    assert np.array_equal(e.get("P"), P0) and np.array_equal(e.get("E"), E0)
+    a = e.get("Alpha_p")
+    assert np.array_equal(a[:, [0, 1, 3]], Ap[:, [0, 1, 3]]) and np.isfinite(a[:, 2]).all()
+    assert np.array_equal(e.window("P", 1)[0], P0)          # samples$P[[1]]
+    assert np.array_equal(r0[:9].view(np.uint64), r1[:9].view(np.uint64))
+    mo, me = o.run(5), e.run(5)
+    assert np.array_equal(o.get("Z").astype(np.int32), e.get("Z"))
+    assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64))
