@@ -125,7 +125,7 @@ BNMF_DEV double canon1024_by256(const double* x, long L, long stride, double* bu
 //   blocks [0, N)            : Esum[n] = canonical sum_g E[n,g]   (rate of P's Gamma, R/sample_Pn.R:103-106)
 //   blocks [N, N+nbP)        : hyper sweep of the P-side prior parameters (R/sample_priors.R:150-200)
 //   blocks [N+nbP, ...)      : hyper sweep of the E-side prior parameters
-__global__ __launch_bounds__(RT) void k_side(Dev d, uint32_t t, int nbP) {
+__global__ __launch_bounds__(RT, 4) void k_side(Dev d, uint32_t t, int nbP) {
   __shared__ double buf[RT];
   const int tid = threadIdx.x, blk = blockIdx.x;
   if (blk < d.N) {
