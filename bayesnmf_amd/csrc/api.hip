@@ -217,6 +217,8 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
     slab = (slab + 3) & ~(size_t)3;
     zg.slab_words = (int)slab;
     zg.zacc_words = (int)((N * (size_t)zg.KP + 3) & ~(size_t)3);
+    zg.p_words = h->z_reg ? (int)((2 * K * N + 3) & ~(size_t)3) : 0;     // workgroup copy of P (fp64) for k_zalloc_reg
+    const size_t shared_words = (size_t)zg.zacc_words + zg.p_words;
     // workgroup width.  k_zalloc is VALU-bound and holds 128 VGPRs per lane: at 16 waves/CU it owns the
     // whole register file and starves k_side (side stream) until its tail.  Measured end to end at the
     // metric config (tools_e2e.py): 16 waves/CU 178 us/iter, 12: 169, 10: 176, 8: 161, 2x4: 165, 6: 179.
@@ -224,14 +226,14 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
     constexpr int Z_MAX_WAVES_PER_CU = 8;
     int best_w = 0, best_per_cu = 0, best_total = 0;
     for (int per_cu = 1; per_cu <= 2; ++per_cu)
-      for (int w : {16, 12, 10, 8, 6, 4, 2, 1}) {
-        const size_t lds = ((size_t)zg.zacc_words + (size_t)w * slab) * 4;
+      for (int w : {16, 8, 4, 2, 1}) {
+        const size_t lds = (shared_words + (size_t)w * slab) * 4;
         if (lds * per_cu <= 160 * 1024 && w * per_cu <= Z_MAX_WAVES_PER_CU && w * per_cu > best_total) { best_total = w * per_cu; best_w = w; best_per_cu = per_cu; }
       }
-    if (const char* e = getenv("BNMF_ZW")) { best_w = atoi(e); best_per_cu = ((size_t)zg.zacc_words + (size_t)best_w * slab) * 4 * 2 <= 160 * 1024 ? 2 : 1; }
+    if (const char* e = getenv("BNMF_ZW")) { best_w = atoi(e); best_per_cu = (shared_words + (size_t)best_w * slab) * 4 * 2 <= 160 * 1024 ? 2 : 1; }
     if (best_w == 0) { delete h; return fail(BNMF_EINVAL, "bnmf_create: K*N too large for k_zalloc LDS (slab %zu B); not supported yet", slab * 4); }
     h->z_zw = best_w;
-    h->z_lds = (((size_t)zg.zacc_words + (size_t)best_w * slab) * 4 + 15) & ~(size_t)15;
+    h->z_lds = ((shared_words + (size_t)best_w * slab) * 4 + 15) & ~(size_t)15;
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
     const long resident = (long)prop.multiProcessorCount * best_per_cu;
@@ -430,9 +432,6 @@ static int launch_zalloc(bnmf_handle* h, uint32_t t) {
   const bool sz = h->cfg.save_Z != 0;
   switch (h->z_zw) {
     case 16: return sz ? launch_zalloc_t<true, 1024>(h, t) : launch_zalloc_t<false, 1024>(h, t);
-    case 12: return sz ? launch_zalloc_t<true, 768>(h, t) : launch_zalloc_t<false, 768>(h, t);
-    case 10: return sz ? launch_zalloc_t<true, 640>(h, t) : launch_zalloc_t<false, 640>(h, t);
-    case 6: return sz ? launch_zalloc_t<true, 384>(h, t) : launch_zalloc_t<false, 384>(h, t);
     case 8: return sz ? launch_zalloc_t<true, 512>(h, t) : launch_zalloc_t<false, 512>(h, t);
     case 4: return sz ? launch_zalloc_t<true, 256>(h, t) : launch_zalloc_t<false, 256>(h, t);
     case 2: return sz ? launch_zalloc_t<true, 128>(h, t) : launch_zalloc_t<false, 128>(h, t);

@@ -238,7 +238,7 @@ BNMF_DEV uint32_t wave_sum_u32(uint32_t v) {
   return v;
 }
 struct __attribute__((aligned(16))) u4 { uint32_t x, y, z, w; };
-struct ZGeom { int KP, HW, TR, slab_words, zacc_words; };
+struct ZGeom { int KP, HW, TR, slab_words, zacc_words, p_words; };
 constexpr int ZH = 68;             // pitch of the per-lane histogram rows (16-byte aligned rows)
 template <bool SAVE_Z, int ZT, int NMAX>
 __global__ __launch_bounds__(ZT) void k_zalloc(Dev d, uint32_t t, ZGeom zg, int ablate) {

@@ -26,6 +26,23 @@ BNMF_DEV void cmp_acc4(uint32_t T, uint32_t u0, uint32_t u1, uint32_t u2, uint32
   b3 += (T <= u3) ? 1u : 0u;
 }
 
+// v_cvt_u32_f64 saturates (x >= 2^32 -> 0xFFFFFFFF, x < 0 / NaN -> 0): C's (uint32_t)x is undefined there
+BNMF_DEV uint32_t cvt_u32_sat(double x) {
+  uint32_t r;
+  asm("v_cvt_u32_f64 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+// inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS round trips)
+BNMF_DEV int wave_incl_scan_dpp(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 // only what this kernel needs (the full Dev by value costs ~60 SGPRs and made the hot loop spill SGPRs)
 struct ZArgs {
   int K, G, N, maxM;
@@ -40,13 +57,15 @@ template <bool SAVE_Z, int ZT, int TRC /* threshold registers: multiple of 4, >=
 __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(ZArgs d, uint32_t t, ZGeom zg, int ablate) {
   constexpr int ZW = ZT / 64;
   constexpr int NC = TRC + 1;                            // factors covered by this instantiation
+  constexpr int NMIN = TRC == 8 ? 1 : TRC == 16 ? 10 : TRC - 2;   // smallest N routed here (api.hip: zg.TR)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = d.K, G = d.G, N = d.N;
   const int KP = zg.KP, HW = zg.HW;
   const int KR = (K + 63) >> 6;
   uint32_t* zacc = (uint32_t*)smem;                      // [N][KP] shared by the workgroup
-  uint32_t* slab = zacc + zg.zacc_words + (size_t)wave * zg.slab_words;
+  double* Pl = (double*)(zacc + zg.zacc_words);          // [N][K] P, shared by the workgroup
+  uint32_t* slab = zacc + zg.zacc_words + zg.p_words + (size_t)wave * zg.slab_words;
   uint32_t* hist = slab;                                 // [HW][ZH] per-lane packed 8-bit bucket counts
   uint32_t* thr = hist + HW * ZH;                        // [K][TRC] threshold rows (16-B aligned)
   double* ae = (double*)(thr + (size_t)K * TRC);         // [N]  A[n] * E[n,g]
@@ -54,6 +73,7 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(ZArgs d, uint32_t t, ZGeom
   uint32_t* zkt = qoff + K + 1;                          // [N] column totals
   uint32_t* zloc = zkt + N;                              // [N][KP]  (SAVE_Z only)
   for (int i = tid; i < N * KP; i += ZT) zacc[i] = 0;
+  for (int i = tid; i < K * N; i += ZT) Pl[i] = d.P[i];
   for (int i = lane; i < HW * ZH; i += 64) hist[i] = 0;
   for (int i = lane; i < N; i += 64) zkt[i] = 0;
   if (SAVE_Z) for (int i = lane; i < N * KP; i += 64) zloc[i] = 0;
@@ -81,23 +101,19 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(ZArgs d, uint32_t t, ZGeom
       const int kk = (r << 6) + lane;
       int q = 0, m = 0;
       if (kk < K) {
-        const double* Pk = d.P + kk;
+        const double* Pk = Pl + kk;                       // P[kk, n] = Pl[kk + K n] (workgroup copy in LDS)
         m = d.M[kk + (size_t)K * g];
         double c = 0.0;
-        int nl = -1;
         double pv[NC];
 #pragma unroll
-        for (int n = 0; n < NC; ++n) pv[n] = Pk[(size_t)K * min(n, N - 1)];
-#pragma unroll
         for (int n = 0; n < NC; ++n) {
-          if (n < N) {
-            const double p = pv[n] * ae[n];
-            c = c + p;
-            if (p > 0.0) nl = n;
-          }
+          if (n < NMIN || n < N) c = c + Pk[(size_t)K * n] * ae[n];
           pv[n] = c;
         }
-        if (c > 0.0 && m > 0 && nl >= 0) {
+        if (c > 0.0 && m > 0) {
+          // thr_n = floor(cum_n 2^32 / Mhat), saturating at 2^32-1 = "never".  Factors at/after the last
+          // positive one have cum_n == Mhat, and fl(Mhat * fl(2^32/Mhat)) >= 2^32 (1 - 2^-52) > 2^32 - 1,
+          // so they saturate by themselves (the oracle's explicit `n >= nlast` test is the same set).
           const double scale = 4294967296.0 / c;
           u4* row = (u4*)(thr + (size_t)kk * TRC);
 #pragma unroll
@@ -106,8 +122,8 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(ZArgs d, uint32_t t, ZGeom
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int n = 4 * j + i;
-              uint32_t tj = 0xFFFFFFFFu;                  // "never": beyond the last positive factor
-              if (n < nthr && n < nl) { const double tt = pv[n] * scale; if (tt < 4294967295.0) tj = (uint32_t)tt; }
+              uint32_t tj = 0xFFFFFFFFu;
+              if (n < NMIN - 1 || n < nthr) tj = cvt_u32_sat(pv[n] * scale);
               tv[i] = tj;
             }
             row[j] = u4{tv[0], tv[1], tv[2], tv[3]};
@@ -123,11 +139,9 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(ZArgs d, uint32_t t, ZGeom
         a_ll = a_ll + (((double)m * lmh - mh) - d.lgfact[mi]);
         a_kl = a_kl + mt * (d.logm[mi] - lmh);
       }
-      int incl = q;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+      const int incl = wave_incl_scan_dpp(q);
       if (kk < K) qoff[kk] = (uint32_t)(carry + incl - q) | ((uint32_t)((4 - (m & 3)) & 3) << 30);
-      carry += __shfl(incl, 63, 64);
+      carry += __builtin_amdgcn_readlane(incl, 63);
     }
     if (lane == 0) qoff[K] = (uint32_t)carry;
     a_sse = wave_tree64(a_sse); a_ll = wave_tree64(a_ll); a_kl = wave_tree64(a_kl);

@@ -11,8 +11,11 @@ def mk(env):
     os.environ.update(env)
     e = Engine(M, 20, prior="gamma", seed=1); apply_hyperprior_params(e, "gamma", M, 20); e.init(); e.run(20, metrics=False)
     return e
-variants = [("reg hybrid", {"BNMF_ABLATE": "512"}), ("nophase2", {"BNMF_ABLATE": "514"}), ("nosearch", {"BNMF_ABLATE": "520"}),
-            ("nophilox", {"BNMF_ABLATE": "528"}), ("noatomic", {"BNMF_ABLATE": "516"}), ("none", {"BNMF_ABLATE": "540"}), ("psync", {})]
+ZW = os.environ.get("ABL_ZW", "16")
+variants = [("base", {}), ("nophase2", {"BNMF_ABLATE": "2"}), ("nosearch", {"BNMF_ABLATE": "8"}),
+            ("nophilox", {"BNMF_ABLATE": "16"}), ("noatomic", {"BNMF_ABLATE": "4"}), ("none", {"BNMF_ABLATE": "28"}),
+            ("noflush", {"BNMF_ABLATE": "1"}), ("nophase2_noflush", {"BNMF_ABLATE": "3"})]
+variants = [(n, dict(e, BNMF_ZW=ZW)) for n, e in variants]
 if len(sys.argv) > 1:
     variants = [v for v in variants if v[0] in sys.argv[1:]] or variants
 eng = [(n, mk(env)) for n, env in variants]
