@@ -212,7 +212,7 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
     for (size_t g = 0; g < G; ++g) { long cs = 0; for (size_t k = 0; k < K; ++k) cs += M[k + K * g]; if (cs > colmax) colmax = cs; }
     if (colmax > 4000000) { delete h; return fail(BNMF_EINVAL, "bnmf_create: a column of M sums to %ld (> 4,000,000 counts): unsupported", colmax); }
     size_t slab;
-    if (h->z_reg) slab = (size_t)zg.HW * ZH + K * (size_t)zg.TR + 2 * N + (K + 1) + N + (cfg->save_Z ? N * (size_t)zg.KP : 0);
+    if (h->z_reg) slab = (size_t)zg.HW * ZH + (K + 1) * (size_t)zreg_row_words(zg.TR) + 2 * N + N + (cfg->save_Z ? N * (size_t)zg.KP : 0);
     else slab = (size_t)zg.HW * ZH + 2 * N + (N - 1) * (size_t)zg.KP + (K + 1) + K + N + (cfg->save_Z ? N * (size_t)zg.KP : 0);
     slab = (slab + 3) & ~(size_t)3;
     zg.slab_words = (int)slab;
@@ -416,17 +416,22 @@ static ZArgs zargs(const bnmf_handle* h) {
   const Dev& d = h->dev;
   return ZArgs{d.K, d.G, d.N, d.maxM, d.k0, d.k1, d.M, d.P, d.E, d.A, d.ZsumK, d.ZsumG, d.Z, d.colsse, d.colll, d.colkl, d.lgfact, d.logm};
 }
-template <bool SZ, int ZT_>
-static int launch_zalloc_t(bnmf_handle* h, uint32_t t) {
-  static bool done[5] = {false, false, false, false, false};
-  if (!h->z_reg) return launch_z(h, t, k_zalloc<SZ, ZT_, 0>, h->dev, ZT_, &done[0]);
+template <bool SZ, int ZT_, bool DIAG>
+static int launch_zreg_t(bnmf_handle* h, uint32_t t) {
+  static bool done[4] = {false, false, false, false};
   const ZArgs za = zargs(h);
   switch (h->zg.TR) {
-    case 8: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 8>, za, ZT_, &done[1]);
-    case 16: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 16>, za, ZT_, &done[2]);
-    case 20: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 20>, za, ZT_, &done[3]);
-    default: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 24>, za, ZT_, &done[4]);
+    case 8: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 8, DIAG>, za, ZT_, &done[0]);
+    case 16: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 16, DIAG>, za, ZT_, &done[1]);
+    case 20: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 20, DIAG>, za, ZT_, &done[2]);
+    default: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 24, DIAG>, za, ZT_, &done[3]);
   }
+}
+template <bool SZ, int ZT_>
+static int launch_zalloc_t(bnmf_handle* h, uint32_t t) {
+  static bool done = false;
+  if (!h->z_reg) return launch_z(h, t, k_zalloc<SZ, ZT_, 0>, h->dev, ZT_, &done);
+  return h->z_ablate ? launch_zreg_t<SZ, ZT_, true>(h, t) : launch_zreg_t<SZ, ZT_, false>(h, t);   // DIAG build honours BNMF_ABLATE
 }
 static int launch_zalloc(bnmf_handle* h, uint32_t t) {
   const bool sz = h->cfg.save_Z != 0;

@@ -6,7 +6,7 @@ from bayesnmf_amd import Engine
 from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
 M, _, _ = synth_counts(96, 10000, 8, 20250218)
 def mk(env):
-    for k in ("BNMF_ABLATE", "BNMF_ZGRID", "BNMF_ZW"):
+    for k in ("BNMF_ABLATE", "BNMF_ZGRID", "BNMF_ZW", "BNMF_ZSEARCH"):
         os.environ.pop(k, None)
     os.environ.update(env)
     e = Engine(M, 20, prior="gamma", seed=1); apply_hyperprior_params(e, "gamma", M, 20); e.init(); e.run(20, metrics=False)
@@ -14,6 +14,10 @@ def mk(env):
 ZW = os.environ.get("ABL_ZW", "16")
 variants = [("base", {}), ("nophase2", {"BNMF_ABLATE": "2"}), ("nosearch", {"BNMF_ABLATE": "8"}),
             ("nophilox", {"BNMF_ABLATE": "16"}), ("noatomic", {"BNMF_ABLATE": "4"}), ("none", {"BNMF_ABLATE": "28"}),
+            ("s1", {"BNMF_ZSEARCH": "1"}), ("s1_noatomic", {"BNMF_ZSEARCH": "1", "BNMF_ABLATE": "4"}), ("s1_nophilox", {"BNMF_ZSEARCH": "1", "BNMF_ABLATE": "16"}),
+            ("s1_nohist", {"BNMF_ZSEARCH": "1", "BNMF_ABLATE": "64"}), ("s1_nozacc", {"BNMF_ZSEARCH": "1", "BNMF_ABLATE": "128"}),
+            ("nohist", {"BNMF_ABLATE": "64"}), ("nozacc", {"BNMF_ABLATE": "128"}),
+            ("empty", {"BNMF_ABLATE": "32"}), ("empty_noflush", {"BNMF_ABLATE": "33"}),
             ("noflush", {"BNMF_ABLATE": "1"}), ("nophase2_noflush", {"BNMF_ABLATE": "3"})]
 variants = [(n, dict(e, BNMF_ZW=ZW)) for n, e in variants]
 if len(sys.argv) > 1:
