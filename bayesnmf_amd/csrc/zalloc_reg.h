@@ -246,10 +246,21 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(ZArgs d, uint32_t t, ZGeom
         const u4 h0 = *(const u4*)rowp;                    // {cend, k | pad << 30, next cend, next k | pad}
         int cend = (int)h0.x;
         uint32_t kkpad = h0.y, lnkz = h0.z, lnkw = h0.w;   // link = (end offset, row id) of the next cell of the list
-        u4 pa = *(const u4*)(rowp + 4);                    // pivots 0..3
-        uint32_t pb = HB == 3 ? rowp[8] : 0u;              // pivot 4
         uint32_t* hl = hist + lane;
         const uint32_t gK = (uint32_t)K * (uint32_t)g;
+        // two LDS atomics per count: zacc[n][k] and the lane's packed histogram.  Branch-free: counts beyond the
+        // cell's last one (ND < 4, only in a cell's last quad) add 0
+#define ZATOM(B0, B1, B2, B3, CELL, ND)                                                                            \
+        if (!(DIAG && (ablate & 4))) {                                                                             \
+          uint32_t* zc_ = ztarget + (CELL);                                                                        \
+          const uint32_t a0_ = (ND) > 0 ? 1u : 0u, a1_ = (ND) > 1 ? 1u : 0u, a2_ = (ND) > 2 ? 1u : 0u, a3_ = (ND) > 3 ? 1u : 0u; \
+          atomicAdd(&zc_[mul24(B0, KP)], a0_); atomicAdd(&hl[mul24((B0) >> 2, ZH)], a0_ << (((B0) & 3) << 3));    \
+          atomicAdd(&zc_[mul24(B1, KP)], a1_); atomicAdd(&hl[mul24((B1) >> 2, ZH)], a1_ << (((B1) & 3) << 3));    \
+          atomicAdd(&zc_[mul24(B2, KP)], a2_); atomicAdd(&hl[mul24((B2) >> 2, ZH)], a2_ << (((B2) & 3) << 3));    \
+          atomicAdd(&zc_[mul24(B3, KP)], a3_); atomicAdd(&hl[mul24((B3) >> 2, ZH)], a3_ << (((B3) & 3) << 3));    \
+        }
+        u4 pa = *(const u4*)(rowp + 4);                    // pivots 0..3
+        uint32_t pb = HB == 3 ? rowp[8] : 0u;              // pivot 4
         // quad -> its random words (clamped) and the 4-block of each count (pivot compares)
 #define ZQUAD(QI, U0, U1, U2, U3, J0, J1, J2, J3, CELL, ND)                                                        \
         {                                                                                                          \
@@ -266,17 +277,6 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(ZArgs d, uint32_t t, ZGeom
           if (NPV > 2) cmp_acc4(pa.z, U0, U1, U2, U3, J0, J1, J2, J3);                                             \
           if (NPV > 3) cmp_acc4(pa.w, U0, U1, U2, U3, J0, J1, J2, J3);                                             \
           if (NPV > 4) cmp_acc4(pb, U0, U1, U2, U3, J0, J1, J2, J3);                                               \
-        }
-        // two LDS atomics per count: zacc[n][k] and the lane's packed histogram.  Branch-free: counts beyond the
-        // cell's last one (ND < 4, only in a cell's last quad) add 0
-#define ZATOM(B0, B1, B2, B3, CELL, ND)                                                                            \
-        if (!(DIAG && (ablate & 4))) {                                                                             \
-          uint32_t* zc_ = ztarget + (CELL);                                                                        \
-          const uint32_t a0_ = (ND) > 0 ? 1u : 0u, a1_ = (ND) > 1 ? 1u : 0u, a2_ = (ND) > 2 ? 1u : 0u, a3_ = (ND) > 3 ? 1u : 0u; \
-          atomicAdd(&zc_[mul24(B0, KP)], a0_); atomicAdd(&hl[mul24((B0) >> 2, ZH)], a0_ << (((B0) & 3) << 3));    \
-          atomicAdd(&zc_[mul24(B1, KP)], a1_); atomicAdd(&hl[mul24((B1) >> 2, ZH)], a1_ << (((B1) & 3) << 3));    \
-          atomicAdd(&zc_[mul24(B2, KP)], a2_); atomicAdd(&hl[mul24((B2) >> 2, ZH)], a2_ << (((B2) & 3) << 3));    \
-          atomicAdd(&zc_[mul24(B3, KP)], a3_); atomicAdd(&hl[mul24((B3) >> 2, ZH)], a3_ << (((B3) & 3) << 3));    \
         }
         uint32_t u0, u1, u2, u3, j0, j1, j2, j3, cell; int nd;
         ZQUAD(q0, u0, u1, u2, u3, j0, j1, j2, j3, cell, nd);
@@ -330,8 +330,8 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(ZArgs d, uint32_t t, ZGeom
           u0 = v0; u1 = v1; u2 = v2; u3 = v3; j0 = i0; j1 = i1; j2 = i2; j3 = i3; cell = ncell; nd = nnd;
         }
         ZATOM(pb0, pb1, pb2, pb3, pcell, pnd);
-#undef ZATOM
 #undef ZQUAD
+#undef ZATOM
         ZTOC(3);
       }
       wave_lds_fence();

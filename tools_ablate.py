@@ -2,6 +2,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
+import bayesnmf_amd.engine as _E
+if os.environ.get('ABL_LIB'): _E.LIB_PATH = os.path.abspath(os.environ['ABL_LIB'])
 from bayesnmf_amd import Engine
 from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
 M, _, _ = synth_counts(96, 10000, 8, 20250218)
@@ -14,9 +16,6 @@ def mk(env):
 ZW = os.environ.get("ABL_ZW", "16")
 variants = [("base", {}), ("nophase2", {"BNMF_ABLATE": "2"}), ("nosearch", {"BNMF_ABLATE": "8"}),
             ("nophilox", {"BNMF_ABLATE": "16"}), ("noatomic", {"BNMF_ABLATE": "4"}), ("none", {"BNMF_ABLATE": "28"}),
-            ("s1", {"BNMF_ZSEARCH": "1"}), ("s1_noatomic", {"BNMF_ZSEARCH": "1", "BNMF_ABLATE": "4"}), ("s1_nophilox", {"BNMF_ZSEARCH": "1", "BNMF_ABLATE": "16"}),
-            ("s1_nohist", {"BNMF_ZSEARCH": "1", "BNMF_ABLATE": "64"}), ("s1_nozacc", {"BNMF_ZSEARCH": "1", "BNMF_ABLATE": "128"}),
-            ("nohist", {"BNMF_ABLATE": "64"}), ("nozacc", {"BNMF_ABLATE": "128"}),
             ("empty", {"BNMF_ABLATE": "32"}), ("empty_noflush", {"BNMF_ABLATE": "33"}),
             ("noflush", {"BNMF_ABLATE": "1"}), ("nophase2_noflush", {"BNMF_ABLATE": "3"})]
 variants = [(n, dict(e, BNMF_ZW=ZW)) for n, e in variants]
