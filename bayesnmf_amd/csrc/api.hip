@@ -2,6 +2,7 @@
 // Host side: device memory, one HIP stream per handle, launch sequencing of the sweep
 // (R/bayesNMF_sampler.R:273-285) and of the constructor draws (:232-257).  There is no CPU path.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -35,6 +36,7 @@ struct bnmf_handle {
   hipStream_t side = nullptr;          // side stream: k_side of the next iteration (overlaps k_zalloc)
   hipEvent_t ev_draw = nullptr, ev_side = nullptr, ev_z = nullptr;
   bool side_valid = false;             // k_side of iteration iter+1 has been issued
+  bool red_pending = false; uint32_t red_t = 0; int red_row = 0;   // k_reduce of the previous iteration, issued late
   int iter = 0;
   bool inited = false;
   Dev dev{};
@@ -175,17 +177,17 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
   HIPCHK(hipMalloc(&h->dRedraw, N * sizeof(int)));
   HIPCHK(hipMalloc(&h->dEsum, N * sizeof(double)));
   HIPCHK(hipMalloc(&h->dPsum, N * sizeof(double)));
-  HIPCHK(hipMalloc(&h->dlpPn, 2 * N * sizeof(double)));
+  HIPCHK(hipMalloc(&h->dlpPn, 3 * N * sizeof(double)));
   h->nblkE = (int)((N * G + ES_T - 1) / ES_T);
-  HIPCHK(hipMalloc(&h->dlpE, 2 * (size_t)h->nblkE * sizeof(double)));
-  HIPCHK(hipMalloc(&h->dcol, 2 * 3 * G * sizeof(double)));   // per-column partials, 2 slots (t & 1)
+  HIPCHK(hipMalloc(&h->dlpE, 3 * (size_t)h->nblkE * sizeof(double)));
+  HIPCHK(hipMalloc(&h->dcol, 3 * 3 * G * sizeof(double)));   // per-column partials, 3 slots (t % 3)
   if (cfg->learning_rank) HIPCHK(hipMalloc(&h->dRankCol, 2 * G * sizeof(double)));
   if (cfg->MH || cfg->likelihood == BNMF_NORMAL) {
     h->mh_S = (int)((G + MH_SEG - 1) / MH_SEG);
     HIPCHK(hipMalloc(&h->dProp, K * sizeof(double)));
     HIPCHK(hipMalloc(&h->dPart, K * (size_t)h->mh_S * 4 * sizeof(double)));
-    HIPCHK(hipMalloc(&h->dAccPn, 2 * N * sizeof(double)));
-    HIPCHK(hipMalloc(&h->dAccEpart, 2 * (size_t)h->nblkE * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dAccPn, 3 * N * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dAccEpart, 3 * (size_t)h->nblkE * sizeof(double)));
     HIPCHK(hipMalloc(&h->dNzE, N * sizeof(int)));
   }
   HIPCHK(hipMalloc(&h->dLut, 2 * (size_t)(mx + 1) * sizeof(double)));
@@ -372,15 +374,18 @@ static int ensure_metrics(bnmf_handle* h, size_t rows) {
 // The per-iteration partial sums (per-column metric terms, log-prior partials, acceptance partials) live
 // in two slots selected by t & 1, so that k_reduce of iteration t can run on the side stream while the
 // main stream already writes iteration t+1's partials.
-static void use_slot(bnmf_handle* h, uint32_t t) {
-  const size_t sl = t & 1u, G = h->cfg.G, N = h->cfg.N;
-  Dev& d = h->dev;
+// Per-iteration partial sums (per-column metric terms, log-prior partials, MH acceptance partials) live in
+// three slots (t % 3): k_reduce of iteration t is issued during iteration t+1 (see launch_side), and the
+// next writers of its slot are the kernels of iteration t+3, ordered behind it through ev_side.
+static void set_slot(const bnmf_handle* h, Dev& d, uint32_t t) {
+  const size_t sl = t % 3u, G = h->cfg.G, N = h->cfg.N;
   d.colsse = h->dcol + sl * 3 * G; d.colll = d.colsse + G; d.colkl = d.colsse + 2 * G;
   d.lpE_part = h->dlpE + sl * (size_t)h->nblkE;
   d.lpPn = h->dlpPn + sl * N;
 }
-static double* accPn_slot(bnmf_handle* h, uint32_t t) { return h->dAccPn ? h->dAccPn + (size_t)(t & 1u) * h->cfg.N : nullptr; }
-static double* accEp_slot(bnmf_handle* h, uint32_t t) { return h->dAccEpart ? h->dAccEpart + (size_t)(t & 1u) * h->nblkE : nullptr; }
+static void use_slot(bnmf_handle* h, uint32_t t) { set_slot(h, h->dev, t); }
+static double* accPn_slot(const bnmf_handle* h, uint32_t t) { return h->dAccPn ? h->dAccPn + (size_t)(t % 3u) * h->cfg.N : nullptr; }
+static double* accEp_slot(const bnmf_handle* h, uint32_t t) { return h->dAccEpart ? h->dAccEpart + (size_t)(t % 3u) * h->nblkE : nullptr; }
 struct Timer {   // optional per-kernel HIP-event bracketing (serialises the two streams: profile mode only)
   bnmf_handle* h; bool on; double acc[BNMF_NKERNEL]{}; int cnt[BNMF_NKERNEL]{};
   void begin(int k, hipStream_t st) { if (on) { hipStreamSynchronize(h->stream); hipStreamSynchronize(h->side); hipEventRecord(h->ev[2 * k], st); } }
@@ -395,16 +400,26 @@ static void launch_edraw(bnmf_handle* h, uint32_t t, int from_prior) {
 }
 // k_side for iteration t (reads P_{t-1}, E_{t-1}): issued on the side stream right after the draws
 // of iteration t-1, so that it overlaps k_zalloc of iteration t-1
-static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm) {
+static void issue_reduce(bnmf_handle* h, uint32_t t, int row, Timer& tm) {
+  Dev dr = h->dev;
+  set_slot(h, dr, t);
+  tm.begin(KN_REDUCE, h->side);
+  hipLaunchKernelGGL(k_reduce, dim3(h->cfg.MH ? 5 : 4), dim3(RT), 0, h->side, dr, row, h->nblkE, (const double*)accPn_slot(h, t), (const double*)accEp_slot(h, t));
+  tm.end(KN_REDUCE, h->side);
+}
+static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm, bool draw_recorded = false) {
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
   const int nbE = (int)(((size_t)h->cfg.N * h->cfg.G + RT - 1) / RT);
-  hipEventRecord(h->ev_draw, h->stream);
+  if (!draw_recorded) hipEventRecord(h->ev_draw, h->stream);   // else: ev_draw is the stop event of the k_edraw dispatch itself
   hipStreamWaitEvent(h->side, h->ev_draw, 0);
   tm.begin(KN_SIDE, h->side);
   hipLaunchKernelGGL(k_side, dim3(h->cfg.N + nbP + nbE), dim3(RT), 0, h->side, h->dev, t, nbP);
   tm.end(KN_SIDE, h->side);
   hipEventRecord(h->ev_side, h->side);
   h->side_valid = true;
+  // k_reduce of the PREVIOUS iteration: its inputs are complete once the draws of this iteration have run
+  // (main-stream order), which ev_draw above implies, so the main stream needs no marker after k_zalloc
+  if (h->red_pending) { issue_reduce(h, h->red_t, h->red_row, tm); h->red_pending = false; }
 }
 template <typename KernelT, typename ArgT>
 static int launch_z(bnmf_handle* h, uint32_t t, KernelT kern, const ArgT& arg, int zt, bool* attr_done) {
@@ -484,13 +499,18 @@ static int launch_record(bnmf_handle* h, uint32_t t) {
   return 0;
 }
 // k_reduce of iteration t: on the side stream, after the main stream has finished k_zalloc / metrics of t
+// metrics of iteration t: sum(A) now (main stream, right after the rank update); the canonical reductions later
 static void launch_reduce(bnmf_handle* h, uint32_t t, int row, Timer& tm) {
   if (h->cfg.learning_rank) hipLaunchKernelGGL(k_sumA, dim3(1), dim3(64), 0, h->stream, h->dev, row, (const double*)accPn_slot(h, t));
+  h->red_pending = true; h->red_t = t; h->red_row = row;
+}
+// ... or at once (init, end of a run): the side stream waits for everything issued on the main stream so far
+static void flush_reduce(bnmf_handle* h, Timer& tm) {
+  if (!h->red_pending) return;
   hipEventRecord(h->ev_z, h->stream);
   hipStreamWaitEvent(h->side, h->ev_z, 0);
-  tm.begin(KN_REDUCE, h->side);
-  hipLaunchKernelGGL(k_reduce, dim3(h->cfg.MH ? 5 : 4), dim3(RT), 0, h->side, h->dev, row, h->nblkE, (const double*)accPn_slot(h, t), (const double*)accEp_slot(h, t));
-  tm.end(KN_REDUCE, h->side);
+  issue_reduce(h, h->red_t, h->red_row, tm);
+  h->red_pending = false;
 }
 // P and E updates of the MH models (R/sample_params.R:56-64 with sample_Pn/_En -> *_normal -> MH_*_poisson)
 static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged) {
@@ -543,8 +563,10 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   if (!h->side_valid) launch_side(h, t, tm);               // first sweep after init / set_array
   hipStreamWaitEvent(h->stream, h->ev_side, 0);            // prior params + Esum of iteration t ready
   tm.begin(KN_PDRAW, h->stream); launch_pdraw(h, t, 0); tm.end(KN_PDRAW, h->stream);
-  tm.begin(KN_EDRAW, h->stream); launch_edraw(h, t, 0); tm.end(KN_EDRAW, h->stream);
-  launch_side(h, t + 1, tm);                               // overlaps the rank update / k_zalloc below
+  // ev_draw rides on the k_edraw dispatch (stop event): no marker packet between k_edraw and k_zalloc
+  if (tm.on) { tm.begin(KN_EDRAW, h->stream); launch_edraw(h, t, 0); tm.end(KN_EDRAW, h->stream); }
+  else hipExtLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, 0);
+  launch_side(h, t + 1, tm, !tm.on);                       // overlaps the rank update / k_zalloc below
   if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
   tm.begin(KN_OTHER, h->stream); if (int rc = launch_record(h, t)) return rc; tm.end(KN_OTHER, h->stream);
   tm.begin(KN_ZALLOC, h->stream); if (int rc = launch_zalloc(h, t)) return rc; tm.end(KN_ZALLOC, h->stream);
@@ -632,6 +654,7 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
   if (c.MH || c.likelihood == BNMF_NORMAL) launch_mh_metrics(h, 1u, true);
   else if (int rc = launch_zalloc(h, 1u)) return rc;
   launch_reduce(h, 1u, 0, tm);
+  flush_reduce(h, tm);
   hipEventRecord(h->ev_z, h->side); hipStreamWaitEvent(h->stream, h->ev_z, 0);
   hipLaunchKernelGGL(k_compose, dim3(1), dim3(64), 0, h->stream, h->dev, 1, 1u);
   HIPCHK(hipGetLastError());
@@ -651,6 +674,7 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
   if (int rc = ensure_metrics(h, (size_t)n_iter)) return rc;
   const uint32_t t0 = (uint32_t)h->iter + 1;
   for (int i = 0; i < n_iter; ++i) if (int rc = ((h->cfg.MH || h->cfg.likelihood == BNMF_NORMAL) ? sweep_mh(h, i, h->cfg.MH ? converged : 0, tm) : sweep(h, i, tm))) return rc;
+  flush_reduce(h, tm);
   hipEventRecord(h->ev_z, h->side); hipStreamWaitEvent(h->stream, h->ev_z, 0);   // last k_reduce done
   hipLaunchKernelGGL(k_compose, dim3((n_iter + 63) / 64), dim3(64), 0, h->stream, h->dev, n_iter, t0);
   HIPCHK(hipGetLastError());
