@@ -213,27 +213,48 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
     long colmax = 0;
     for (size_t g = 0; g < G; ++g) { long cs = 0; for (size_t k = 0; k < K; ++k) cs += M[k + K * g]; if (cs > colmax) colmax = cs; }
     if (colmax > 4000000) { delete h; return fail(BNMF_EINVAL, "bnmf_create: a column of M sums to %ld (> 4,000,000 counts): unsupported", colmax); }
-    size_t slab;
-    if (h->z_reg) slab = (size_t)zg.HW * ZH + (K + 1) * (size_t)zreg_row_words(zg.TR) + 2 * N + N + (cfg->save_Z ? N * (size_t)zg.KP : 0);
-    else slab = (size_t)zg.HW * ZH + 2 * N + (N - 1) * (size_t)zg.KP + (K + 1) + K + N + (cfg->save_Z ? N * (size_t)zg.KP : 0);
-    slab = (slab + 3) & ~(size_t)3;
-    zg.slab_words = (int)slab;
-    zg.zacc_words = (int)((N * (size_t)zg.KP + 3) & ~(size_t)3);
-    zg.p_words = h->z_reg ? (int)((2 * K * N + 3) & ~(size_t)3) : 0;     // workgroup copy of P (fp64) for k_zalloc_reg
-    const size_t shared_words = (size_t)zg.zacc_words + zg.p_words;
-    // workgroup width.  k_zalloc is VALU-bound and holds 128 VGPRs per lane: at 16 waves/CU it owns the
-    // whole register file and starves k_side (side stream) until its tail.  Measured end to end at the
-    // metric config (tools_e2e.py): 16 waves/CU 178 us/iter, 12: 169, 10: 176, 8: 161, 2x4: 165, 6: 179.
-    // So: at most 8 waves per CU, in one workgroup when LDS allows.
+    // LDS need of a geometry; the general kernel (k_zalloc) takes the whole column in one row chunk when that
+    // leaves room for at least two waves per workgroup, else row chunks of 64 with ZsumG kept in global memory
+    bool force_chunk = false;
+    if (const char* e = getenv("BNMF_ZCHUNK")) force_chunk = atoi(e) != 0;   // diagnostics / tests
+    size_t slab = 0, shared_words = 0;
+    auto geometry = [&](bool chunked) {
+      if (h->z_reg) {
+        zg.KC = (int)K;
+        slab = (size_t)zg.HW * ZH + (K + 1) * (size_t)zreg_row_words(zg.TR) + 2 * N + N + (cfg->save_Z ? N * (size_t)zg.KP : 0);
+        zg.zacc_words = (int)((N * (size_t)zg.KP + 3) & ~(size_t)3);
+        zg.p_words = (int)((2 * K * N + 3) & ~(size_t)3);                  // workgroup copy of P (fp64)
+      } else {
+        zg.KC = chunked ? 64 : (int)((K + 63) & ~(size_t)63);
+        zg.KP = chunked ? 65 : ((K % 32 == 0) ? (int)K + 1 : (int)(K | 1));
+        const bool loc = chunked || cfg->save_Z;
+        slab = (size_t)zg.HW * ZH + 2 * N + (N - 1) * (size_t)zg.KP + (zg.KC + 1) + zg.KC + N + (loc ? N * (size_t)zg.KP : 0);
+        zg.zacc_words = chunked ? 0 : (int)((N * (size_t)zg.KP + 3) & ~(size_t)3);
+        zg.p_words = 0;
+      }
+      slab = (slab + 3) & ~(size_t)3;
+      zg.slab_words = (int)slab;
+      shared_words = (size_t)zg.zacc_words + zg.p_words;
+    };
+    // workgroup width.  k_zalloc holds 128 VGPRs per lane: at 16 waves/CU it owns the whole register file and
+    // starves k_side (side stream) until its tail.  Measured end to end at the metric config (tools_e2e.py):
+    // 16 waves/CU 178 us/iter, 12: 169, 10: 176, 8: 161, 2x4: 165, 6: 179.  So: at most 8 waves per CU, in one
+    // workgroup when LDS allows.
     constexpr int Z_MAX_WAVES_PER_CU = 8;
     int best_w = 0, best_per_cu = 0, best_total = 0;
-    for (int per_cu = 1; per_cu <= 2; ++per_cu)
-      for (int w : {16, 8, 4, 2, 1}) {
-        const size_t lds = (shared_words + (size_t)w * slab) * 4;
-        if (lds * per_cu <= 160 * 1024 && w * per_cu <= Z_MAX_WAVES_PER_CU && w * per_cu > best_total) { best_total = w * per_cu; best_w = w; best_per_cu = per_cu; }
-      }
+    auto pick = [&]() {
+      best_w = best_per_cu = best_total = 0;
+      for (int per_cu = 1; per_cu <= 2; ++per_cu)
+        for (int w : {16, 8, 4, 2, 1}) {
+          const size_t lds = (shared_words + (size_t)w * slab) * 4;
+          if (lds * per_cu <= 160 * 1024 && w * per_cu <= Z_MAX_WAVES_PER_CU && w * per_cu > best_total) { best_total = w * per_cu; best_w = w; best_per_cu = per_cu; }
+        }
+    };
+    geometry(force_chunk && !h->z_reg);
+    pick();
+    if (!h->z_reg && best_total < 2 && !force_chunk) { geometry(true); pick(); }
     if (const char* e = getenv("BNMF_ZW")) { best_w = atoi(e); best_per_cu = (shared_words + (size_t)best_w * slab) * 4 * 2 <= 160 * 1024 ? 2 : 1; }
-    if (best_w == 0) { delete h; return fail(BNMF_EINVAL, "bnmf_create: K*N too large for k_zalloc LDS (slab %zu B); not supported yet", slab * 4); }
+    if (best_w == 0) { delete h; return fail(BNMF_EINVAL, "bnmf_create: N = %zu needs %zu B of LDS per wavefront for the allocation kernel (limit 160 KiB): unsupported", N, slab * 4); }
     h->z_zw = best_w;
     h->z_lds = ((shared_words + (size_t)best_w * slab) * 4 + 15) & ~(size_t)15;
     hipDeviceProp_t prop;
@@ -445,7 +466,7 @@ static int launch_zreg_t(bnmf_handle* h, uint32_t t) {
 template <bool SZ, int ZT_>
 static int launch_zalloc_t(bnmf_handle* h, uint32_t t) {
   static bool done = false;
-  if (!h->z_reg) return launch_z(h, t, k_zalloc<SZ, ZT_, 0>, h->dev, ZT_, &done);
+  if (!h->z_reg) return launch_z(h, t, k_zalloc<SZ, ZT_>, h->dev, ZT_, &done);
   return h->z_ablate ? launch_zreg_t<SZ, ZT_, true>(h, t) : launch_zreg_t<SZ, ZT_, false>(h, t);   // DIAG build honours BNMF_ABLATE
 }
 static int launch_zalloc(bnmf_handle* h, uint32_t t) {

@@ -238,76 +238,56 @@ BNMF_DEV uint32_t wave_sum_u32(uint32_t v) {
   return v;
 }
 struct __attribute__((aligned(16))) u4 { uint32_t x, y, z, w; };
-struct ZGeom { int KP, HW, TR, slab_words, zacc_words, p_words; };
+struct ZGeom { int KP, HW, TR, KC, slab_words, zacc_words, p_words; };
 constexpr int ZH = 68;             // pitch of the per-lane histogram rows (16-byte aligned rows)
-template <bool SAVE_Z, int ZT, int NMAX>
+// General kernel (any N, any K): the rows of a column are processed in chunks of zg.KC rows (a multiple of
+// 64; KC >= K, i.e. one chunk, whenever the whole column's thresholds fit the wave's LDS slab).  With more
+// than one chunk the workgroup-level zacc[n][k] does not fit LDS either (zg.zacc_words == 0): the chunk's counts
+// go to the wave's zloc[n][k - kbase] and its non-zero entries are flushed to ZsumG with global integer
+// atomics at the end of the chunk.  Metric accumulators and the ZsumK histogram run across the chunks of a
+// column in row order, so the results are bit-identical to the one-chunk mapping.
+template <bool SAVE_Z, int ZT>
 __global__ __launch_bounds__(ZT) void k_zalloc(Dev d, uint32_t t, ZGeom zg, int ablate) {
-  // `ablate` is a diagnostic bitmask (0 in production): 1 no flush, 2 no phase 2, 4 no LDS atomics,
-  // 8 no threshold search, 16 no Philox
   constexpr int ZW = ZT / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = d.K, G = d.G, N = d.N;
-  const int KP = zg.KP, HW = zg.HW;
-  const int KR = (K + 63) >> 6;                          // row rounds per lane
-  uint32_t* zacc = (uint32_t*)smem;                      // [N][KP] shared by the workgroup
+  const int KP = zg.KP, HW = zg.HW, KC = zg.KC;          // KP: pitch of the [n][row] LDS arrays (>= min(K, KC), odd)
+  const bool chunked = zg.zacc_words == 0;
+  const bool use_loc = SAVE_Z || chunked;
+  uint32_t* zacc = (uint32_t*)smem;                      // [N][KP] shared by the workgroup (one-chunk mode only)
   uint32_t* slab = zacc + zg.zacc_words + (size_t)wave * zg.slab_words;
   uint32_t* hist = slab;                                 // [HW][ZH] per-lane packed 8-bit bucket counts (16-B aligned)
   double* ae = (double*)(hist + HW * ZH);                // [N]  A[n] * E[n,g]
-  uint32_t* thr = (uint32_t*)(ae + N);                   // [N-1][KP] thresholds
-  uint32_t* qoff = thr + (size_t)(N - 1) * KP;           // [K+1]  quad offset (22 bits) | nlast << 22
-  int* mcnt = (int*)(qoff + K + 1);                      // [K]
-  uint32_t* zkt = (uint32_t*)(mcnt + K);                 // [N] column totals
-  uint32_t* zloc = zkt + N;                              // [N][KP]  (SAVE_Z only)
-  for (int i = tid; i < N * KP; i += ZT) zacc[i] = 0;
+  uint32_t* thr = (uint32_t*)(ae + N);                   // [N-1][KP] thresholds of the current chunk
+  uint32_t* qoff = thr + (size_t)(N - 1) * KP;           // [KC+1]  quad offset (22 bits) | nlast << 22
+  int* mcnt = (int*)(qoff + KC + 1);                     // [KC]
+  uint32_t* zkt = (uint32_t*)(mcnt + KC);                // [N] column totals
+  uint32_t* zloc = zkt + N;                              // [N][KP]  (SAVE_Z or chunked)
+  for (int i = tid; i < zg.zacc_words; i += ZT) zacc[i] = 0;
   for (int i = lane; i < HW * ZH; i += 64) hist[i] = 0;
   for (int i = lane; i < N; i += 64) zkt[i] = 0;
-  if (SAVE_Z) for (int i = lane; i < N * KP; i += 64) zloc[i] = 0;
+  if (use_loc) for (int i = lane; i < N * KP; i += 64) zloc[i] = 0;
   __syncthreads();
   const int nthr = N - 1;
-  uint32_t* ztarget = SAVE_Z ? zloc : zacc;
+  uint32_t* ztarget = use_loc ? zloc : zacc;
   const int gw = blockIdx.x * ZW + wave, nw = gridDim.x * ZW;
   for (int g = gw; g < G; g += nw) {
-    // ---------------- phase 1
     double a_sse = 0.0, a_ll = 0.0, a_kl = 0.0;
-    int carry = 0;
     const double* Eg = d.E + (size_t)N * g;
     for (int n = lane; n < N; n += 64) ae[n] = d.A[n] * Eg[n];
     wave_lds_fence();
-    for (int r = 0; r < KR; ++r) {
-      const int kk = (r << 6) + lane;
-      int q = 0, nl = -1;
-      if (kk < K) {
-        const double* Pk = d.P + kk;
-        const int m = d.M[kk + (size_t)K * g];
-        double c = 0.0;
-        if (NMAX > 0) {
-          // single pass: all P loads in flight, cumulative sums kept in registers
-          double pv[NMAX > 0 ? NMAX : 1];
-#pragma unroll
-          for (int n = 0; n < NMAX; ++n) pv[n] = (ablate & 128) ? 1.0 + n : Pk[(size_t)K * min(n, N - 1)];
-#pragma unroll
-          for (int n = 0; n < NMAX; ++n) {
-            if (n < N) {
-              const double p = pv[n] * ae[n];
-              c = c + p;
-              if (p > 0.0) nl = n;
-            }
-            pv[n] = c;
-          }
-          if (c > 0.0 && m > 0 && nl >= 0 && (ablate & 32)) q = (m + 3) >> 2;
-          else if (c > 0.0 && m > 0 && nl >= 0) {
-            const double scale = 4294967296.0 / c;
-#pragma unroll
-            for (int n = 0; n < NMAX; ++n) {
-              if (n < nthr) {
-                const double tt = pv[n] * scale;
-                thr[(size_t)n * KP + kk] = (n >= nl || tt >= 4294967295.0) ? 0xFFFFFFFFu : (uint32_t)tt;
-              }
-            }
-            q = (m + 3) >> 2;
-          }
-        } else {
+    for (int kbase = 0; kbase < K; kbase += KC) {
+      const int kend = min(K, kbase + KC), kc = kend - kbase;
+      // ---------------- phase 1: thresholds, metric terms and quad counts of rows [kbase, kend)
+      int carry = 0;
+      for (int r = 0; (r << 6) < kc; ++r) {
+        const int cl = (r << 6) + lane, kk = kbase + cl;   // row within the chunk / in the matrix
+        int q = 0, nl = -1;
+        if (cl < kc) {
+          const double* Pk = d.P + kk;
+          const int m = d.M[kk + (size_t)K * g];
+          double c = 0.0;
           for (int n0 = 0; n0 < N; n0 += 8) {             // 8 independent P loads in flight
             double pv[8];
 #pragma unroll
@@ -333,95 +313,85 @@ __global__ __launch_bounds__(ZT) void k_zalloc(Dev d, uint32_t t, ZGeom zg, int 
                 if (n0 + j < nthr) {
                   cc = cc + pv[j] * ae[n0 + j];
                   const double tt = cc * scale;
-                  thr[(size_t)(n0 + j) * KP + kk] = (n0 + j >= nl || tt >= 4294967295.0) ? 0xFFFFFFFFu : (uint32_t)tt;
+                  thr[(size_t)(n0 + j) * KP + cl] = (n0 + j >= nl || tt >= 4294967295.0) ? 0xFFFFFFFFu : (uint32_t)tt;
                 }
               }
             }
             q = (m + 3) >> 2;
           }
+          const double dd = c - (double)m;
+          const double mh = c < 1e-6 ? 1e-6 : c;
+          const double lmh = dlog(mh);
+          const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
+          const double mt = m < 1 ? 1e-6 : (double)m;
+          a_sse = a_sse + dd * dd;                        // canonical: lane l adds rows l, l+64, ...
+          a_ll = a_ll + (((double)m * lmh - mh) - d.lgfact[mi]);
+          a_kl = a_kl + mt * (d.logm[mi] - lmh);
+          mcnt[cl] = q > 0 ? m : 0;
         }
-        const double dd = c - (double)m;
-        const double mh = c < 1e-6 ? 1e-6 : c;
-        const double lmh = (ablate & 64) ? mh : dlog(mh);
-        const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
-        const double mt = m < 1 ? 1e-6 : (double)m;
-        a_sse = a_sse + dd * dd;                          // canonical: lane l adds rows l, l+64, ...
-        a_ll = a_ll + (((double)m * lmh - mh) - d.lgfact[mi]);
-        a_kl = a_kl + mt * (d.logm[mi] - lmh);
-        mcnt[kk] = q > 0 ? m : 0;
-      }
-      int incl = q;
+        int incl = q;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-      if (kk < K) qoff[kk] = (uint32_t)(carry + incl - q) | ((uint32_t)(nl < 0 ? 0 : nl) << 22);
-      carry += __shfl(incl, 63, 64);
-    }
-    const int Q = carry;
-    if (lane == 0) qoff[K] = (uint32_t)Q;
-    a_sse = wave_tree64(a_sse); a_ll = wave_tree64(a_ll); a_kl = wave_tree64(a_kl);
-    if (lane == 0) { d.colsse[g] = a_sse; d.colll[g] = a_ll; d.colkl[g] = a_kl; }
-    wave_lds_fence();
-    // ---------------- phase 2: lane takes quads [q0, q1), in chunks of <= 63 quads so that the
-    // packed 8-bit per-lane histogram cannot overflow (<= 252 counts per flush)
-    const int per = (Q + 63) >> 6;
-    for (int cbase = 0; cbase < per; cbase += 63) {
-      const int q0 = min(Q, lane * per + cbase);
-      const int q1 = min(Q, min(lane * per + per, q0 + 63));
-      if (q0 < q1 && !(ablate & 2)) {
-        int cell;
-        {  // upper_bound(qoff[0..K] & mask, q0) - 1, branch-free
-          int b = 0, len = K + 1;
-          while (len > 1) { const int half = len >> 1; b = ((int)(qoff[b + half - 1] & 0x3FFFFFu) <= q0) ? b + half : b; len -= half; }
-          cell = b + ((int)(qoff[b] & 0x3FFFFFu) <= q0 ? 1 : 0) - 1;
-        }
-        uint32_t qw = qoff[cell];
-        int cstart = (int)(qw & 0x3FFFFFu), nl = (int)(qw >> 22);
-        int cend = (int)(qoff[cell + 1] & 0x3FFFFFu);
-        int mc = mcnt[cell];
-        for (int qi = q0; qi < q1; ++qi) {
-          if (qi >= cend) {
-            do { ++cell; qw = qoff[cell]; cstart = cend; cend = (int)(qoff[cell + 1] & 0x3FFFFFu); } while (qi >= cend);
-            nl = (int)(qw >> 22);
-            mc = mcnt[cell];
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        if (cl < kc) qoff[cl] = (uint32_t)(carry + incl - q) | ((uint32_t)(nl < 0 ? 0 : nl) << 22);
+        carry += __shfl(incl, 63, 64);
+      }
+      const int Q = carry;
+      if (lane == 0) qoff[kc] = (uint32_t)Q;
+      wave_lds_fence();
+      // ---------------- phase 2: lane takes quads [q0, q1) of the chunk, in sub-chunks of <= 63 quads so that
+      // the packed 8-bit per-lane histogram cannot overflow (<= 252 counts per flush)
+      const int per = (Q + 63) >> 6;
+      for (int cbase = 0; cbase < per; cbase += 63) {
+        const int q0 = min(Q, lane * per + cbase);
+        const int q1 = min(Q, min(lane * per + per, q0 + 63));
+        if (q0 < q1) {
+          int cell;
+          {  // upper_bound(qoff[0..kc] & mask, q0) - 1, branch-free
+            int b = 0, len = kc + 1;
+            while (len > 1) { const int half = len >> 1; b = ((int)(qoff[b + half - 1] & 0x3FFFFFu) <= q0) ? b + half : b; len -= half; }
+            cell = b + ((int)(qoff[b] & 0x3FFFFFu) <= q0 ? 1 : 0) - 1;
           }
-          const int j0 = (qi - cstart) << 2;
-          const int nd = mc - j0;                          // >= 1; draws of this quad = min(4, nd)
-          u32x4 w;
-          if (ablate & 16) w = u32x4{(uint32_t)qi * 2654435761u, (uint32_t)qi * 40503u, (uint32_t)qi, ~(uint32_t)qi};
-          else w = philox4x32_10((uint32_t)(j0 >> 2), (uint32_t)(cell + (size_t)K * g), t, BNMF_V_Z, d.k0, d.k1);
-          const uint32_t* col = thr + cell;
-          const uint32_t u0 = min(w.x, 0xFFFFFFFEu), u1 = min(w.y, 0xFFFFFFFEu), u2 = min(w.z, 0xFFFFFFFEu), u3 = min(w.w, 0xFFFFFFFEu);
-          int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-          if (nthr > 0 && !(ablate & 8)) {
-            int len = nthr;
-            while (len > 1) {                             // 4 interleaved branch-free searches
-              const int half = len >> 1, off = half - 1;
-              const uint32_t t0 = col[(b0 + off) * KP], t1 = col[(b1 + off) * KP], t2 = col[(b2 + off) * KP], t3 = col[(b3 + off) * KP];
-              b0 = (t0 <= u0) ? b0 + half : b0;
-              b1 = (t1 <= u1) ? b1 + half : b1;
-              b2 = (t2 <= u2) ? b2 + half : b2;
-              b3 = (t3 <= u3) ? b3 + half : b3;
-              len -= half;
+          uint32_t qw = qoff[cell];
+          int cstart = (int)(qw & 0x3FFFFFu);
+          int cend = (int)(qoff[cell + 1] & 0x3FFFFFu);
+          int mc = mcnt[cell];
+          for (int qi = q0; qi < q1; ++qi) {
+            if (qi >= cend) {
+              do { ++cell; cstart = cend; cend = (int)(qoff[cell + 1] & 0x3FFFFFu); } while (qi >= cend);
+              mc = mcnt[cell];
             }
-            b0 += (col[b0 * KP] <= u0) ? 1 : 0;
-            b1 += (col[b1 * KP] <= u1) ? 1 : 0;
-            b2 += (col[b2 * KP] <= u2) ? 1 : 0;
-            b3 += (col[b3 * KP] <= u3) ? 1 : 0;
-          }
-          uint32_t* zc = ztarget + cell;
-          uint32_t* hl = hist + lane;
-          if (ablate & 4) { if (b0 + b1 + b2 + b3 + nl == -12345) zc[0] = w.x; }
-          else {
+            const int j0 = (qi - cstart) << 2;
+            const int nd = mc - j0;                        // >= 1; draws of this quad = min(4, nd)
+            const u32x4 w = philox4x32_10((uint32_t)(j0 >> 2), (uint32_t)(kbase + cell + (size_t)K * g), t, BNMF_V_Z, d.k0, d.k1);
+            const uint32_t* col = thr + cell;
+            const uint32_t u0 = min(w.x, 0xFFFFFFFEu), u1 = min(w.y, 0xFFFFFFFEu), u2 = min(w.z, 0xFFFFFFFEu), u3 = min(w.w, 0xFFFFFFFEu);
+            int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+            if (nthr > 0) {
+              int len = nthr;
+              while (len > 1) {                           // 4 interleaved branch-free searches
+                const int half = len >> 1, off = half - 1;
+                const uint32_t t0 = col[(b0 + off) * KP], t1 = col[(b1 + off) * KP], t2 = col[(b2 + off) * KP], t3 = col[(b3 + off) * KP];
+                b0 = (t0 <= u0) ? b0 + half : b0;
+                b1 = (t1 <= u1) ? b1 + half : b1;
+                b2 = (t2 <= u2) ? b2 + half : b2;
+                b3 = (t3 <= u3) ? b3 + half : b3;
+                len -= half;
+              }
+              b0 += (col[b0 * KP] <= u0) ? 1 : 0;
+              b1 += (col[b1 * KP] <= u1) ? 1 : 0;
+              b2 += (col[b2 * KP] <= u2) ? 1 : 0;
+              b3 += (col[b3 * KP] <= u3) ? 1 : 0;
+            }
+            uint32_t* zc = ztarget + cell;
+            uint32_t* hl = hist + lane;
             atomicAdd(&zc[b0 * KP], 1u); atomicAdd(&hl[(b0 >> 2) * ZH], 1u << ((b0 & 3) << 3));
             if (nd > 1) { atomicAdd(&zc[b1 * KP], 1u); atomicAdd(&hl[(b1 >> 2) * ZH], 1u << ((b1 & 3) << 3)); }
             if (nd > 2) { atomicAdd(&zc[b2 * KP], 1u); atomicAdd(&hl[(b2 >> 2) * ZH], 1u << ((b2 & 3) << 3)); }
             if (nd > 3) { atomicAdd(&zc[b3 * KP], 1u); atomicAdd(&hl[(b3 >> 2) * ZH], 1u << ((b3 & 3) << 3)); }
           }
         }
-      }
-      wave_lds_fence();
-      // flush the packed histograms: lane n sums byte (n&3) of word n>>2 over the 64 lanes
-      if (!(ablate & 256)) {
+        wave_lds_fence();
+        // flush the packed histograms: lane n sums byte (n&3) of word n>>2 over the 64 lanes
         for (int n = lane; n < N; n += 64) {
           const uint32_t* hr = hist + (n >> 2) * ZH;
           const int sh = (n & 3) << 3;
@@ -435,27 +405,37 @@ __global__ __launch_bounds__(ZT) void k_zalloc(Dev d, uint32_t t, ZGeom zg, int 
         }
         wave_lds_fence();
         for (int i = lane; i < HW * ZH; i += 64) hist[i] = 0;
+        wave_lds_fence();
+      }
+      // ---------------- end of chunk: Z[kbase:kend, :, g], and the chunk's counts into ZsumG / zacc
+      if (use_loc) {
+        for (int i = lane; i < kc * N; i += 64) {          // i = cl + kc*n: coalesced Z store
+          const int cl = i % kc, n = i / kc;
+          const size_t a = (size_t)n * KP + cl;
+          const uint32_t z = zloc[a];
+          if (SAVE_Z) d.Z[kbase + cl + (size_t)K * (n + (size_t)N * g)] = (int32_t)z;
+          if (z) {
+            if (chunked) { if (!(ablate & 1)) atomicAdd(&d.ZsumG[kbase + cl + (size_t)K * n], (int32_t)z); }
+            else atomicAdd(&zacc[a], z);
+            zloc[a] = 0;
+          }
+        }
       }
       wave_lds_fence();
     }
-    // ---------------- phase 3: ZsumK[:,g] (and Z[:,:,g])
+    a_sse = wave_tree64(a_sse); a_ll = wave_tree64(a_ll); a_kl = wave_tree64(a_kl);
+    if (lane == 0) { d.colsse[g] = a_sse; d.colll[g] = a_ll; d.colkl[g] = a_kl; }
+    // ---------------- ZsumK[:,g]
     for (int n = lane; n < N; n += 64) { d.ZsumK[n + (size_t)N * g] = (int32_t)zkt[n]; zkt[n] = 0; }
-    if (SAVE_Z) {
-      for (int i = lane; i < K * N; i += 64) {            // i = kk + K*n: coalesced Z store
-        const int kk = i % K, n = i / K;
-        const size_t a = (size_t)n * KP + kk;
-        const uint32_t z = zloc[a];
-        d.Z[kk + (size_t)K * (n + (size_t)N * g)] = (int32_t)z;
-        if (z) { atomicAdd(&zacc[a], z); zloc[a] = 0; }
-      }
-    }
     wave_lds_fence();
   }
   __syncthreads();
-  for (int i = tid; i < K * N; i += ZT) {
-    const int kk = i % K, n = i / K;
-    const uint32_t v = zacc[(size_t)n * KP + kk];
-    if (v && !(ablate & 1)) atomicAdd(&d.ZsumG[kk + (size_t)K * n], (int32_t)v);
+  if (!chunked) {
+    for (int i = tid; i < K * N; i += ZT) {
+      const int kk = i % K, n = i / K;
+      const uint32_t v = zacc[(size_t)n * KP + kk];
+      if (v && !(ablate & 1)) atomicAdd(&d.ZsumG[kk + (size_t)K * n], (int32_t)v);
+    }
   }
 }
 

@@ -238,6 +238,39 @@ def test_ragged_and_edge_shapes():
         assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), (K, G, N)
 
 
+@pytest.mark.parametrize("shape,force", [((200, 9, 30), True), ((33, 17, 26), True), ((130, 12, 40), True),
+                                         ((1536, 12, 100), False)])
+def test_row_chunked_allocation_kernel(shape, force, monkeypatch):
+    """Large K x N (BASELINE config 5: K = 1,536, N = 100): the column's thresholds do not fit one wave's LDS
+    slab, so k_zalloc walks the rows in chunks of 64 and keeps ZsumG in global memory.  Forced on small shapes
+    (BNMF_ZCHUNK=1) and taken automatically at the config-5 row/factor counts; bit-exact against the oracle."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import apply_hyperprior_params
+    K, G, N = shape
+    if force:
+        monkeypatch.setenv("BNMF_ZCHUNK", "1")
+    rng = np.random.default_rng(K + N)
+    M = rng.poisson(rng.gamma(0.5, 12.0, size=(K, G))).astype(np.int32)
+    M[:, G // 2] = 0
+    M[K // 3, :] = 0
+    for save_Z in (False, True):
+        o = O.Oracle(M, N, prior="gamma", seed=9, save_Z=True, nthreads=4)
+        e = Engine(M, N, prior="gamma", seed=9, save_Z=save_Z)
+        apply_hyperprior_params(o, "gamma", M, N)
+        apply_hyperprior_params(e, "gamma", M, N)
+        o.init(); e.init()
+        mo, me = o.run(4), e.run(4)
+        if save_Z:
+            assert np.array_equal(o.get("Z").astype(np.int32), e.get("Z")), shape
+        assert np.array_equal(o.get("ZsumK").astype(np.int32), e.get("ZsumK")), shape
+        assert np.array_equal(o.get("ZsumG").astype(np.int32), e.get("ZsumG")), shape
+        assert np.array_equal(o.get("P").view(np.uint64), e.get("P").view(np.uint64)), shape
+        assert np.array_equal(o.get("E").view(np.uint64), e.get("E").view(np.uint64)), shape
+        assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), shape
+        e.close()
+
+
 def test_bayesNMF_end_to_end_gpu(tmp_path):
     """bayesNMF() on the engine: fixed-rank Poisson-Gamma recovers the generating signatures."""
     from bayesnmf_amd.sampler import bayesNMF
