@@ -33,8 +33,9 @@ struct bnmf_handle {
   bnmf_config cfg{};
   int device = 0;
   hipStream_t stream = nullptr;        // main stream: draws, k_zalloc, reductions
-  hipStream_t side = nullptr;          // side stream: k_side of the next iteration (overlaps k_zalloc)
-  hipEvent_t ev_draw = nullptr, ev_side = nullptr, ev_z = nullptr;
+  hipStream_t side = nullptr;          // side stream: k_side (E part) of the next iteration (overlaps k_zalloc), k_reduce
+  hipStream_t side2 = nullptr;         // second side stream: k_side P part (starts right after k_pdraw) and Esum
+  hipEvent_t ev_draw = nullptr, ev_side = nullptr, ev_sideP = nullptr, ev_p = nullptr, ev_z = nullptr;
   bool side_valid = false;             // k_side of iteration iter+1 has been issued
   bool red_pending = false; uint32_t red_t = 0; int red_row = 0;   // k_reduce of the previous iteration, issued late
   int iter = 0;
@@ -158,8 +159,11 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
   const size_t K = cfg->K, G = cfg->G, N = cfg->N;
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&h->ev_draw, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_sideP, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_p, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_z, hipEventDisableTiming));
   HIPCHK(hipMalloc(&h->dM, K * G * sizeof(int32_t)));
   HIPCHK(hipMemcpy(h->dM, M, K * G * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -245,7 +249,7 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
     auto pick = [&]() {
       best_w = best_per_cu = best_total = 0;
       for (int per_cu = 1; per_cu <= 2; ++per_cu)
-        for (int w : {16, 8, 4, 2, 1}) {
+        for (int w : {16, 8, 6, 4, 2, 1}) {
           const size_t lds = (shared_words + (size_t)w * slab) * 4;
           if (lds * per_cu <= 160 * 1024 && w * per_cu <= Z_MAX_WAVES_PER_CU && w * per_cu > best_total) { best_total = w * per_cu; best_w = w; best_per_cu = per_cu; }
         }
@@ -276,12 +280,13 @@ int bnmf_destroy(bnmf_handle* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->side) hipStreamSynchronize(h->side);
+  if (h->side2) hipStreamSynchronize(h->side2);
   for (auto& a : h->arr) { if (a.d) hipFree(a.d); if (a.ring) hipFree(a.ring); }
   hipFree(h->dM); hipFree(h->dZsumK); hipFree(h->dZsumG); if (h->dZ) hipFree(h->dZ);
   hipFree(h->dR); hipFree(h->dRedraw); hipFree(h->dEsum); hipFree(h->dPsum); hipFree(h->dlpPn);
   hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol);
   if (h->dProp) { hipFree(h->dProp); hipFree(h->dPart); hipFree(h->dAccPn); hipFree(h->dAccEpart); hipFree(h->dNzE); }
-  if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->side) hipStreamDestroy(h->side);
+  if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->side) hipStreamDestroy(h->side); if (h->side2) hipStreamDestroy(h->side2);
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -295,6 +300,7 @@ int bnmf_set_array(bnmf_handle* h, int id, const double* x, size_t n) {
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->side));
+  HIPCHK(hipStreamSynchronize(h->side2));
   h->side_valid = false;                 // state changed: the pre-issued k_side must be redone
   if (id == BNMF_R) { int r = (int)x[0]; HIPCHK(hipMemcpy(h->dR, &r, sizeof(int), hipMemcpyHostToDevice)); h->arr[BNMF_R].set = true; return 0; }
   if (id == BNMF_ZSUMK || id == BNMF_ZSUMG || id == BNMF_Z) {
@@ -339,6 +345,7 @@ int bnmf_get_array(bnmf_handle* h, int id, double* out, size_t n) {
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->side));
+  HIPCHK(hipStreamSynchronize(h->side2));
   if (id == BNMF_R) { int r; HIPCHK(hipMemcpy(&r, h->dR, sizeof(int), hipMemcpyDeviceToHost)); out[0] = r; return 0; }
   if (id == BNMF_ZSUMK || id == BNMF_ZSUMG || id == BNMF_Z) {
     const int32_t* src = id == BNMF_ZSUMK ? h->dZsumK : id == BNMF_ZSUMG ? h->dZsumG : h->dZ;
@@ -409,7 +416,7 @@ static double* accPn_slot(const bnmf_handle* h, uint32_t t) { return h->dAccPn ?
 static double* accEp_slot(const bnmf_handle* h, uint32_t t) { return h->dAccEpart ? h->dAccEpart + (size_t)(t % 3u) * h->nblkE : nullptr; }
 struct Timer {   // optional per-kernel HIP-event bracketing (serialises the two streams: profile mode only)
   bnmf_handle* h; bool on; double acc[BNMF_NKERNEL]{}; int cnt[BNMF_NKERNEL]{};
-  void begin(int k, hipStream_t st) { if (on) { hipStreamSynchronize(h->stream); hipStreamSynchronize(h->side); hipEventRecord(h->ev[2 * k], st); } }
+  void begin(int k, hipStream_t st) { if (on) { hipStreamSynchronize(h->stream); hipStreamSynchronize(h->side); hipStreamSynchronize(h->side2); hipEventRecord(h->ev[2 * k], st); } }
   void end(int k, hipStream_t st) { if (on) { hipEventRecord(h->ev[2 * k + 1], st); hipEventSynchronize(h->ev[2 * k + 1]); float ms = 0; hipEventElapsedTime(&ms, h->ev[2 * k], h->ev[2 * k + 1]); acc[k] += ms; cnt[k]++; } }
 };
 static void launch_pdraw(bnmf_handle* h, uint32_t t, int from_prior) {
@@ -428,18 +435,41 @@ static void issue_reduce(bnmf_handle* h, uint32_t t, int row, Timer& tm) {
   hipLaunchKernelGGL(k_reduce, dim3(h->cfg.MH ? 5 : 4), dim3(RT), 0, h->side, dr, row, h->nblkE, (const double*)accPn_slot(h, t), (const double*)accEp_slot(h, t));
   tm.end(KN_REDUCE, h->side);
 }
-static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm, bool draw_recorded = false) {
+static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm) {
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
   const int nbE = (int)(((size_t)h->cfg.N * h->cfg.G + RT - 1) / RT);
-  if (!draw_recorded) hipEventRecord(h->ev_draw, h->stream);   // else: ev_draw is the stop event of the k_edraw dispatch itself
+  hipEventRecord(h->ev_draw, h->stream);
   hipStreamWaitEvent(h->side, h->ev_draw, 0);
   tm.begin(KN_SIDE, h->side);
-  hipLaunchKernelGGL(k_side, dim3(h->cfg.N + nbP + nbE), dim3(RT), 0, h->side, h->dev, t, nbP);
+  hipLaunchKernelGGL(k_side, dim3(h->cfg.N + nbP + nbE), dim3(RT), 0, h->side, h->dev, t, nbP, 0);
   tm.end(KN_SIDE, h->side);
   hipEventRecord(h->ev_side, h->side);
+  hipEventRecord(h->ev_sideP, h->side);
   h->side_valid = true;
   // k_reduce of the PREVIOUS iteration: its inputs are complete once the draws of this iteration have run
   // (main-stream order), which ev_draw above implies, so the main stream needs no marker after k_zalloc
+  if (h->red_pending) { issue_reduce(h, h->red_t, h->red_row, tm); h->red_pending = false; }
+}
+// The same work in three launches, for the Gibbs sweep.  The P-side hyper sweep depends on P_{t-1} only and has
+// the longest per-lane latency (rejection sampling of Alpha): it starts right behind k_pdraw on its own stream.
+// Esum follows it once k_edraw is done; both are over long before k_zalloc, so that the event the next k_pdraw
+// waits for is already satisfied when the main stream reaches it (a late cross-stream event costs ~12 us).
+// The E-side sweep (needed only by the next k_edraw) shares the CUs with k_zalloc and ends with it.
+static void launch_side_P(bnmf_handle* h, uint32_t t) {       // ev_p = completion of k_pdraw(t-1)
+  const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
+  hipStreamWaitEvent(h->side2, h->ev_p, 0);
+  hipLaunchKernelGGL(k_side, dim3(nbP), dim3(RT), 0, h->side2, h->dev, t, nbP, h->cfg.N);
+}
+static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm) {   // ev_draw = completion of k_edraw(t-1)
+  const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
+  const int nbE = (int)(((size_t)h->cfg.N * h->cfg.G + RT - 1) / RT);
+  hipStreamWaitEvent(h->side2, h->ev_draw, 0);
+  hipLaunchKernelGGL(k_side, dim3(h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, 0);
+  hipEventRecord(h->ev_sideP, h->side2);
+  hipStreamWaitEvent(h->side, h->ev_draw, 0);
+  hipLaunchKernelGGL(k_side, dim3(nbE), dim3(RT), 0, h->side, h->dev, t, nbP, h->cfg.N + nbP);
+  hipEventRecord(h->ev_side, h->side);
+  h->side_valid = true;
   if (h->red_pending) { issue_reduce(h, h->red_t, h->red_row, tm); h->red_pending = false; }
 }
 template <typename KernelT, typename ArgT>
@@ -474,6 +504,7 @@ static int launch_zalloc(bnmf_handle* h, uint32_t t) {
   switch (h->z_zw) {
     case 16: return sz ? launch_zalloc_t<true, 1024>(h, t) : launch_zalloc_t<false, 1024>(h, t);
     case 8: return sz ? launch_zalloc_t<true, 512>(h, t) : launch_zalloc_t<false, 512>(h, t);
+    case 6: return sz ? launch_zalloc_t<true, 384>(h, t) : launch_zalloc_t<false, 384>(h, t);
     case 4: return sz ? launch_zalloc_t<true, 256>(h, t) : launch_zalloc_t<false, 256>(h, t);
     case 2: return sz ? launch_zalloc_t<true, 128>(h, t) : launch_zalloc_t<false, 128>(h, t);
     default: return sz ? launch_zalloc_t<true, 64>(h, t) : launch_zalloc_t<false, 64>(h, t);
@@ -569,6 +600,7 @@ static int sweep_mh(bnmf_handle* h, int row, int converged, Timer& tm) {
   use_slot(h, t);
   if (!h->side_valid) launch_side(h, t, tm);
   hipStreamWaitEvent(h->stream, h->ev_side, 0);
+  hipStreamWaitEvent(h->stream, h->ev_sideP, 0);
   tm.begin(KN_MH, h->stream); launch_mh_PE(h, t, converged); tm.end(KN_MH, h->stream);
   launch_side(h, t + 1, tm);
   if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
@@ -582,12 +614,21 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   const uint32_t t = (uint32_t)h->iter;
   use_slot(h, t);
   if (!h->side_valid) launch_side(h, t, tm);               // first sweep after init / set_array
-  hipStreamWaitEvent(h->stream, h->ev_side, 0);            // prior params + Esum of iteration t ready
-  tm.begin(KN_PDRAW, h->stream); launch_pdraw(h, t, 0); tm.end(KN_PDRAW, h->stream);
-  // ev_draw rides on the k_edraw dispatch (stop event): no marker packet between k_edraw and k_zalloc
-  if (tm.on) { tm.begin(KN_EDRAW, h->stream); launch_edraw(h, t, 0); tm.end(KN_EDRAW, h->stream); }
-  else hipExtLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, 0);
-  launch_side(h, t + 1, tm, !tm.on);                       // overlaps the rank update / k_zalloc below
+  hipStreamWaitEvent(h->stream, h->ev_sideP, 0);           // P-side prior params + Esum of iteration t ready
+  if (tm.on) {                                             // profile mode: one kernel at a time
+    tm.begin(KN_PDRAW, h->stream); launch_pdraw(h, t, 0); tm.end(KN_PDRAW, h->stream);
+    hipStreamWaitEvent(h->stream, h->ev_side, 0);
+    tm.begin(KN_EDRAW, h->stream); launch_edraw(h, t, 0); tm.end(KN_EDRAW, h->stream);
+    launch_side(h, t + 1, tm);
+  } else {
+    // completion events ride on the dispatches themselves (stop events): no marker packets on the main stream
+    hipExtLaunchKernelGGL(k_pdraw, dim3(h->cfg.N), dim3(PD_T), (uint32_t)(2 * (size_t)h->cfg.K * sizeof(double)), h->stream,
+                          nullptr, h->ev_p, 0, h->dev, t, 0);
+    launch_side_P(h, t + 1);
+    hipStreamWaitEvent(h->stream, h->ev_side, 0);          // E-side prior params of iteration t ready
+    hipExtLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, 0);
+    launch_side_E(h, t + 1, tm);                           // overlaps the rank update / k_zalloc below
+  }
   if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
   tm.begin(KN_OTHER, h->stream); if (int rc = launch_record(h, t)) return rc; tm.end(KN_OTHER, h->stream);
   tm.begin(KN_ZALLOC, h->stream); if (int rc = launch_zalloc(h, t)) return rc; tm.end(KN_ZALLOC, h->stream);
@@ -682,6 +723,7 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
   if (metrics_row1) HIPCHK(hipMemcpyAsync(metrics_row1, h->dMetrics, BNMF_NMETRIC * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->side));
+  HIPCHK(hipStreamSynchronize(h->side2));
   h->inited = true;
   return 0;
 }
@@ -702,6 +744,7 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
   if (metrics) HIPCHK(hipMemcpyAsync(metrics, h->dMetrics, (size_t)n_iter * BNMF_NMETRIC * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->side));
+  HIPCHK(hipStreamSynchronize(h->side2));
   return 0;
 }
 int bnmf_run(bnmf_handle* h, int n_iter, int converged, double* metrics) {

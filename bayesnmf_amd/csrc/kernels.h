@@ -125,9 +125,9 @@ BNMF_DEV double canon1024_by256(const double* x, long L, long stride, double* bu
 //   blocks [0, N)            : Esum[n] = canonical sum_g E[n,g]   (rate of P's Gamma, R/sample_Pn.R:103-106)
 //   blocks [N, N+nbP)        : hyper sweep of the P-side prior parameters (R/sample_priors.R:150-200)
 //   blocks [N+nbP, ...)      : hyper sweep of the E-side prior parameters
-__global__ __launch_bounds__(RT, 4) void k_side(Dev d, uint32_t t, int nbP) {
+__global__ __launch_bounds__(RT, 4) void k_side(Dev d, uint32_t t, int nbP, int blk0) {
   __shared__ double buf[RT];
-  const int tid = threadIdx.x, blk = blockIdx.x;
+  const int tid = threadIdx.x, blk = blockIdx.x + blk0;   // one launch (blk0 = 0) or one launch per part
   if (blk < d.N) {
     const double r = canon1024_by256(d.E + blk, d.G, d.N, buf, tid);
     if (tid == 0) d.Esum[blk] = r;
