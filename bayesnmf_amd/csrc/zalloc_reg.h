@@ -357,12 +357,14 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(ZArgs d, uint32_t t, ZGeom
     // ---------------- phase 3: ZsumK[:,g] (and Z[:,:,g])
     for (int n = lane; n < N; n += 64) { d.ZsumK[n + (size_t)N * g] = (int32_t)zkt[n]; zkt[n] = 0; }
     if (SAVE_Z) {
-      for (int i = lane; i < K * N; i += 64) {            // i = kk + K*n: coalesced Z store
-        const int kk = i % K, n = i / K;
-        const size_t a = (size_t)n * KP + kk;
-        const uint32_t z = zloc[a];
-        d.Z[kk + (size_t)K * (n + (size_t)N * g)] = (int32_t)z;
-        if (z) { atomicAdd(&zacc[a], z); zloc[a] = 0; }
+      int32_t* Zg = d.Z + (size_t)K * N * g;              // Z[:, :, g], element (kk, n) at kk + K n: coalesced over kk
+      for (int n = 0; n < N; ++n) {
+        for (int kk = lane; kk < K; kk += 64) {
+          const size_t a = (size_t)n * KP + kk;
+          const uint32_t z = zloc[a];
+          Zg[kk + (size_t)K * n] = (int32_t)z;
+          if (z) { atomicAdd(&zacc[a], z); zloc[a] = 0; }
+        }
       }
     }
     wave_lds_fence();
