@@ -143,6 +143,28 @@ def _temp_schedule(n):
     return np.concatenate([np.zeros(3), 10.0 ** np.linspace(-6, 0, 40), np.ones(max(0, n - 43))])
 
 
+@pytest.mark.parametrize("G,iters", [(2000, 4), (10000, 3)])
+def test_full_size_chain_bitexact(G, iters):
+    """BASELINE config 2 (G = 2,000) and the metric configuration (G = 10,000), K = 96, N = 20, at full size:
+    every array of the sweep and the metrics rows agree bit for bit with the oracle after a few iterations."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    M, _, _ = synth_counts(96, G, 8, 20250218)
+    o = O.Oracle(M, 20, prior="gamma", seed=3, nthreads=16)
+    e = Engine(M, 20, prior="gamma", seed=3)
+    apply_hyperprior_params(o, "gamma", M, 20)
+    apply_hyperprior_params(e, "gamma", M, 20)
+    o.init(); e.init()
+    mo, me = o.run(iters), e.run(iters)
+    for nm in ("ZsumK", "ZsumG"):
+        assert np.array_equal(o.get(nm).astype(np.int32), e.get(nm)), nm
+    for nm in ("P", "E", "Alpha_p", "Beta_p", "Alpha_e", "Beta_e"):
+        assert np.array_equal(o.get(nm).view(np.uint64), e.get(nm).view(np.uint64)), nm
+    assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64))
+    e.close()
+
+
 @pytest.mark.parametrize("method", ["SBFI", "BFI"])
 def test_learned_rank_chain_bitexact(method):
     """sample_R / sample_An (R/sample_params.R:101-241): A, R, and everything downstream bit-exact
