@@ -241,7 +241,7 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
       shared_words = (size_t)zg.zacc_words + zg.p_words;
     };
     // workgroup width.  k_zalloc holds 128 VGPRs per lane: at 16 waves/CU it owns the whole register file and
-    // starves k_side (side stream) until its tail.  Measured end to end at the metric config (tools_e2e.py):
+    // starves k_side (side stream) until its tail.  Measured end to end at the metric config (tools/e2e.py):
     // 16 waves/CU 178 us/iter, 12: 169, 10: 176, 8: 161, 2x4: 165, 6: 179.  So: at most 8 waves per CU, in one
     // workgroup when LDS allows.
     constexpr int Z_MAX_WAVES_PER_CU = 8;

@@ -35,7 +35,7 @@ def z_bytes(K, G, N, save_Z):
 
 def pmc_traffic(save_Z):
     """HBM bytes per k_zalloc launch from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
-    rocprofv3 --pmc passes by tools_pmc2.sh, gfx950-corrected; committed under profiles/).  None if absent."""
+    rocprofv3 --pmc passes by tools/pmc2.sh, gfx950-corrected; committed under profiles/).  None if absent."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
         return d["k_zalloc_full" if save_Z else "k_zalloc_stats"]["hbm_bytes_per_launch"]

@@ -1,6 +1,6 @@
 """Interleaved A/B timing of k_zalloc variants in ONE process (cdna guide rule 24)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bayesnmf_amd.engine as _E
 if os.environ.get('ABL_LIB'): _E.LIB_PATH = os.path.abspath(os.environ['ABL_LIB'])
@@ -8,7 +8,7 @@ from bayesnmf_amd import Engine
 from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
 M, _, _ = synth_counts(96, 10000, 8, 20250218)
 def mk(env):
-    for k in ("BNMF_ABLATE", "BNMF_ZGRID", "BNMF_ZW", "BNMF_ZSEARCH"):
+    for k in ("BNMF_ABLATE", "BNMF_ZGRID", "BNMF_ZW"):
         os.environ.pop(k, None)
     os.environ.update(env)
     e = Engine(M, 20, prior="gamma", seed=1); apply_hyperprior_params(e, "gamma", M, 20); e.init(); e.run(20, metrics=False)

@@ -1,6 +1,6 @@
 """k_zalloc time vs waves per CU (interleaved in one process)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from bayesnmf_amd import Engine
 from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params

@@ -2,12 +2,12 @@
 # HBM traffic of the kernels (separate --pmc passes, as MI355X_MICROARCH.md prescribes): FETCH_SIZE and WRITE_SIZE
 export TMPDIR=/tmp
 OUT=$1; mkdir -p $OUT
-ITERS=30 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/f -- python3 tools_prof.py > $OUT/f.log 2>&1
-ITERS=30 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/w -- python3 tools_prof.py > $OUT/w.log 2>&1
-ITERS=30 SAVE_Z=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fz -- python3 tools_prof.py > $OUT/fz.log 2>&1
-ITERS=30 SAVE_Z=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/wz -- python3 tools_prof.py > $OUT/wz.log 2>&1
-ITERS=30 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s -- python3 tools_prof.py > $OUT/s.log 2>&1
-ITERS=30 SAVE_Z=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sz -- python3 tools_prof.py > $OUT/sz.log 2>&1
+ITERS=30 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/f -- python3 tools/prof.py > $OUT/f.log 2>&1
+ITERS=30 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/w -- python3 tools/prof.py > $OUT/w.log 2>&1
+ITERS=30 SAVE_Z=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fz -- python3 tools/prof.py > $OUT/fz.log 2>&1
+ITERS=30 SAVE_Z=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/wz -- python3 tools/prof.py > $OUT/wz.log 2>&1
+ITERS=30 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s -- python3 tools/prof.py > $OUT/s.log 2>&1
+ITERS=30 SAVE_Z=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sz -- python3 tools/prof.py > $OUT/sz.log 2>&1
 python3 - <<PY
 import csv, glob, collections, json
 res = {}

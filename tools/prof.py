@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bayesnmf_amd import Engine
 from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
 M, _, _ = synth_counts(96, 10000, 8, 20250218)

@@ -1,7 +1,7 @@
 """Determinism stress: many short chains on tiny shapes (all kernels launch-bound, maximal stream overlap);
 every repetition must reproduce the first one bit for bit."""
 import os, sys, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bayesnmf_amd import Engine
 from bayesnmf_amd.setup import apply_hyperprior_params
 rng = np.random.default_rng(8)

@@ -1,10 +1,10 @@
 """In-kernel section timers of k_zalloc_reg (libbnmf_zprof.so, built with -DZPROF): prints the share of
 wave-cycles per section at the metric config."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bayesnmf_amd.engine as E
-E.LIB_PATH = os.path.join(os.path.dirname(E.LIB_PATH), "libbnmf_zprof.so")
+E.LIB_PATH = os.path.join(os.path.dirname(E.LIB_PATH), "libbnmf_zprof.so")   # build: hipcc ... -DZPROF -o bayesnmf_amd/libbnmf_zprof.so bayesnmf_amd/csrc/api.hip
 from bayesnmf_amd import Engine
 from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
 K, G, N = 96, 10000, 20
