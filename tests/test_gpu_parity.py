@@ -413,3 +413,31 @@ def test_user_supplied_initial_values():
     mo, me = o.run(5), e.run(5)
     assert np.array_equal(o.get("Z").astype(np.int32), e.get("Z"))
     assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64))
+
+
+def _match_cosine(P, Pt):
+    """Best one-to-one cosine match of the columns of P to the columns of Pt (assignment problem)."""
+    from scipy.optimize import linear_sum_assignment
+    A = (P / np.linalg.norm(P, axis=0)).T @ (Pt / np.linalg.norm(Pt, axis=0))
+    r, c = linear_sum_assignment(-A)
+    return A[r, c]
+
+
+@pytest.mark.parametrize("rank", [4, "1:10"])
+def test_reference_example_data_known_answer(rank, tmp_path):
+    """The reference's only documented outcome (vignettes/bayesNMF_tutorial.pdf p.10-13): on its bundled example
+    (inst/extdata/example_data.rds, M 96 x 64 generated from four COSMIC signatures) the default model
+    bayesNMF(data$M, rank = 4) and bayesNMF(data$M, rank = 1:10) (Poisson, truncated-normal prior, MH, SBFI)
+    recovers the four signatures (cosine >= 0.96 in the vignette) and learns rank 4.  Data fixture:
+    tests/golden/reference_example_data.npz (made by tests/golden/make_example_fixture.py)."""
+    import os
+    from bayesnmf_amd.sampler import bayesNMF
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_example_data.npz"))
+    M, Pt = d["M"], d["P"]
+    rk = 4 if rank == 4 else range(1, 11)
+    s = bayesNMF(M, rk, output_dir=str(tmp_path / "o"), periodic_save=False, save_all_samples=False, seed=7)
+    keep = np.asarray(s.MAP["A"]).ravel() > 0.5
+    assert int(keep.sum()) == 4, s.MAP["A"]
+    cos = _match_cosine(np.asarray(s.MAP["P"])[:, keep], Pt)
+    assert cos.min() >= 0.95, cos
+    s.close()
