@@ -205,8 +205,8 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
   HIPCHK(hipMalloc(&h->dRaw, h->metrics_rows * 8 * sizeof(double)));
   hipLaunchKernelGGL(k_luts, dim3((mx + 256) / 256), dim3(256), 0, h->stream, h->dLut, h->dLut + (mx + 1), mx);
   HIPCHK(hipGetLastError());
-  // k_zalloc geometry: independent waves, one LDS slab per wave, zacc shared per workgroup.
-  // N <= 24 takes the register-resident kernel (zalloc_reg.h), larger N the LDS-search kernel.
+  // Allocation-kernel geometry: independent waves, one LDS slab per wave, zacc (and P) shared per workgroup.
+  // N <= 25 takes k_zalloc_reg (zalloc_reg.h), larger N the general LDS-search kernel k_zalloc (kernels.h).
   {
     ZGeom& zg = h->zg;
     zg.KP = (K % 32 == 0) ? (int)K + 1 : (int)(K | 1);

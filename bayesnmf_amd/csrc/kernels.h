@@ -206,7 +206,7 @@ __global__ __launch_bounds__(ES_T) void k_edraw(Dev d, uint32_t t, int from_prio
   if (tid == 0) d.lpE_part[blockIdx.x] = r;
 }
 
-// ---- k_zalloc: the hot kernel ----
+// ---- k_zalloc: the general Z-allocation kernel (any N, any K); the metric configuration runs k_zalloc_reg ----
 // sample_Zkg R/sample_params.R:253-265 for every cell, fused with Mhat (R/utils.R:29-49) and the
 // per-cell RMSE / KL / Poisson log-lik terms (R/utils.R:62-112, :412-471).
 //
