@@ -46,6 +46,7 @@ struct bnmf_handle {
   int* dR = nullptr; int* dRedraw = nullptr;
   double *dEsum = nullptr, *dPsum = nullptr, *dlpPn = nullptr, *dlpE = nullptr, *dcol = nullptr;
   double *dLut = nullptr, *dTemp = nullptr, *dMetrics = nullptr, *dRaw = nullptr, *dRankCol = nullptr;
+  int32_t* dMt = nullptr; double* dEt = nullptr;
   double *dProp = nullptr, *dPart = nullptr, *dAccPn = nullptr, *dAccEpart = nullptr; int* dNzE = nullptr; int mh_S = 1;
   size_t metrics_rows = 0;
   int maxM = 0, nblkE = 0;
@@ -95,7 +96,7 @@ static void refresh_dev(bnmf_handle* h) {
   d.rank_method = c.rank_method; d.save_Z = c.save_Z;
   d.k0 = (uint32_t)c.seed; d.k1 = (uint32_t)(c.seed >> 32) ^ c.chain_id;
   d.maxM = h->maxM;
-  d.M = h->dM; d.R = h->dR;
+  d.M = h->dM; d.Mt = h->dMt; d.Et = h->dEt; d.R = h->dR;
   d.P = h->arr[BNMF_P].d; d.E = h->arr[BNMF_E].d; d.A = h->arr[BNMF_A].d;
   d.ZsumK = h->dZsumK; d.ZsumG = h->dZsumG; d.Z = h->dZ;
   d.Alpha_p = h->arr[BNMF_ALPHA_P].d; d.Beta_p = h->arr[BNMF_BETA_P].d;
@@ -193,6 +194,13 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
     HIPCHK(hipMalloc(&h->dAccPn, 3 * N * sizeof(double)));
     HIPCHK(hipMalloc(&h->dAccEpart, 3 * (size_t)h->nblkE * sizeof(double)));
     HIPCHK(hipMalloc(&h->dNzE, N * sizeof(int)));
+    HIPCHK(hipMalloc(&h->dEt, N * G * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dMt, K * G * sizeof(int32_t)));
+    {
+      std::vector<int32_t> mt(K * G);
+      for (size_t g = 0; g < G; ++g) for (size_t k = 0; k < K; ++k) mt[g + G * k] = M[k + K * g];
+      HIPCHK(hipMemcpy(h->dMt, mt.data(), K * G * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
   }
   HIPCHK(hipMalloc(&h->dLut, 2 * (size_t)(mx + 1) * sizeof(double)));
   if (cfg->n_temperature > 0 && cfg->temperature) {
@@ -285,7 +293,7 @@ int bnmf_destroy(bnmf_handle* h) {
   hipFree(h->dM); hipFree(h->dZsumK); hipFree(h->dZsumG); if (h->dZ) hipFree(h->dZ);
   hipFree(h->dR); hipFree(h->dRedraw); hipFree(h->dEsum); hipFree(h->dPsum); hipFree(h->dlpPn);
   hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol);
-  if (h->dProp) { hipFree(h->dProp); hipFree(h->dPart); hipFree(h->dAccPn); hipFree(h->dAccEpart); hipFree(h->dNzE); }
+  if (h->dProp) { hipFree(h->dProp); hipFree(h->dPart); hipFree(h->dAccPn); hipFree(h->dAccEpart); hipFree(h->dNzE); hipFree(h->dEt); hipFree(h->dMt); }
   if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->side) hipStreamDestroy(h->side); if (h->side2) hipStreamDestroy(h->side2);
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);

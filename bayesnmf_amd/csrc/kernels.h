@@ -24,6 +24,8 @@ struct Dev {
   uint32_t k0, k1;
   int maxM;
   const int32_t* M;
+  const int32_t* Mt;    // [G][K] transpose of M (MH / Normal models: lanes walk the columns of one row)
+  double* Et;           // [G][N] transpose of E, refreshed by k_mh_nz before the P-side updates
   double *P, *E, *A;
   int* R;
   int32_t *ZsumK, *ZsumG, *Z;

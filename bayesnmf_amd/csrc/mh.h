@@ -44,11 +44,17 @@ BNMF_DEV double mh_prior_or_cond(const Dev& d, int e, uint32_t t, bool use_prior
   return rtnorm0(s, mu, dsqrt(var));
 }
 
-// nzE[n] = number of non-zero entries in row n of E (all(E[n,] == 0) test of sample_Pn_normal :56)
+// nzE[n] = number of non-zero entries in row n of E (all(E[n,] == 0) test of sample_Pn_normal :56); also writes
+// the transpose Et[g + G n] = E[n, g] that the P-side kernels read (E is constant during the P updates): there a
+// wave's lanes walk consecutive columns g of ONE row, and E[n + N g] / M[k + K g] would be 64 cache lines per load
 __global__ void k_mh_nz(Dev d, int* nzE) {
   const int n = blockIdx.x;
   int c = 0;
-  for (int g = threadIdx.x; g < d.G; g += blockDim.x) c += d.E[n + (size_t)d.N * g] != 0.0 ? 1 : 0;
+  for (int g = threadIdx.x; g < d.G; g += blockDim.x) {
+    const double e = d.E[n + (size_t)d.N * g];
+    d.Et[g + (size_t)d.G * n] = e;
+    c += e != 0.0 ? 1 : 0;
+  }
   if (c) atomicAdd(&nzE[n], c);
 }
 
@@ -73,18 +79,18 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow_partial(Dev d, int n, int S, 
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   const int gbeg = s * MH_SEG, gend = min(G, gbeg + MH_SEG);
   for (int g = gbeg + lane; g < gend; g += 64) {
-    const double* Eg = d.E + (size_t)N * g;
-    const int m = d.M[k + (size_t)K * g];
+    const double* Eg = d.Et + g;                      // E[j, g] = Eg[G j]: coalesced over the lanes' columns
+    const int m = d.Mt[g + (size_t)G * k];
     if (MODE == 0) {
       double mh = 0.0, mno = 0.0;
-      for (int j = 0; j < N; ++j) { const double term = pa[j] * Eg[j]; mh = mh + term; mno = mno + (j == n ? 0.0 * Eg[j] : term); }
-      const double en = Eg[n];
+      for (int j = 0; j < N; ++j) { const double term = pa[j] * Eg[(size_t)G * j]; mh = mh + term; mno = mno + (j == n ? 0.0 * Eg[(size_t)G * j] : term); }
+      const double en = Eg[(size_t)G * n];
       const double V = d.likelihood == BNMF_NORMAL ? d.sigmasq[g] : mh;   // sigmasq_kg: Mhat (proposal) or sigmasq_g :137-147
       a0 = a0 + en * (((double)m - mno) / V);           // :155-161
       a1 = a1 + (a_n * (en * en)) * (1.0 / V);           // :163-169
     } else {
       double m0 = 0.0, m1 = 0.0;
-      for (int j = 0; j < N; ++j) { const double e = Eg[j]; m0 = m0 + pa[j] * e; m1 = m1 + (j == n ? pn_prop : pa[j]) * e; }
+      for (int j = 0; j < N; ++j) { const double e = Eg[(size_t)G * j]; m0 = m0 + pa[j] * e; m1 = m1 + (j == n ? pn_prop : pa[j]) * e; }
       const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
       const double lgf = d.lgfact[mi];
       a0 = a0 + dpois_log(m, m1, lgf);                                  // loglik_poisson_new :216-218
