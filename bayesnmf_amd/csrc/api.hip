@@ -429,10 +429,10 @@ struct Timer {   // optional per-kernel HIP-event bracketing (serialises the two
 };
 static void launch_pdraw(bnmf_handle* h, uint32_t t, int from_prior) {
   const size_t lds = 2 * (size_t)h->cfg.K * sizeof(double);
-  hipLaunchKernelGGL(k_pdraw, dim3(h->cfg.N), dim3(PD_T), lds, h->stream, h->dev, t, from_prior);
+  hipLaunchKernelGGL(k_pdraw, dim3(h->cfg.N), dim3(PD_T), lds, h->stream, h->dev, t, from_prior, 1);
 }
 static void launch_edraw(bnmf_handle* h, uint32_t t, int from_prior) {
-  hipLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, from_prior);
+  hipLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, from_prior, 1);
 }
 // k_side for iteration t (reads P_{t-1}, E_{t-1}): issued on the side stream right after the draws
 // of iteration t-1, so that it overlaps k_zalloc of iteration t-1
@@ -467,12 +467,15 @@ static void launch_side_P(bnmf_handle* h, uint32_t t) {       // ev_p = completi
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
   hipStreamWaitEvent(h->side2, h->ev_p, 0);
   hipLaunchKernelGGL(k_side, dim3(nbP), dim3(RT), 0, h->side2, h->dev, t, nbP, h->cfg.N);
+  hipLaunchKernelGGL(k_lpp, dim3(h->cfg.N), dim3(64), 0, h->side2, h->dev, t - 1);   // log-prior of the P just drawn
 }
 static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm) {   // ev_draw = completion of k_edraw(t-1)
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
   const int nbE = (int)(((size_t)h->cfg.N * h->cfg.G + RT - 1) / RT);
   hipStreamWaitEvent(h->side2, h->ev_draw, 0);
   hipLaunchKernelGGL(k_side, dim3(h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, 0);
+  // log-prior of the E just drawn (iteration t-1, whose slot pointers h->dev still holds): off the critical path
+  hipLaunchKernelGGL(k_lpe, dim3(h->nblkE), dim3(ES_T), 0, h->side2, h->dev, t - 1);
   hipEventRecord(h->ev_sideP, h->side2);
   hipStreamWaitEvent(h->side, h->ev_draw, 0);
   hipLaunchKernelGGL(k_side, dim3(nbE), dim3(RT), 0, h->side, h->dev, t, nbP, h->cfg.N + nbP);
@@ -569,6 +572,7 @@ static void flush_reduce(bnmf_handle* h, Timer& tm) {
   if (!h->red_pending) return;
   hipEventRecord(h->ev_z, h->stream);
   hipStreamWaitEvent(h->side, h->ev_z, 0);
+  hipStreamWaitEvent(h->side, h->ev_sideP, 0);             // k_lpe of the last iteration (side2)
   issue_reduce(h, h->red_t, h->red_row, tm);
   h->red_pending = false;
 }
@@ -631,10 +635,10 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   } else {
     // completion events ride on the dispatches themselves (stop events): no marker packets on the main stream
     hipExtLaunchKernelGGL(k_pdraw, dim3(h->cfg.N), dim3(PD_T), (uint32_t)(2 * (size_t)h->cfg.K * sizeof(double)), h->stream,
-                          nullptr, h->ev_p, 0, h->dev, t, 0);
+                          nullptr, h->ev_p, 0, h->dev, t, 0, 0);
     launch_side_P(h, t + 1);
     hipStreamWaitEvent(h->stream, h->ev_side, 0);          // E-side prior params of iteration t ready
-    hipExtLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, 0);
+    hipExtLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, 0, 0);
     launch_side_E(h, t + 1, tm);                           // overlaps the rank update / k_zalloc below
   }
   if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(RT, 4) void k_side(Dev d, uint32_t t, int nbP, int 
 // sample_Pn_poisson R/sample_Pn.R:98-120 (dispatch :11-42); Psum[n] and the log-prior of column n
 // are reduced canonically (W = 64) over k.
 constexpr int PD_T = 128;
-__global__ __launch_bounds__(PD_T) void k_pdraw(Dev d, uint32_t t, int from_prior) {
+__global__ __launch_bounds__(PD_T) void k_pdraw(Dev d, uint32_t t, int from_prior, int with_lp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
   double* Pn = (double*)dyn;          // [K]
   double* lp = Pn + d.K;              // [K]
@@ -169,10 +169,11 @@ __global__ __launch_bounds__(PD_T) void k_pdraw(Dev d, uint32_t t, int from_prio
     d.P[e] = x;
     d.ZsumG[e] = 0;                    // consumed; k_zalloc accumulates the next one
     Pn[k] = x;
-    lp[k] = prior_logdens<0>(d, e, x, t);
+    if (with_lp) lp[k] = prior_logdens<0>(d, e, x, t);
   }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;
+  if (wave && !with_lp) return;                           // the log-prior is then computed off the critical path (k_lpp)
   const double* src = wave ? lp : Pn;
   double acc = 0.0;
   for (int k = lane; k < K; k += 64) acc = acc + src[k];
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(PD_T) void k_pdraw(Dev d, uint32_t t, int from_prio
 // ---- k_edraw: one lane per element (n,g) of E, flat column-major index e = n + N g ----
 // sample_En_poisson R/sample_En.R:97-119; log-prior partial per 256-element block (canonical tree)
 constexpr int ES_T = 256;
-__global__ __launch_bounds__(ES_T) void k_edraw(Dev d, uint32_t t, int from_prior) {
+__global__ __launch_bounds__(ES_T) void k_edraw(Dev d, uint32_t t, int from_prior, int with_lp) {
   __shared__ double buf[ES_T];
   const int tid = threadIdx.x;
   const long e = (long)blockIdx.x * ES_T + tid;
@@ -202,8 +203,28 @@ __global__ __launch_bounds__(ES_T) void k_edraw(Dev d, uint32_t t, int from_prio
       x = rgamma(s, shape, rate);
     }
     d.E[e] = x;
-    lp = prior_logdens<1>(d, (int)e, x, t);
+    if (with_lp) lp = prior_logdens<1>(d, (int)e, x, t);
   }
+  if (!with_lp) return;                                 // the log-prior is then computed off the critical path (k_lpe)
+  const double r = block_tree<ES_T>(lp, buf, tid);
+  if (tid == 0) d.lpE_part[blockIdx.x] = r;
+}
+
+// log-prior of column n of P_t under iteration t's prior parameters: canonical W = 64 over k, as in k_pdraw
+__global__ __launch_bounds__(64) void k_lpp(Dev d, uint32_t t) {
+  const int n = blockIdx.x, lane = threadIdx.x, K = d.K;
+  double acc = 0.0;
+  for (int k = lane; k < K; k += 64) { const int e = k + K * n; acc = acc + prior_logdens<0>(d, e, d.P[e], t); }
+  acc = wave_tree64(acc);
+  if (lane == 0) d.lpPn[n] = acc;
+}
+// log-prior partials of E_t under iteration t's prior parameters, same 256-element blocks and tree as k_edraw
+__global__ __launch_bounds__(ES_T) void k_lpe(Dev d, uint32_t t) {
+  __shared__ double buf[ES_T];
+  const int tid = threadIdx.x;
+  const long e = (long)blockIdx.x * ES_T + tid;
+  double lp = 0.0;
+  if (e < (long)d.lenE) lp = prior_logdens<1>(d, (int)e, d.E[e], t);
   const double r = block_tree<ES_T>(lp, buf, tid);
   if (tid == 0) d.lpE_part[blockIdx.x] = r;
 }
