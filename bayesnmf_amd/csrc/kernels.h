@@ -130,6 +130,10 @@ BNMF_DEV double canon1024_by256(const double* x, long L, long stride, double* bu
 __global__ __launch_bounds__(RT, 4) void k_side(Dev d, uint32_t t, int nbP, int blk0) {
   __shared__ double buf[RT];
   const int tid = threadIdx.x, blk = blockIdx.x + blk0;   // one launch (blk0 = 0) or one launch per part
+  // The small launches (P part, Esum: a few dozen workgroups) share the CUs with k_zalloc, whose older waves win the
+  // instruction arbitration: without a raised priority these few young waves starve (Esum took 56 us for a 10,000-term
+  // reduction) although the event the next k_pdraw waits for hangs on them.  Too few waves to slow k_zalloc down.
+  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);
   if (blk < d.N) {
     const double r = canon1024_by256(d.E + blk, d.G, d.N, buf, tid);
     if (tid == 0) d.Esum[blk] = r;
@@ -212,6 +216,7 @@ __global__ __launch_bounds__(ES_T) void k_edraw(Dev d, uint32_t t, int from_prio
 
 // log-prior of column n of P_t under iteration t's prior parameters: canonical W = 64 over k, as in k_pdraw
 __global__ __launch_bounds__(64) void k_lpp(Dev d, uint32_t t) {
+  __builtin_amdgcn_s_setprio(3);                        // N one-wave workgroups beside k_zalloc (see k_side)
   const int n = blockIdx.x, lane = threadIdx.x, K = d.K;
   double acc = 0.0;
   for (int k = lane; k < K; k += 64) { const int e = k + K * n; acc = acc + prior_logdens<0>(d, e, d.P[e], t); }
