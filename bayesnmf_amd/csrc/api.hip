@@ -37,6 +37,7 @@ struct bnmf_handle {
   hipStream_t side2 = nullptr;         // second side stream: k_side P part (starts right after k_pdraw) and Esum
   hipEvent_t ev_draw = nullptr, ev_side = nullptr, ev_sideP = nullptr, ev_p = nullptr, ev_z = nullptr;
   bool side_valid = false;             // k_side of iteration iter+1 has been issued
+  const void* z_attr_kernel = nullptr;   // allocation kernel whose dynamic-LDS limit has been raised for this handle
   bool red_pending = false; uint32_t red_t = 0; int red_row = 0;   // k_reduce of the previous iteration, issued late
   int iter = 0;
   bool inited = false;
@@ -484,8 +485,11 @@ static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm) {   // ev_draw 
   if (h->red_pending) { issue_reduce(h, h->red_t, h->red_row, tm); h->red_pending = false; }
 }
 template <typename KernelT, typename ArgT>
-static int launch_z(bnmf_handle* h, uint32_t t, KernelT kern, const ArgT& arg, int zt, bool* attr_done) {
-  if (!*attr_done) { HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); *attr_done = true; }
+static int launch_z(bnmf_handle* h, uint32_t t, KernelT kern, const ArgT& arg, int zt) {
+  if (h->z_attr_kernel != (const void*)kern) {           // once per handle (per device): allow > 64 KiB of dynamic LDS
+    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    h->z_attr_kernel = (const void*)kern;
+  }
   hipLaunchKernelGGL(kern, dim3(h->z_grid), dim3(zt), h->z_lds, h->stream, arg, t, h->zg, h->z_ablate);
   return 0;
 }
@@ -495,19 +499,17 @@ static ZArgs zargs(const bnmf_handle* h) {
 }
 template <bool SZ, int ZT_, bool DIAG>
 static int launch_zreg_t(bnmf_handle* h, uint32_t t) {
-  static bool done[4] = {false, false, false, false};
   const ZArgs za = zargs(h);
   switch (h->zg.TR) {
-    case 8: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 8, DIAG>, za, ZT_, &done[0]);
-    case 16: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 16, DIAG>, za, ZT_, &done[1]);
-    case 20: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 20, DIAG>, za, ZT_, &done[2]);
-    default: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 24, DIAG>, za, ZT_, &done[3]);
+    case 8: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 8, DIAG>, za, ZT_);
+    case 16: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 16, DIAG>, za, ZT_);
+    case 20: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 20, DIAG>, za, ZT_);
+    default: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 24, DIAG>, za, ZT_);
   }
 }
 template <bool SZ, int ZT_>
 static int launch_zalloc_t(bnmf_handle* h, uint32_t t) {
-  static bool done = false;
-  if (!h->z_reg) return launch_z(h, t, k_zalloc<SZ, ZT_>, h->dev, ZT_, &done);
+  if (!h->z_reg) return launch_z(h, t, k_zalloc<SZ, ZT_>, h->dev, ZT_);
   return h->z_ablate ? launch_zreg_t<SZ, ZT_, true>(h, t) : launch_zreg_t<SZ, ZT_, false>(h, t);   // DIAG build honours BNMF_ABLATE
 }
 static int launch_zalloc(bnmf_handle* h, uint32_t t) {
