@@ -8,7 +8,9 @@ rng = np.random.default_rng(8)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 tot_bad = 0
 for (K, G, N, prior, kw) in [(5, 3, 1, "gamma", {}), (70, 9, 2, "gamma", {}), (33, 17, 26, "gamma", {}), (96, 300, 8, "gamma", {}),
-                             (40, 30, 4, "exponential", {}), (40, 30, 5, "gamma", dict(learning_rank=True))]:
+                             (40, 30, 4, "exponential", {}), (40, 30, 5, "gamma", dict(learning_rank=True)),
+                             (40, 700, 4, "truncnormal", dict(MH=True)), (30, 40, 3, "truncnormal", dict(likelihood="normal")),
+                             (96, 2000, 20, "gamma", {})]:
     M = rng.poisson(rng.gamma(0.5, 20.0, size=(K, G))).astype(np.int32)
     ref, bad = None, 0
     for r in range(reps):
