@@ -35,10 +35,10 @@ struct bnmf_handle {
   hipStream_t stream = nullptr;        // main stream: draws, k_zalloc, reductions
   hipStream_t side = nullptr;          // side stream: k_side (E part) of the next iteration (overlaps k_zalloc), k_reduce
   hipStream_t side2 = nullptr;         // second side stream: k_side P part (starts right after k_pdraw) and Esum
-  hipEvent_t ev_draw = nullptr, ev_side = nullptr, ev_sideP = nullptr, ev_p = nullptr, ev_z = nullptr;
+  hipEvent_t ev_draw = nullptr, ev_side = nullptr, ev_sideP = nullptr, ev_p = nullptr, ev_z = nullptr, ev_red = nullptr;
   bool side_valid = false;             // k_side of iteration iter+1 has been issued
   const void* z_attr_kernel = nullptr;   // allocation kernel whose dynamic-LDS limit has been raised for this handle
-  bool red_pending = false; uint32_t red_t = 0; int red_row = 0;   // k_reduce of the previous iteration, issued late
+  bool red_pending = false, red_issued = false; uint32_t red_t = 0; int red_row = 0;   // k_reduce of the previous iteration, issued late
   int iter = 0;
   bool inited = false;
   Dev dev{};
@@ -121,6 +121,7 @@ static void refresh_dev(bnmf_handle* h) {
 
 extern "C" {
 
+int bnmf_destroy(bnmf_handle* h);
 int bnmf_version(void) { return BNMF_VERSION; }
 const char* bnmf_last_error(void) { return g_err; }
 const char* bnmf_kernel_name(int i) { return (i >= 0 && i < BNMF_NKERNEL) ? k_names[i] : ""; }
@@ -138,6 +139,8 @@ int bnmf_device_info(int device, char* buf, size_t buflen) {
            (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), (size_t)p.sharedMemPerBlock);
   return 0;
 }
+
+static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h);
 
 int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
   if (!cfg || !M || !out) return fail(BNMF_EINVAL, "bnmf_create: null argument");
@@ -158,6 +161,17 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
   bnmf_handle* h = new bnmf_handle();
   h->cfg = *cfg;
   h->device = cfg->device;
+  if (int rc = create_impl(cfg, M, h)) {             // every failure path releases the handle and its device memory
+    char keep[sizeof g_err]; memcpy(keep, g_err, sizeof keep);
+    bnmf_destroy(h);
+    memcpy(g_err, keep, sizeof keep);
+    return rc;
+  }
+  *out = h;
+  return 0;
+}
+
+static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h) {
   const size_t K = cfg->K, G = cfg->G, N = cfg->N;
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
@@ -167,10 +181,11 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
   HIPCHK(hipEventCreateWithFlags(&h->ev_sideP, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_p, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_z, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_red, hipEventDisableTiming));
   HIPCHK(hipMalloc(&h->dM, K * G * sizeof(int32_t)));
   HIPCHK(hipMemcpy(h->dM, M, K * G * sizeof(int32_t), hipMemcpyHostToDevice));
   int mx = 0;
-  for (size_t i = 0; i < K * G; ++i) { if (M[i] < 0) { delete h; return fail(BNMF_EINVAL, "bnmf_create: negative count in M"); } if (M[i] > mx) mx = M[i]; }
+  for (size_t i = 0; i < K * G; ++i) { if (M[i] < 0) return fail(BNMF_EINVAL, "bnmf_create: negative count in M"); if (M[i] > mx) mx = M[i]; }
   h->maxM = mx;
   HIPCHK(hipMalloc(&h->dZsumK, N * G * sizeof(int32_t)));
   HIPCHK(hipMalloc(&h->dZsumG, K * N * sizeof(int32_t)));
@@ -225,7 +240,7 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
     if (const char* e = getenv("BNMF_ZREG")) h->z_reg = h->z_reg && atoi(e) != 0;   // diagnostics only
     long colmax = 0;
     for (size_t g = 0; g < G; ++g) { long cs = 0; for (size_t k = 0; k < K; ++k) cs += M[k + K * g]; if (cs > colmax) colmax = cs; }
-    if (colmax > 4000000) { delete h; return fail(BNMF_EINVAL, "bnmf_create: a column of M sums to %ld (> 4,000,000 counts): unsupported", colmax); }
+    if (colmax > 4000000) { return fail(BNMF_EINVAL, "bnmf_create: a column of M sums to %ld (> 4,000,000 counts): unsupported", colmax); }
     // LDS need of a geometry; the general kernel (k_zalloc) takes the whole column in one row chunk when that
     // leaves room for at least two waves per workgroup, else row chunks of 64 with ZsumG kept in global memory
     bool force_chunk = false;
@@ -265,9 +280,12 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
     };
     geometry(force_chunk && !h->z_reg);
     pick();
+    // the register path keeps (K+1) threshold rows per wave and a workgroup copy of P: for large K (e.g. K = 1,536
+    // with N <= 25) that exceeds LDS, so fall back to the general kernel, which can walk the rows in chunks
+    if (h->z_reg && best_total < 2) { h->z_reg = false; geometry(force_chunk); pick(); }
     if (!h->z_reg && best_total < 2 && !force_chunk) { geometry(true); pick(); }
     if (const char* e = getenv("BNMF_ZW")) { best_w = atoi(e); best_per_cu = (shared_words + (size_t)best_w * slab) * 4 * 2 <= 160 * 1024 ? 2 : 1; }
-    if (best_w == 0) { delete h; return fail(BNMF_EINVAL, "bnmf_create: N = %zu needs %zu B of LDS per wavefront for the allocation kernel (limit 160 KiB): unsupported", N, slab * 4); }
+    if (best_w == 0) return fail(BNMF_EINVAL, "bnmf_create: K = %zu, N = %zu needs %zu B of LDS per wavefront for the allocation kernel (limit 160 KiB): unsupported", K, N, slab * 4);
     h->z_zw = best_w;
     h->z_lds = ((shared_words + (size_t)best_w * slab) * 4 + 15) & ~(size_t)15;
     hipDeviceProp_t prop;
@@ -280,7 +298,6 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
   }
   HIPCHK(hipStreamSynchronize(h->stream));
   refresh_dev(h);
-  *out = h;
   return 0;
 }
 
@@ -295,7 +312,7 @@ int bnmf_destroy(bnmf_handle* h) {
   hipFree(h->dR); hipFree(h->dRedraw); hipFree(h->dEsum); hipFree(h->dPsum); hipFree(h->dlpPn);
   hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol);
   if (h->dProp) { hipFree(h->dProp); hipFree(h->dPart); hipFree(h->dAccPn); hipFree(h->dAccEpart); hipFree(h->dNzE); hipFree(h->dEt); hipFree(h->dMt); }
-  if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->side) hipStreamDestroy(h->side); if (h->side2) hipStreamDestroy(h->side2);
+  if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); if (h->side) hipStreamDestroy(h->side); if (h->side2) hipStreamDestroy(h->side2);
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -389,10 +406,6 @@ int bnmf_get_iter(bnmf_handle* h, int* iter) { if (!h || !iter) return fail(BNMF
 }  // extern "C"
 
 // ------------------------------------------------------------------ launch helpers
-static int check_model_supported(const bnmf_handle* h) {
-  const bnmf_config& c = h->cfg;
-  return 0;
-}
 static int need_hyper(bnmf_handle* h, std::initializer_list<int> ids) {
   for (int id : ids) if (!h->arr[id].d) return fail(BNMF_EUNSET, "hyper-prior array id %d was not set (fill_hyperprior_params, R/setup.R:15-88)", id);
   return 0;
@@ -408,12 +421,10 @@ static int ensure_metrics(bnmf_handle* h, size_t rows) {
   refresh_dev(h);
   return 0;
 }
-// The per-iteration partial sums (per-column metric terms, log-prior partials, acceptance partials) live
-// in two slots selected by t & 1, so that k_reduce of iteration t can run on the side stream while the
-// main stream already writes iteration t+1's partials.
 // Per-iteration partial sums (per-column metric terms, log-prior partials, MH acceptance partials) live in
 // three slots (t % 3): k_reduce of iteration t is issued during iteration t+1 (see launch_side), and the
-// next writers of its slot are the kernels of iteration t+3, ordered behind it through ev_side.
+// next writers of its slot are the kernels of iteration t+3: k_zalloc / k_lpe behind it through ev_side, k_lpp (side2)
+// through ev_red.
 static void set_slot(const bnmf_handle* h, Dev& d, uint32_t t) {
   const size_t sl = t % 3u, G = h->cfg.G, N = h->cfg.N;
   d.colsse = h->dcol + sl * 3 * G; d.colll = d.colsse + G; d.colkl = d.colsse + 2 * G;
@@ -443,6 +454,7 @@ static void issue_reduce(bnmf_handle* h, uint32_t t, int row, Timer& tm) {
   tm.begin(KN_REDUCE, h->side);
   hipLaunchKernelGGL(k_reduce, dim3(h->cfg.MH ? 5 : 4), dim3(RT), 0, h->side, dr, row, h->nblkE, (const double*)accPn_slot(h, t), (const double*)accEp_slot(h, t));
   tm.end(KN_REDUCE, h->side);
+  hipEventRecord(h->ev_red, h->side); h->red_issued = true;
 }
 static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm) {
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
@@ -467,6 +479,8 @@ static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm) {
 static void launch_side_P(bnmf_handle* h, uint32_t t) {       // ev_p = completion of k_pdraw(t-1)
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
   hipStreamWaitEvent(h->side2, h->ev_p, 0);
+  // k_lpp below rewrites lpPn slot (t-1) % 3, last read by k_reduce of iteration t-4 (side stream): order behind it
+  if (h->red_issued) hipStreamWaitEvent(h->side2, h->ev_red, 0);
   hipLaunchKernelGGL(k_side, dim3(nbP), dim3(RT), 0, h->side2, h->dev, t, nbP, h->cfg.N);
   hipLaunchKernelGGL(k_lpp, dim3(h->cfg.N), dim3(64), 0, h->side2, h->dev, t - 1);   // log-prior of the P just drawn
 }
@@ -618,8 +632,8 @@ static int sweep_mh(bnmf_handle* h, int row, int converged, Timer& tm) {
   tm.begin(KN_MH, h->stream); launch_mh_PE(h, t, converged); tm.end(KN_MH, h->stream);
   launch_side(h, t + 1, tm);
   if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
-  if (int rc = launch_record(h, t)) return rc;
   tm.begin(KN_OTHER, h->stream); launch_mh_metrics(h, t, h->cfg.learning_rank != 0); tm.end(KN_OTHER, h->stream);
+  if (int rc = launch_record(h, t)) return rc;              // after sample_sigmasq, like record_sample (:279) after sample_params (:276)
   launch_reduce(h, t, row, tm);
   return 0;
 }
@@ -654,7 +668,6 @@ extern "C" {
 
 int bnmf_init(bnmf_handle* h, double* metrics_row1) {
   if (!h) return fail(BNMF_EINVAL, "bnmf_init: null handle");
-  if (int rc = check_model_supported(h)) return rc;
   HIPCHK(hipSetDevice(h->device));
   const bnmf_config& c = h->cfg;
   const int N = c.N;
@@ -726,9 +739,9 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
     hipLaunchKernelGGL(k_rank_R, dim3(1), dim3(64), 0, h->stream, h->dev, 1u, 1);
     hipLaunchKernelGGL(k_rank_Aprior, dim3((N + 63) / 64), dim3(64), 0, h->stream, h->dev, 1u);
   }
-  if (int rc = launch_record(h, 1u)) return rc;
   if (c.MH || c.likelihood == BNMF_NORMAL) launch_mh_metrics(h, 1u, true);
   else if (int rc = launch_zalloc(h, 1u)) return rc;
+  if (int rc = launch_record(h, 1u)) return rc;
   launch_reduce(h, 1u, 0, tm);
   flush_reduce(h, tm);
   hipEventRecord(h->ev_z, h->side); hipStreamWaitEvent(h->stream, h->ev_z, 0);
@@ -750,7 +763,10 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
   HIPCHK(hipSetDevice(h->device));
   if (int rc = ensure_metrics(h, (size_t)n_iter)) return rc;
   const uint32_t t0 = (uint32_t)h->iter + 1;
-  for (int i = 0; i < n_iter; ++i) if (int rc = ((h->cfg.MH || h->cfg.likelihood == BNMF_NORMAL) ? sweep_mh(h, i, h->cfg.MH ? converged : 0, tm) : sweep(h, i, tm))) return rc;
+  for (int i = 0; i < n_iter; ++i) {
+    if (int rc = ((h->cfg.MH || h->cfg.likelihood == BNMF_NORMAL) ? sweep_mh(h, i, h->cfg.MH ? converged : 0, tm) : sweep(h, i, tm))) return rc;
+    HIPCHK(hipGetLastError());                               // a refused launch of this iteration (bad geometry, LDS size)
+  }
   flush_reduce(h, tm);
   hipEventRecord(h->ev_z, h->side); hipStreamWaitEvent(h->stream, h->ev_z, 0);   // last k_reduce done
   hipLaunchKernelGGL(k_compose, dim3((n_iter + 63) / 64), dim3(64), 0, h->stream, h->dev, n_iter, t0);
@@ -779,16 +795,17 @@ int bnmf_window(bnmf_handle* h, int id, int last_n, double* out) {
   const int W = h->cfg.window;
   if (W <= 0) return fail(BNMF_ESTATE, "bnmf_window: the handle was created with window = 0");
   if (last_n < 1 || last_n > W || last_n > h->iter) return fail(BNMF_ESIZE, "bnmf_window: last_n = %d but only min(window = %d, iter = %d) samples are kept", last_n, W, h->iter);
+  if (id < 0 || id >= BNMF_ID_MAX) return fail(BNMF_EINVAL, "bnmf_window: unknown id %d", id);
   const Arr& a = h->arr[id];
   const size_t len = id_len(h, id);
   if (!a.ring || len == 0) return fail(BNMF_EUNSET, "bnmf_window: id %d is not recorded for this model", id);
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
-  for (int i = 0; i < last_n; ++i) {
-    const int it = h->iter - last_n + 1 + i;                  // oldest first
-    const size_t slot = (size_t)((it - 1) % W);
-    HIPCHK(hipMemcpy(out + (size_t)i * len, a.ring + slot * len, len * sizeof(double), hipMemcpyDeviceToHost));
-  }
+  // sample `it` lives in slot (it-1) % W: the last_n samples, oldest first, are at most two contiguous runs of the ring
+  const size_t s0 = (size_t)((h->iter - last_n) % W);
+  const size_t n1 = (s0 + (size_t)last_n <= (size_t)W) ? (size_t)last_n : (size_t)W - s0;
+  HIPCHK(hipMemcpy(out, a.ring + s0 * len, n1 * len * sizeof(double), hipMemcpyDeviceToHost));
+  if (n1 < (size_t)last_n) HIPCHK(hipMemcpy(out + n1 * len, a.ring, ((size_t)last_n - n1) * len * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -4,14 +4,22 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one whole Gibbs iteration (hyper sweep -> P -> E -> Z allocation -> metrics row) of
-the Poisson-Gamma model at K=96, G=10,000, N=20 on synthetic counts already resident in HBM.
-One independent chain per GPU (chain_id = rank); no data-path collective; RCCL only gathers the
-chains' final metrics rows.  Rank 0 prints ONE JSON line.
+A "step" is one whole Gibbs iteration of the reference's loop body (R/bayesNMF_sampler.R:273-285):
+hyper sweep -> P -> E -> Z allocation -> record_sample into the MAP_over = 1000 deep device ring ->
+metrics row, for the Poisson-Gamma model at K=96, G=10,000, N=20 on synthetic counts already resident
+in HBM.  One independent chain per GPU (chain_id = rank); no data-path collective; RCCL only gathers
+the chains' final metrics rows.  Rank 0 prints ONE JSON line.
+
+`--gpus N` without WORLD_SIZE in the environment starts the N ranks itself (fresh child processes,
+before anything here touches the GPU).  The timed region is repeated `--reps` times (default 5), each
+repetition timing EXACTLY `--steps` iterations between barriers; `value` is the median repetition
+(SURVEY.md 8d protocol) and every repetition is listed under `rep_values`.
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
 import time
 
@@ -21,7 +29,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 K_, G_, N_, R_TRUE, DATA_SEED = 96, 10000, 20, 8, 20250218
+MAP_OVER = 1000                # new_convergence_control() default: depth of the record_sample ring
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PROFILE_TAG = "r02"
 
 
 def z_bytes(K, G, N, save_Z):
@@ -36,19 +46,21 @@ def z_bytes(K, G, N, save_Z):
 def pmc_traffic(save_Z):
     """HBM bytes per k_zalloc launch from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
     rocprofv3 --pmc passes by tools/pmc2.sh, gfx950-corrected; committed under profiles/).  None if absent."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        return d["k_zalloc_full" if save_Z else "k_zalloc_stats"]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    for tag in (PROFILE_TAG, "r01"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))
+            return d["k_zalloc_full" if save_Z else "k_zalloc_stats"]["hbm_bytes_per_launch"]
+        except Exception:
+            continue
+    return None
 
 
-def roofline_of(chain, K, G, N, save_Z, total_counts, n_iter):
+def roofline_of(chain, K, G, N, save_Z, total_counts, n_iter, kernel="k_zalloc_reg"):
     prof = chain.profile(n_iter)
     zb = z_bytes(K, G, N, save_Z)
     z_ms = prof["k_zalloc"]
     achieved = zb / (z_ms * 1e-3) / 1e9 if z_ms > 0 else 0.0
-    return prof, {"bound": "hbm", "kernel": "k_zalloc_reg" + ("<save_Z>" if save_Z else ""), "achieved": achieved,
+    return prof, {"bound": "hbm", "kernel": kernel + ("<save_Z>" if save_Z else ""), "achieved": achieved,
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(save_Z),
                   "algorithmic_bytes_per_launch": zb, "avg_launch_ms": z_ms,
                   "draws_per_s": total_counts / (z_ms * 1e-3) if z_ms > 0 else 0.0,
@@ -56,30 +68,127 @@ def roofline_of(chain, K, G, N, save_Z, total_counts, n_iter):
                           if not save_Z else "full mode: Z (K x N x G int32) written every iteration"}
 
 
-def make_chain(M, N, seed, chain_id, device, save_Z=False):
+def make_chain(M, N, seed, chain_id, device, save_Z=False, window=MAP_OVER, prior="gamma", **kw):
     from bayesnmf_amd import Engine
     from bayesnmf_amd.setup import apply_hyperprior_params
-    e = Engine(M, N, prior="gamma", seed=seed, chain_id=chain_id, device=device, save_Z=save_Z)
-    apply_hyperprior_params(e, "gamma", M, N)
+    e = Engine(M, N, prior=prior, seed=seed, chain_id=chain_id, device=device, save_Z=save_Z, window=window, **kw)
+    apply_hyperprior_params(e, prior, M, N)
     e.init()
     return e
 
 
-def cpu_baseline(M, N, budget_s=15.0):
-    """The CPU oracle ("port" of the reference sweep) timed on this box's host cores on a
-    bounded sample of the same workload."""
+def _time_oracle(M, N, cores, budget_s):
     import oracle as O
     from bayesnmf_amd.setup import apply_hyperprior_params
-    cores = min(os.cpu_count() or 1, 64)
     o = O.Oracle(M, N, prior="gamma", seed=1, nthreads=cores)
     apply_hyperprior_params(o, "gamma", M, N)
     o.init()
     t0 = time.perf_counter(); o.run(1); dt = time.perf_counter() - t0
     n = int(max(2, min(200, budget_s / max(dt, 1e-3))))
     t0 = time.perf_counter(); o.run(n); dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "Gibbs iterations/s", "cores": cores, "kind": "port",
-            "sample": f"{n} iterations of the same K={M.shape[0]}, G={M.shape[1]}, N={N} Poisson-Gamma sweep "
-                      f"(CPU oracle, scalar C + OpenMP over columns)"}
+    o.close()
+    return n / dt, n
+
+
+def probe_rscript(M, N):
+    """the reference pure-R path can be timed only where the box has Rscript with the bayesNMF
+    package installed.  Returns its it/s (config-1-sized sample, R is single-threaded) or the reason it cannot run."""
+    rs = shutil.which("Rscript")
+    if not rs:
+        return {"available": False, "reason": "Rscript not on PATH"}
+    try:
+        r = subprocess.run([rs, "-e", "suppressMessages(library(bayesNMF))"], capture_output=True, timeout=60)
+        if r.returncode != 0:
+            return {"available": False, "reason": "library(bayesNMF) failed: " + r.stderr.decode()[-200:]}
+        import tempfile
+        d = tempfile.mkdtemp()
+        np.savetxt(os.path.join(d, "M.csv"), M[:, :100], fmt="%d", delimiter=",")
+        code = (f"suppressMessages(library(bayesNMF)); M <- as.matrix(read.csv('{d}/M.csv', header=FALSE)); "
+                f"cc <- new_convergence_control(maxiters=20, MAP_over=10, MAP_every=10, miniters=0); t0 <- Sys.time(); "
+                f"s <- bayesNMF(M, rank={N}, prior='gamma', likelihood='poisson', MH=FALSE, periodic_save=FALSE, "
+                f"save_all_samples=FALSE, convergence_control=cc, output_dir='{d}/out', overwrite=TRUE); "
+                f"cat(as.numeric(difftime(Sys.time(), t0, units='secs')))")
+        r = subprocess.run([rs, "-e", code], capture_output=True, timeout=600)
+        secs = float(r.stdout.decode().strip().split()[-1])
+        return {"available": True, "value": 20.0 / secs, "unit": "Gibbs iterations/s", "cores": 1, "kind": "reference",
+                "sample": f"20 iterations of bayesNMF() in R on the first 100 columns (K={M.shape[0]}, N={N})"}
+    except Exception as ex:  # noqa: BLE001
+        return {"available": False, "reason": repr(ex)[:200]}
+
+
+def cpu_baseline(M, N, budget_s=10.0):
+    """The CPU oracle ("port" of the reference sweep) timed on this box's host cores on a bounded sample of
+    the same workload: all cores (OpenMP over columns) and one core.  The reference itself is pure R: it is
+    probed for and timed only if this box happens to have it installed."""
+    cores = min(os.cpu_count() or 1, 64)
+    v_all, n_all = _time_oracle(M, N, cores, budget_s)
+    v_one, n_one = _time_oracle(M, N, 1, budget_s)
+    return {"value": v_all, "unit": "Gibbs iterations/s", "cores": cores, "kind": "port",
+            "value_1core": v_one,
+            "sample": f"{n_all} iterations on {cores} cores and {n_one} iterations on 1 core of the same K={M.shape[0]}, "
+                      f"G={M.shape[1]}, N={N} Poisson-Gamma sweep (CPU oracle: scalar C, OpenMP over columns)",
+            "reference_R": probe_rscript(M, N)}
+
+
+def secondary_configs(device, quick=False):
+    """BASELINE.json configs 2-5 at full size on one GPU (one chain each), each with the HBM roofline of its
+    allocation / dominant kernel.  Parity for these shapes is in tests/; these are timings only."""
+    from bayesnmf_amd.setup import synth_counts
+    out = []
+
+    def run(name, K, G, N, prior, iters, rtrue, seed_off, kernel, **kw):
+        t0 = time.perf_counter()
+        M, _, _ = synth_counts(K, G, rtrue, DATA_SEED + seed_off)
+        c = make_chain(M, N, 1, 0, device, prior=prior, **kw)
+        c.run(max(2, iters // 5), metrics=False)
+        rec = {"config": name, "K": K, "G": G, "N": N, "window": kw.get("window", MAP_OVER)}
+        phases = [("it_per_s", False)] + ([("it_per_s_after_convergence", True)] if kw.get("MH") else [])
+        for key, conv in phases:
+            t1 = time.perf_counter(); c.run(iters, converged=conv, metrics=True); dt = time.perf_counter() - t1
+            rec[key] = iters / dt
+        if not kw.get("MH"):
+            zb = z_bytes(K, G, N, False)
+            prof = c.profile(max(3, iters // 10))
+            zms = prof["k_zalloc"]
+            rec["roofline"] = {"bound": "hbm", "kernel": kernel, "algorithmic_bytes_per_launch": zb, "avg_launch_ms": zms,
+                               "achieved": zb / (zms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": zb / (zms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            rec["kernel_ms"] = prof
+        else:
+            # sequential-in-n Normal-approximation sweeps: every factor update reads M (int32) and Mhat-sized data once
+            b = N * 2 * (4 * K * G + 8 * N * G)
+            rec["roofline"] = {"bound": "hbm", "kernel": "k_mh_*", "algorithmic_bytes_per_iteration": b,
+                               "achieved": b * rec["it_per_s"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": b * rec["it_per_s"] / 1e9 / HBM_PEAK_GBS}
+        rec["setup_s"] = time.perf_counter() - t0
+        c.close()
+        out.append(rec)
+
+    run("2: Poisson-Gamma fixed rank N=20, K=96 x G=2,000", 96, 2000, 20, "gamma", 1000, 8, 2, "k_zalloc_reg")
+    run("3: Poisson-TruncNormal+MH fixed rank N=20, K=96 x G=5,000", 96, 5000, 20, "truncnormal", 60, 8, 3, "k_mh", MH=True)
+    run("4: Poisson-Gamma SBFI learned rank 1:50, K=96 x G=10,000", 96, 10000, 50, "gamma", 60, 12, 4, "k_zalloc",
+        learning_rank=True, rank_method="SBFI", temperature=np.ones(8000))
+    if not quick:
+        run("5: Poisson-Gamma fixed rank N=100, K=1,536 x G=50,000", 1536, 50000, 100, "gamma", 6, 30, 5, "k_zalloc (row-chunked)",
+            window=2)
+    return out
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher: start the N ranks as fresh children (this process has not
+    touched the GPU), pass rank 0's JSON line through."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, p.wait())
+    sys.exit(rc)
 
 
 def main():
@@ -87,10 +196,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step region; value = median")
+    ap.add_argument("--window", type=int, default=MAP_OVER, help="record_sample ring depth (MAP_over); 0 = recording off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the timings of BASELINE configs 2-5")
     ap.add_argument("--save-z", action="store_true", help="full mode: materialise Z every iteration")
     ap.add_argument("--G", type=int, default=G_)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -107,7 +222,8 @@ def main():
 
     from bayesnmf_amd.setup import synth_counts
     M, _, _ = synth_counts(K_, args.G, R_TRUE, DATA_SEED)
-    chain = make_chain(M, N_, seed=1, chain_id=rank, device=local_rank, save_Z=args.save_z)
+    total_counts = int(M.sum())
+    chain = make_chain(M, N_, seed=1, chain_id=rank, device=local_rank, save_Z=args.save_z, window=args.window)
 
     def barrier():
         if dist is not None:
@@ -115,52 +231,67 @@ def main():
         torch.cuda.synchronize()
 
     chain.run(args.warmup, metrics=False)
-    barrier()
-    t0 = time.perf_counter()
-    met = chain.run(args.steps, metrics=True)       # synchronises the chain's stream at the end
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    barrier()
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    # roofline of the dominant kernel (k_zalloc): HIP events on the chain's own stream, one kernel at a time.
+    # Done before the timed region (it advances the chain like any other iterations and keeps the clocks up).
+    prof, roof = roofline_of(chain, K_, args.G, N_, args.save_z, total_counts, min(200, max(20, args.steps // 10)))
+    chain.run(max(args.warmup, 20), metrics=False)   # refill the two-stream pipeline after the serialised profile pass
+
+    rep_dt = []
+    met = None
+    for _ in range(max(1, args.reps)):
+        barrier()
+        t0 = time.perf_counter()
+        met = chain.run(args.steps, metrics=True)       # synchronises the chain's streams at the end
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        barrier()
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        rep_dt.append(float(tmax.item()))
     gathered = None
     if dist is not None:
         from bayesnmf_amd.multichain import gather_rows
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         gathered = gather_rows(met[-1:], dist, device="cuda")   # RCCL: gather the chains' last metrics rows
-    tmax = float(tmax.item())
+    tmed = float(np.median(rep_dt))
 
-    # roofline of the dominant kernel (k_zalloc), HIP events on the chain's own stream
-    total_counts = int(M.sum())
-    prof, roof = roofline_of(chain, K_, args.G, N_, args.save_z, total_counts, min(200, max(20, args.steps // 10)))
     out = None
     if rank == 0:
         out = {
             "metric": "Gibbs iters/sec at K=96, G=10k, N=20; per-chain scaling at 1/2/4/8 GPUs",
-            "value": world * args.steps / tmax,
+            "value": world * args.steps / tmed,
             "unit": "Gibbs iterations/s (aggregate over chains)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * tmax / args.steps,
+            "ms_per_step": 1e3 * tmed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"Poisson-Gamma fixed rank N={N_}, K={K_} x G={args.G} synthetic counts, "
                                    f"one chain per GPU, {'full (save_Z)' if args.save_z else 'stats'} mode, "
-                                   f"metrics every iteration",
-                       "chains": world, "seed": 1, "sum_M": total_counts},
+                                   f"record_sample into a {args.window}-deep device ring "
+                                   f"({'on' if args.window > 0 else 'OFF'}) and a metrics row every iteration",
+                       "chains": world, "seed": 1, "sum_M": total_counts, "record_window": args.window},
+            "reps": len(rep_dt), "rep_values": [world * args.steps / t for t in rep_dt],
             "roofline": roof,
             "kernel_ms": prof,
         }
         if world == 1 and not args.save_z:
             # the same kernel in full mode (Z materialised): the only mode in which HBM traffic is substantial
-            cz = make_chain(M, N_, seed=1, chain_id=0, device=local_rank, save_Z=True)
+            cz = make_chain(M, N_, seed=1, chain_id=0, device=local_rank, save_Z=True, window=0)
             cz.run(50, metrics=False)
             _, out["roofline_save_Z"] = roofline_of(cz, K_, args.G, N_, True, total_counts, 100)
             cz.close()
         if gathered is not None:
             out["chains_final_logposterior"] = [float(g[0][4]) for g in gathered]
+    chain.close()
+    if rank == 0:
+        if world == 1 and not args.no_secondary:
+            try:
+                out["secondary"] = secondary_configs(local_rank)
+            except Exception as ex:  # noqa: BLE001  (a secondary timing must not lose the headline line)
+                out["secondary_error"] = repr(ex)[:300]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(M, N_)
-        print(json.dumps(out))
-    chain.close()
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

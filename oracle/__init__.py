@@ -58,6 +58,8 @@ def lib():
         L.orc_init.argtypes = [C.c_void_p, dp]
         L.orc_run.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
         L.orc_get_iter.argtypes = [C.c_void_p]
+        L.orc_set_M.argtypes = [C.c_void_p, ip]
+        L.orc_t_step.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int]
         L.orc_last_error.restype = C.c_char_p
         L.orc_last_error.argtypes = [C.c_void_p]
         for f in ("log", "exp", "lgamma", "digamma", "qnorm", "log_pnorm"):
@@ -218,6 +220,20 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(lib().orc_last_error(self._h).decode())
         return out
+
+    STEPS = dict(hyper=0, P=1, E=2, R=3, A=4, Z=5, sigmasq=6)
+
+    def step(self, what, t, converged=False):
+        """One conditional of the sweep on the current state, with the random streams of iteration t."""
+        rc = lib().orc_t_step(self._h, self.STEPS[what], int(t), int(converged))
+        if rc != 0:
+            raise ValueError(f"orc_t_step({what}) not defined for this model")
+
+    def set_M(self, M):
+        M = np.asfortranarray(M, dtype=np.int32)
+        assert M.shape == (self.K, self.G)
+        lib().orc_set_M(self._h, M.ctypes.data_as(C.POINTER(C.c_int32)))
+        self.M = M
 
     @property
     def iter(self):

@@ -893,6 +893,32 @@ int orc_run(orc_handle* o, int n_iter, int converged, double* metrics /* n_iter 
 }
 const char* orc_last_error(orc_handle* o) { return o->err; }
 
+/* ---- single-step hooks for the law tests (tests/test_oracle_laws.py): one conditional of the sweep on the
+ * current state with the streams of iteration t; orc_set_M swaps the data (Geweke joint-distribution test) ---- */
+int orc_set_M(orc_handle* o, const int32_t* M) {
+  memcpy(o->M, M, sizeof(int32_t) * (size_t)o->cfg.K * o->cfg.G);
+  return 0;
+}
+enum { STEP_HYPER = 0, STEP_P = 1, STEP_E = 2, STEP_R = 3, STEP_A = 4, STEP_Z = 5, STEP_SIGMASQ = 6 };
+int orc_t_step(orc_handle* o, int what, uint32_t t, int converged) {
+  const long K = o->cfg.K, G = o->cfg.G, N = o->cfg.N;
+  const int normal = o->cfg.likelihood == LIK_NORMAL, mh = o->cfg.MH;
+  o->converged = converged;
+  switch (what) {
+    case STEP_HYPER:
+      for (long e = 0; e < K * N; ++e) hyper_elem(o, 0, e, t);
+      for (long e = 0; e < N * G; ++e) hyper_elem(o, 1, e, t);
+      return 0;
+    case STEP_P: if (normal) sample_P_normal(o, t); else if (mh) sample_P_mh(o, t); else sample_P_poisson(o, t, 0); return 0;
+    case STEP_E: if (normal) sample_E_normal(o, t); else if (mh) sample_E_mh(o, t); else sample_E_poisson(o, t, 0); return 0;
+    case STEP_R: sample_R(o, t, 0); return 0;
+    case STEP_A: sample_A(o, t, 0); return 0;
+    case STEP_Z: if (normal || mh) return -1; sample_Z_and_metrics(o, t); return 0;
+    case STEP_SIGMASQ: if (!normal) return -1; sample_sigmasq(o, t); return 0;
+    default: return -1;
+  }
+}
+
 /* ---- unit-test exports ---- */
 void orc_t_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   orc_philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);

@@ -1,0 +1,268 @@
+"""GPU parity tests of the BASELINE.json configurations' real kernel paths (through the C ABI):
+config 4's learned rank at N = 50 (general allocation kernel with excluded factors), full-size property
+runs of configs 3, 4 and 5, the large-K fallback of the register kernel, record_sample against the oracle,
+the vignette's initial-value checks and the ABI's error codes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _temp_schedule(n):
+    return np.concatenate([np.zeros(3), 10.0 ** np.linspace(-6, 0, 40), np.ones(max(0, n - 43))])
+
+
+def _mk(cls, M, N, prior, **kw):
+    from bayesnmf_amd.setup import apply_hyperprior_params
+    c = cls(M, N, prior=prior, **kw)
+    apply_hyperprior_params(c, prior, M, N)
+    return c
+
+
+def test_config4_learned_rank_N50_bitexact():
+    """Config 4's model on its real kernel path: rank = 1:50 => N = 50 > 25, so the Z allocation runs on the
+    general kernel k_zalloc with A containing zeros (R/sample_params.R:101-241, :253-265).  Bit-exact against
+    the oracle at a reduced number of columns."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts
+    M, _, _ = synth_counts(96, 72, 5, 20250230)
+    N = 50
+    temp = _temp_schedule(200)
+    kw = dict(learning_rank=True, rank_method="SBFI", seed=13, temperature=temp, save_Z=True)
+    o = _mk(O.Oracle, M, N, "gamma", nthreads=8, **kw)
+    e = _mk(Engine, M, N, "gamma", **kw)
+    r0, r1 = o.init(), e.init()
+    assert np.array_equal(o.get("A"), e.get("A")) and o.get("R")[0] == e.get("R")[0]
+    assert np.array_equal(r0[:9].view(np.uint64), r1[:9].view(np.uint64))
+    saw_zero = False
+    for step in range(4):
+        mo, me = o.run(12), e.run(12)
+        A = e.get("A")[0]
+        saw_zero = saw_zero or (A == 0).any()
+        assert np.array_equal(o.get("A"), e.get("A")), f"A differs at block {step}"
+        assert o.get("R")[0] == e.get("R")[0]
+        Z = e.get("Z")
+        assert np.array_equal(o.get("Z").astype(np.int32), Z)
+        assert (Z[:, A == 0, :] == 0).all()
+        for nm in ("P", "E", "Alpha_e", "Beta_p"):
+            assert np.array_equal(o.get(nm).view(np.uint64), e.get(nm).view(np.uint64)), nm
+        assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64))
+    assert saw_zero, "the run never excluded a factor: the zero-probability path was not exercised"
+
+
+def test_config4_full_size_properties():
+    """Config 4 at full size (K = 96, G = 10,000, N = 50, SBFI): sum_n Z = M for every cell, Z = 0 wherever
+    A[n] = 0, marginals consistent."""
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts
+    M, _, _ = synth_counts(96, 10000, 12, 20250222)
+    N = 50
+    A0 = np.ones((1, N)); A0[0, 5::3] = 0.0                       # start with a third of the factors excluded
+    e = _mk(Engine, M, N, "gamma", learning_rank=True, rank_method="SBFI", seed=1, temperature=np.ones(100), save_Z=True)
+    e.set("A", A0)
+    e.init()
+    met = e.run(3)
+    A = e.get("A")[0]
+    Z = e.get("Z")
+    assert (Z >= 0).all()
+    assert (Z[:, A == 0, :] == 0).all()
+    if A.sum() > 0:
+        assert (Z.sum(1) == M).all()
+    assert np.array_equal(e.get("ZsumK"), Z.sum(0)) and np.array_equal(e.get("ZsumG"), Z.sum(2))
+    assert np.all(np.isfinite(met[:, :9]))
+    assert met[-1, 7] == A.sum()
+    e.close()
+
+
+def test_config3_N20_bitexact_reduced_G():
+    """Config 3's model at its full rank N = 20 (K = 96), G reduced to two 512-column segments so that the
+    oracle finishes in seconds: both phases (accept-all, true MH) bit-exact."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts
+    M, _, _ = synth_counts(96, 600, 8, 20250223)
+    N = 20
+    o = _mk(O.Oracle, M, N, "truncnormal", MH=True, seed=4, nthreads=16)
+    e = _mk(Engine, M, N, "truncnormal", MH=True, seed=4)
+    o.init(); e.init()
+    for conv in (False, True):
+        mo, me = o.run(3, converged=conv), e.run(3, converged=conv)
+        for nm in ("P", "E", "P_acceptance_rate", "E_acceptance_rate", "Mu_p", "Sigmasq_e"):
+            a, b = o.get(nm), e.get(nm)
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), f"{nm}: {np.sum(a != b)} differ (converged={conv})"
+        assert np.array_equal(mo.view(np.uint64), me.view(np.uint64))
+
+
+def test_config3_full_size_properties():
+    """Config 3 at full size (Poisson-TruncNormal + MH, N = 20, K = 96, G = 5,000), both phases: state stays
+    finite and non-negative, acceptance rates are 1 before convergence and in [0, 1] after, the fit improves."""
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts
+    M, _, _ = synth_counts(96, 5000, 8, 20250221)
+    e = _mk(Engine, M, 20, "truncnormal", MH=True, seed=1)
+    r0 = e.init()
+    met = e.run(30, converged=False)
+    assert np.all(np.isfinite(met))
+    assert (e.get("P_acceptance_rate") == 1.0).all() and (e.get("E_acceptance_rate") == 1.0).all()
+    assert (met[:, 9] == 1.0).all() and (met[:, 10] == 1.0).all()
+    assert met[-1, 1] < r0[1]                                      # RMSE below the prior draw's
+    met2 = e.run(10, converged=True)
+    P, E = e.get("P"), e.get("E")
+    assert np.isfinite(P).all() and np.isfinite(E).all() and (P >= 0).all() and (E >= 0).all()
+    for nm in ("P_acceptance_rate", "E_acceptance_rate"):
+        a = e.get(nm)
+        assert (a >= 0).all() and (a <= 1).all()
+    assert np.all(np.isfinite(met2)) and (met2[:, 9] <= 1).all() and (met2[:, 9] > 0).all()
+    e.close()
+
+
+def test_config5_full_size_properties():
+    """Config 5 at FULL size (K = 1,536, G = 50,000, N = 100): the row-chunked allocation kernel; the marginals
+    of Z reproduce the row and column sums of M exactly, metrics finite."""
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts
+    M, _, _ = synth_counts(1536, 50000, 30, 20250223)
+    e = _mk(Engine, M, 100, "gamma", seed=1)
+    e.init()
+    met = e.run(2)
+    zk, zg = e.get("ZsumK"), e.get("ZsumG")
+    assert (zk >= 0).all() and (zg >= 0).all()
+    assert np.array_equal(zk.sum(0, dtype=np.int64), M.sum(0, dtype=np.int64))
+    assert np.array_equal(zg.sum(1, dtype=np.int64), M.sum(1, dtype=np.int64))
+    assert np.all(np.isfinite(met[:, :9]))
+    e.close()
+
+
+@pytest.mark.parametrize("K,G,N", [(1536, 12, 5), (700, 9, 20)])
+def test_large_K_small_N_falls_back_to_general_kernel(K, G, N):
+    """N <= 25 normally takes the register kernel, whose per-wave LDS slab grows with K; when it does not fit
+    (K = 1,536: SBS-1536 catalogues) create falls back to the general kernel instead of failing.  Bit-exact."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    rng = np.random.default_rng(K + N)
+    M = rng.poisson(rng.gamma(0.5, 12.0, size=(K, G))).astype(np.int32)
+    o = _mk(O.Oracle, M, N, "gamma", seed=5, save_Z=True, nthreads=8)
+    e = _mk(Engine, M, N, "gamma", seed=5, save_Z=True)
+    o.init(); e.init()
+    mo, me = o.run(4), e.run(4)
+    assert np.array_equal(o.get("Z").astype(np.int32), e.get("Z"))
+    assert np.array_equal(o.get("E").view(np.uint64), e.get("E").view(np.uint64))
+    assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64))
+    e.close()
+
+
+@pytest.mark.parametrize("model", ["gamma", "truncnormal_mh", "normal"])
+def test_record_sample_against_oracle(model):
+    """record_sample (R/bayesNMF_sampler.R:651-672): every recorded array of every iteration in the device
+    ring equals what the ORACLE held at that iteration (incl. iteration 1 and, for the Normal likelihood,
+    sigmasq drawn in the same iteration), across a wrap-around of the ring."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts
+    M, _, _ = synth_counts(96, 40, 3, 77)
+    N = 4
+    if model == "gamma":
+        kw, prior, names = dict(), "gamma", ["P", "E", "A", "R", "Alpha_p", "Beta_p", "Alpha_e", "Beta_e"]
+    elif model == "truncnormal_mh":
+        kw, prior = dict(MH=True), "truncnormal"
+        names = ["P", "E", "Mu_p", "Sigmasq_p", "Mu_e", "Sigmasq_e", "P_acceptance_rate", "E_acceptance_rate"]
+    else:
+        kw, prior, names = dict(likelihood="normal"), "exponential", ["P", "E", "Lambda_p", "Lambda_e", "sigmasq"]
+    W = 5
+    o = _mk(O.Oracle, M, N, prior, seed=21, nthreads=4, **kw)
+    e = _mk(Engine, M, N, prior, seed=21, window=W, **kw)
+    o.init(); e.init()
+    hist = {1: {nm: o.get(nm).copy() for nm in names}}
+    for nm in names:                                                # samples[[nm]][[1]]
+        assert np.array_equal(e.window(nm, 1)[0].view(np.uint64), hist[1][nm].view(np.uint64)), (nm, 1)
+    for it in range(2, 13):
+        o.run(1); e.run(1)
+        hist[it] = {nm: o.get(nm).copy() for nm in names}
+        if it in (3, 7, 12):
+            n = min(W, it)
+            for nm in names:
+                win = e.window(nm, n)
+                for j, i2 in enumerate(range(it - n + 1, it + 1)):
+                    assert np.array_equal(win[j].view(np.uint64), hist[i2][nm].view(np.uint64)), (nm, i2, it)
+    e.close()
+
+
+@pytest.mark.parametrize("prior", ["truncnormal", "exponential", "gamma"])
+def test_vignette_initial_value_checks(prior, tmp_path):
+    """The reference's own executable checks (vignettes/advanced.qmd:181-185, :245-249, :315-319):
+    samples$P[[1]] == init_params$P, samples$<prior param>[[1]] == init_prior_params$<...>, and the supplied
+    hyper-prior scalar is kept — through the bayesNMF() mirror with rank = 1:10 as in the vignette."""
+    import os
+    from bayesnmf_amd.sampler import bayesNMF
+    from bayesnmf_amd.convergence import new_convergence_control
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_example_data.npz"))
+    M = d["M"]
+    K, G = M.shape
+    N = 10
+    init_params = dict(R=[N], A=np.ones((1, N)), P=np.ones((K, N)), E=np.ones((N, G)))
+    if prior == "truncnormal":
+        ipp = dict(Mu_p=np.zeros((K, N)), Sigmasq_p=np.ones((K, N)), Mu_e=np.zeros((N, G)), Sigmasq_e=np.ones((N, G)))
+        hp = dict(m_p=0.0, s_p=np.sqrt(M.mean() / N), a_p=N + 1.0, b_p=np.sqrt(N), m_e=0.0, s_e=np.sqrt(M.mean() / N),
+                  a_e=N + 1.0, b_e=np.sqrt(N))
+        key, hkey = "Mu_p", "m_p"
+    elif prior == "exponential":
+        ipp = dict(Lambda_p=np.ones((K, N)), Lambda_e=np.ones((N, G)))
+        hp = dict(a_p=10 * np.sqrt(N), b_p=10 * np.sqrt(M.mean()), a_e=10 * np.sqrt(N), b_e=10 * np.sqrt(M.mean()))
+        key, hkey = "Lambda_p", "a_p"
+    else:
+        ipp = dict(Alpha_p=np.ones((K, N)), Beta_p=np.ones((K, N)), Alpha_e=np.ones((N, G)), Beta_e=np.ones((N, G)))
+        hp = dict(a_p=10 * np.sqrt(N), b_p=10.0, c_p=10 * np.sqrt(M.mean()), d_p=10.0, a_e=10 * np.sqrt(N), b_e=10.0,
+                  c_e=10 * np.sqrt(M.mean()), d_e=10.0)
+        key, hkey = "Alpha_p", "a_p"
+    cc = new_convergence_control(MAP_over=20, MAP_every=10, maxiters=40, tol=0.01, miniters=0)   # "short", shortened further
+    s = bayesNMF(M, range(1, N + 1), prior=prior, hyperprior_params=hp, init_prior_params=ipp, init_params=init_params,
+                 output_dir=str(tmp_path / "o"), save_all_samples=True, overwrite=True, convergence_control=cc,
+                 periodic_save=False, post_warmup=10)
+    smp = s.samples
+    assert np.array_equal(smp["P"][0], init_params["P"])
+    assert np.array_equal(smp[key][0], ipp[key])
+    assert s.hyperprior_params[hkey] == hp[hkey]
+    assert np.array_equal(smp["A"][0], init_params["A"]) and smp["R"][0][0] == N
+    s.close()
+
+
+def test_abi_error_codes():
+    """Error behaviour of the boundary: negative codes + bnmf_last_error(), nothing thrown across the ABI."""
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.engine import BnmfError
+    from bayesnmf_amd.setup import apply_hyperprior_params
+    M = np.random.default_rng(0).poisson(5.0, size=(12, 9)).astype(np.int32)
+    with pytest.raises(BnmfError) as ei:
+        Engine(M, 3, prior="gamma", MH=True)
+    assert ei.value.code == -6                                      # BNMF_EMODEL (check_model)
+    with pytest.raises(BnmfError) as ei:
+        Engine(M, 3, prior="truncnormal", MH=False)
+    assert ei.value.code == -6
+    with pytest.raises(BnmfError) as ei:
+        Engine(-M - 1, 3, prior="gamma")
+    assert ei.value.code == -1                                      # BNMF_EINVAL: negative counts
+    e = Engine(M, 3, prior="gamma", window=4)
+    with pytest.raises(BnmfError) as ei:
+        e.run(1)
+    assert ei.value.code == -7                                      # BNMF_ESTATE: run before init
+    with pytest.raises(BnmfError) as ei:
+        e.init()
+    assert ei.value.code == -3                                      # BNMF_EUNSET: hyper-prior arrays missing
+    with pytest.raises(BnmfError) as ei:
+        e.set("P", np.ones((5, 5)))
+    assert ei.value.code == -2                                      # BNMF_ESIZE
+    apply_hyperprior_params(e, "gamma", M, 3)
+    e.init()
+    with pytest.raises(BnmfError) as ei:
+        e.get("Z")
+    assert ei.value.code == -3                                      # Z not materialised (save_Z = 0)
+    with pytest.raises(BnmfError) as ei:
+        e.window("P", 3)
+    assert ei.value.code == -2                                      # only one sample recorded so far
+    with pytest.raises(BnmfError) as ei:
+        e.window("sigmasq", 1)
+    assert ei.value.code == -3                                      # not recorded for this model
+    e.run(2)
+    assert len(e.window("P", 3)) == 3
+    e.close()
