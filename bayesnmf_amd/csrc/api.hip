@@ -51,6 +51,8 @@ struct bnmf_handle {
   double *dProp = nullptr, *dPart = nullptr, *dAccPn = nullptr, *dAccEpart = nullptr; int* dNzE = nullptr; int mh_S = 1;
   size_t metrics_rows = 0;
   int maxM = 0, nblkE = 0;
+  int wcap = 0;                        // ring capacity = window + 1: the hyper sweep of iteration t+1 is issued (and, in the
+                                       // Gibbs sweep, recorded) during iteration t, one slot ahead of the oldest kept sample
   int z_grid = 0, z_zw = 8, z_ablate = 0; bool z_reg = false; size_t z_lds = 0; ZGeom zg{};
   hipEvent_t ev[2 * BNMF_NKERNEL]{};
   bool have_ev = false;
@@ -439,12 +441,19 @@ struct Timer {   // optional per-kernel HIP-event bracketing (serialises the two
   void begin(int k, hipStream_t st) { if (on) { hipStreamSynchronize(h->stream); hipStreamSynchronize(h->side); hipStreamSynchronize(h->side2); hipEventRecord(h->ev[2 * k], st); } }
   void end(int k, hipStream_t st) { if (on) { hipEventRecord(h->ev[2 * k + 1], st); hipEventSynchronize(h->ev[2 * k + 1]); float ms = 0; hipEventElapsedTime(&ms, h->ev[2 * k], h->ev[2 * k + 1]); acc[k] += ms; cnt[k]++; } }
 };
-static void launch_pdraw(bnmf_handle* h, uint32_t t, int from_prior) {
-  const size_t lds = 2 * (size_t)h->cfg.K * sizeof(double);
-  hipLaunchKernelGGL(k_pdraw, dim3(h->cfg.N), dim3(PD_T), lds, h->stream, h->dev, t, from_prior, 1);
+static RecDst rec_at(const bnmf_handle* h, uint32_t t, bool on);
+static bool fused_rec(const bnmf_handle* h);
+static RecDst rec_pdraw(const bnmf_handle* h, uint32_t t, bool on) {   // what k_pdraw records
+  RecDst r = rec_at(h, t, on);
+  if (h->cfg.learning_rank) { r.A = nullptr; r.R = nullptr; }          // then k_sumA records them, after the rank update
+  return r;
 }
-static void launch_edraw(bnmf_handle* h, uint32_t t, int from_prior) {
-  hipLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, from_prior, 1);
+static void launch_pdraw(bnmf_handle* h, uint32_t t, int from_prior, bool rec) {
+  const size_t lds = 2 * (size_t)h->cfg.K * sizeof(double);
+  hipLaunchKernelGGL(k_pdraw, dim3(h->cfg.N), dim3(PD_T), lds, h->stream, h->dev, t, from_prior, 1, rec_pdraw(h, t, rec));
+}
+static void launch_edraw(bnmf_handle* h, uint32_t t, int from_prior, bool rec) {
+  hipLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, from_prior, 1, rec_at(h, t, rec).E);
 }
 // k_side for iteration t (reads P_{t-1}, E_{t-1}): issued on the side stream right after the draws
 // of iteration t-1, so that it overlaps k_zalloc of iteration t-1
@@ -462,7 +471,7 @@ static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm) {
   hipEventRecord(h->ev_draw, h->stream);
   hipStreamWaitEvent(h->side, h->ev_draw, 0);
   tm.begin(KN_SIDE, h->side);
-  hipLaunchKernelGGL(k_side, dim3(h->cfg.N + nbP + nbE), dim3(RT), 0, h->side, h->dev, t, nbP, 0);
+  hipLaunchKernelGGL(k_side, dim3(h->cfg.N + nbP + nbE), dim3(RT), 0, h->side, h->dev, t, nbP, 0, rec_at(h, t, fused_rec(h)));
   tm.end(KN_SIDE, h->side);
   hipEventRecord(h->ev_side, h->side);
   hipEventRecord(h->ev_sideP, h->side);
@@ -481,19 +490,22 @@ static void launch_side_P(bnmf_handle* h, uint32_t t) {       // ev_p = completi
   hipStreamWaitEvent(h->side2, h->ev_p, 0);
   // k_lpp below rewrites lpPn slot (t-1) % 3, last read by k_reduce of iteration t-4 (side stream): order behind it
   if (h->red_issued) hipStreamWaitEvent(h->side2, h->ev_red, 0);
-  hipLaunchKernelGGL(k_side, dim3(nbP), dim3(RT), 0, h->side2, h->dev, t, nbP, h->cfg.N);
+  hipLaunchKernelGGL(k_side, dim3(nbP), dim3(RT), 0, h->side2, h->dev, t, nbP, h->cfg.N, rec_at(h, t, fused_rec(h)));
   hipLaunchKernelGGL(k_lpp, dim3(h->cfg.N), dim3(64), 0, h->side2, h->dev, t - 1);   // log-prior of the P just drawn
 }
 static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm) {   // ev_draw = completion of k_edraw(t-1)
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
   const int nbE = (int)(((size_t)h->cfg.N * h->cfg.G + RT - 1) / RT);
   hipStreamWaitEvent(h->side2, h->ev_draw, 0);
-  hipLaunchKernelGGL(k_side, dim3(h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, 0);
+  hipLaunchKernelGGL(k_side, dim3(h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{});
   // log-prior of the E just drawn (iteration t-1, whose slot pointers h->dev still holds): off the critical path
   hipLaunchKernelGGL(k_lpe, dim3(h->nblkE), dim3(ES_T), 0, h->side2, h->dev, t - 1);
   hipEventRecord(h->ev_sideP, h->side2);
   hipStreamWaitEvent(h->side, h->ev_draw, 0);
-  hipLaunchKernelGGL(k_side, dim3(nbE), dim3(RT), 0, h->side, h->dev, t, nbP, h->cfg.N + nbP);
+  hipLaunchKernelGGL(k_side, dim3(nbE), dim3(RT), 0, h->side, h->dev, t, nbP, h->cfg.N + nbP, rec_at(h, t, fused_rec(h)));
+  // ONE event for the main stream: ev_side fires when the E part (side) AND the P part / Esum / k_lpe (side2) are done.
+  // (A wait costs a barrier packet on the main stream, ~8 us even when the event has long fired.)
+  hipStreamWaitEvent(h->side, h->ev_sideP, 0);
   hipEventRecord(h->ev_side, h->side);
   h->side_valid = true;
   if (h->red_pending) { issue_reduce(h, h->red_t, h->red_row, tm); h->red_pending = false; }
@@ -558,15 +570,42 @@ static std::vector<int> recorded_ids(const bnmf_handle* h) {
   if (h->cfg.likelihood == BNMF_NORMAL) ids.push_back(BNMF_SIGMASQ);
   return ids;
 }
+static int ensure_rings(bnmf_handle* h) {
+  if (h->cfg.window <= 0) return 0;
+  h->wcap = h->cfg.window + 1;
+  for (int id : recorded_ids(h)) {
+    Arr& a = h->arr[id];
+    if (!a.ring) HIPCHK(hipMalloc(&a.ring, (size_t)h->wcap * id_len(h, id) * sizeof(double)));
+  }
+  return 0;
+}
+// the Gibbs sweep (Poisson, no MH) records inside its producers: k_pdraw (P, and A, R when the rank is fixed), k_edraw (E),
+// k_side (prior parameters), k_sumA (A, R when the rank is learned).  The MH / Normal sweeps copy with k_record.
+static bool fused_rec(const bnmf_handle* h) { return h->cfg.window > 0 && !h->cfg.MH && h->cfg.likelihood == BNMF_POISSON; }
+static double* ring_at(const bnmf_handle* h, int id, uint32_t t) {
+  const Arr& a = h->arr[id];
+  return a.ring ? a.ring + (size_t)((t - 1) % (uint32_t)h->wcap) * id_len(h, id) : nullptr;
+}
+static RecDst rec_at(const bnmf_handle* h, uint32_t t, bool on) {
+  RecDst r{};
+  if (!on || h->wcap <= 0) return r;
+  r.P = ring_at(h, BNMF_P, t); r.E = ring_at(h, BNMF_E, t); r.A = ring_at(h, BNMF_A, t); r.R = ring_at(h, BNMF_R, t);
+  static const int PP[3][4] = {{BNMF_MU_P, BNMF_SIGMASQ_P, BNMF_MU_E, BNMF_SIGMASQ_E},      // indexed by the prior enum
+                               {BNMF_LAMBDA_P, -1, BNMF_LAMBDA_E, -1},
+                               {BNMF_ALPHA_P, BNMF_BETA_P, BNMF_ALPHA_E, BNMF_BETA_E}};
+  const int* pp = PP[h->cfg.prior];
+  for (int i = 0; i < 4; ++i) r.pp[i] = pp[i] >= 0 ? ring_at(h, pp[i], t) : nullptr;
+  return r;
+}
 static int launch_record(bnmf_handle* h, uint32_t t) {
   const int W = h->cfg.window;
   if (W <= 0) return 0;
-  const size_t slot = (size_t)((t - 1) % (uint32_t)W);
+  const size_t slot = (size_t)((t - 1) % (uint32_t)h->wcap);
   RecArgs ra{}; ra.n = 0; ra.R = nullptr; ra.Rdst = nullptr;
   for (int id : recorded_ids(h)) {
     Arr& a = h->arr[id];
     const size_t len = id_len(h, id);
-    if (!a.ring) { HIPCHK(hipMalloc(&a.ring, (size_t)W * len * sizeof(double))); }
+    if (!a.ring) return fail(BNMF_ESTATE, "record: ring of id %d missing", id);
     if (id == BNMF_R) { ra.R = h->dR; ra.Rdst = a.ring + slot; continue; }
     if (!a.d) continue;
     ra.src[ra.n] = a.d + (is_prior_param(id) ? (size_t)(t & 1u) * len : 0);
@@ -580,7 +619,7 @@ static int launch_record(bnmf_handle* h, uint32_t t) {
 // k_reduce of iteration t: on the side stream, after the main stream has finished k_zalloc / metrics of t
 // metrics of iteration t: sum(A) now (main stream, right after the rank update); the canonical reductions later
 static void launch_reduce(bnmf_handle* h, uint32_t t, int row, Timer& tm) {
-  if (h->cfg.learning_rank) hipLaunchKernelGGL(k_sumA, dim3(1), dim3(64), 0, h->stream, h->dev, row, (const double*)accPn_slot(h, t));
+  if (h->cfg.learning_rank) hipLaunchKernelGGL(k_sumA, dim3(1), dim3(64), 0, h->stream, h->dev, row, (const double*)accPn_slot(h, t), rec_at(h, t, fused_rec(h)));
   h->red_pending = true; h->red_t = t; h->red_row = row;
 }
 // ... or at once (init, end of a run): the side stream waits for everything issued on the main stream so far
@@ -641,24 +680,22 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   h->iter += 1;
   const uint32_t t = (uint32_t)h->iter;
   use_slot(h, t);
+  const bool rec = fused_rec(h);
   if (!h->side_valid) launch_side(h, t, tm);               // first sweep after init / set_array
-  hipStreamWaitEvent(h->stream, h->ev_sideP, 0);           // P-side prior params + Esum of iteration t ready
+  hipStreamWaitEvent(h->stream, h->ev_side, 0);            // prior parameters + Esum of iteration t ready (the only wait)
   if (tm.on) {                                             // profile mode: one kernel at a time
-    tm.begin(KN_PDRAW, h->stream); launch_pdraw(h, t, 0); tm.end(KN_PDRAW, h->stream);
-    hipStreamWaitEvent(h->stream, h->ev_side, 0);
-    tm.begin(KN_EDRAW, h->stream); launch_edraw(h, t, 0); tm.end(KN_EDRAW, h->stream);
+    tm.begin(KN_PDRAW, h->stream); launch_pdraw(h, t, 0, rec); tm.end(KN_PDRAW, h->stream);
+    tm.begin(KN_EDRAW, h->stream); launch_edraw(h, t, 0, rec); tm.end(KN_EDRAW, h->stream);
     launch_side(h, t + 1, tm);
   } else {
     // completion events ride on the dispatches themselves (stop events): no marker packets on the main stream
     hipExtLaunchKernelGGL(k_pdraw, dim3(h->cfg.N), dim3(PD_T), (uint32_t)(2 * (size_t)h->cfg.K * sizeof(double)), h->stream,
-                          nullptr, h->ev_p, 0, h->dev, t, 0, 0);
+                          nullptr, h->ev_p, 0, h->dev, t, 0, 0, rec_pdraw(h, t, rec));
     launch_side_P(h, t + 1);
-    hipStreamWaitEvent(h->stream, h->ev_side, 0);          // E-side prior params of iteration t ready
-    hipExtLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, 0, 0);
+    hipExtLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, 0, 0, rec_at(h, t, rec).E);
     launch_side_E(h, t + 1, tm);                           // overlaps the rank update / k_zalloc below
   }
   if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
-  tm.begin(KN_OTHER, h->stream); if (int rc = launch_record(h, t)) return rc; tm.end(KN_OTHER, h->stream);
   tm.begin(KN_ZALLOC, h->stream); if (int rc = launch_zalloc(h, t)) return rc; tm.end(KN_ZALLOC, h->stream);
   launch_reduce(h, t, row, tm);
   return 0;
@@ -732,8 +769,9 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
   h->iter = 1;
   Timer tm{h, false};
   use_slot(h, 1u);
-  launch_pdraw(h, 1u, haveP ? 2 : 1);                       // skip = names(init_params): supplied P / E kept verbatim
-  launch_edraw(h, 1u, haveE ? 2 : 1);
+  if (int rc = ensure_rings(h)) return rc;
+  launch_pdraw(h, 1u, haveP ? 2 : 1, false);                // skip = names(init_params): supplied P / E kept verbatim
+  launch_edraw(h, 1u, haveE ? 2 : 1, false);                // (iteration 1 is recorded by k_record below, every model)
   launch_side(h, 2u, tm);
   if (!haveA && c.learning_rank) {                            // R ~ Uniform{0..N}, A[n] ~ Bernoulli(pi(R))
     hipLaunchKernelGGL(k_rank_R, dim3(1), dim3(64), 0, h->stream, h->dev, 1u, 1);
@@ -801,9 +839,9 @@ int bnmf_window(bnmf_handle* h, int id, int last_n, double* out) {
   if (!a.ring || len == 0) return fail(BNMF_EUNSET, "bnmf_window: id %d is not recorded for this model", id);
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
-  // sample `it` lives in slot (it-1) % W: the last_n samples, oldest first, are at most two contiguous runs of the ring
-  const size_t s0 = (size_t)((h->iter - last_n) % W);
-  const size_t n1 = (s0 + (size_t)last_n <= (size_t)W) ? (size_t)last_n : (size_t)W - s0;
+  // sample `it` lives in slot (it-1) % (W+1): the last_n samples, oldest first, are at most two contiguous runs of the ring
+  const size_t C = (size_t)h->wcap, s0 = (size_t)(h->iter - last_n) % C;
+  const size_t n1 = (s0 + (size_t)last_n <= C) ? (size_t)last_n : C - s0;
   HIPCHK(hipMemcpy(out, a.ring + s0 * len, n1 * len * sizeof(double), hipMemcpyDeviceToHost));
   if (n1 < (size_t)last_n) HIPCHK(hipMemcpy(out + n1 * len, a.ring, ((size_t)last_n - n1) * len * sizeof(double), hipMemcpyDeviceToHost));
   return 0;

@@ -39,6 +39,10 @@ struct Dev {
   double* raw;                       // device rows [row][8]: sse, ll, kl, lpE, lpP, sumA (k_reduce -> k_compose)
   size_t lenP, lenE;                 // K*N, N*G: the prior-parameter arrays hold 2 slots, slot(t) = t & 1
 };
+// record_sample fused into the producers (R/bayesNMF_sampler.R:651-672): the ring slot of the iteration whose values a
+// kernel writes, one pointer per recorded array (null = not recorded / window 0).  pp[0..1]: P-side prior parameters in
+// the order (Alpha|Mu|Lambda, Beta|Sigmasq), pp[2..3]: E-side.
+struct RecDst { double *P, *E, *A, *R; double* pp[4]; };
 // prior parameters of iteration t live in slot t&1, so the hyper sweep of iteration t+1 can run
 // (on the side stream) while iteration t's values are still being read
 template <int SIDE> BNMF_DEV double* slot(const Dev& d, double* base, uint32_t t) { return base + (size_t)(t & 1u) * (SIDE ? d.lenE : d.lenP); }
@@ -47,7 +51,7 @@ BNMF_DEV double clamp_tiny(double v) { return (v < 1e-300) ? 1e-300 : v; }
 
 // ---- hyper sweep of one element: R/sample_priors.R:150-200 (element-wise conditionals) ----
 template <int SIDE>
-BNMF_DEV void hyper_elem(const Dev& d, int e, uint32_t t, double v) {
+BNMF_DEV void hyper_elem(const Dev& d, int e, uint32_t t, double v, double* rec0 = nullptr, double* rec1 = nullptr) {
   if (d.prior == BNMF_GAMMA) {
     const HRef &hA = SIDE ? d.hA_e : d.hA_p, &hB = SIDE ? d.hB_e : d.hB_p;
     const HRef &hC = SIDE ? d.hC_e : d.hC_p, &hD = SIDE ? d.hD_e : d.hD_p;
@@ -57,14 +61,19 @@ BNMF_DEV void hyper_elem(const Dev& d, int e, uint32_t t, double v) {
     const double al_old = slot<SIDE>(d, Al, t - 1)[e];
     const double b = rgamma(s, hy(hA, e) + al_old, hy(hB, e) + v);        // sample_Beta_*  :323-345
     slot<SIDE>(d, Be, t)[e] = b;
+    if (rec1) rec1[e] = b;
     const double tau = (hy(hD, e) - dlog(clamp_tiny(b))) - dlog(clamp_tiny(v));
     Stream s2(d.k0, d.k1, SIDE ? BNMF_V_ALPHA_E : BNMF_V_ALPHA_P, (uint32_t)e, t);
-    slot<SIDE>(d, Al, t)[e] = ralpha(s2, hy(hC, e), tau, al_old);           // sample_Alpha_* :356-397
+    const double al = ralpha(s2, hy(hC, e), tau, al_old);                   // sample_Alpha_* :356-397
+    slot<SIDE>(d, Al, t)[e] = al;
+    if (rec0) rec0[e] = al;
   } else if (d.prior == BNMF_EXPONENTIAL) {
     const HRef &hA = SIDE ? d.hA_e : d.hA_p, &hB = SIDE ? d.hB_e : d.hB_p;
     double* La = SIDE ? d.Lam_e : d.Lam_p;
     Stream s(d.k0, d.k1, SIDE ? BNMF_V_LAMBDA_E : BNMF_V_LAMBDA_P, (uint32_t)e, t);
-    slot<SIDE>(d, La, t)[e] = rgamma(s, hy(hA, e) + 1.0, hy(hB, e) + v);    // sample_Lambda_* :284-308
+    const double la = rgamma(s, hy(hA, e) + 1.0, hy(hB, e) + v);            // sample_Lambda_* :284-308
+    slot<SIDE>(d, La, t)[e] = la;
+    if (rec0) rec0[e] = la;
   } else {
     const HRef &hM = SIDE ? d.hM_e : d.hM_p, &hS = SIDE ? d.hS_e : d.hS_p;
     const HRef &hA = SIDE ? d.hA_e : d.hA_p, &hB = SIDE ? d.hB_e : d.hB_p;
@@ -76,10 +85,13 @@ BNMF_DEV void hyper_elem(const Dev& d, int e, uint32_t t, double v) {
     Stream s(d.k0, d.k1, SIDE ? BNMF_V_MU_E : BNMF_V_MU_P, (uint32_t)e, t);
     const double mu = num / den + (1.0 / den) * rnorm_std(s);               // sd = 1/denom (quirk) :214-236
     slot<SIDE>(d, Mu, t)[e] = mu;
+    if (rec0) rec0[e] = mu;
     const double dl = v - mu;
     const double rate = (SIDE ? hy(hA, e) : hy(hB, e)) + (dl * dl) / 2.0;   // A_e for B_e (quirk) :263-270
     Stream s2(d.k0, d.k1, SIDE ? BNMF_V_SIGSQ_E : BNMF_V_SIGSQ_P, (uint32_t)e, t);
-    slot<SIDE>(d, Sg, t)[e] = rinvgamma(s2, hy(hA, e) + 0.5, rate);
+    const double sgn = rinvgamma(s2, hy(hA, e) + 0.5, rate);
+    slot<SIDE>(d, Sg, t)[e] = sgn;
+    if (rec1) rec1[e] = sgn;
   }
 }
 // prior draw of an element of P / E: R/sample_Pn.R:12-30, R/sample_En.R:12-30
@@ -127,7 +139,7 @@ BNMF_DEV double canon1024_by256(const double* x, long L, long stride, double* bu
 //   blocks [0, N)            : Esum[n] = canonical sum_g E[n,g]   (rate of P's Gamma, R/sample_Pn.R:103-106)
 //   blocks [N, N+nbP)        : hyper sweep of the P-side prior parameters (R/sample_priors.R:150-200)
 //   blocks [N+nbP, ...)      : hyper sweep of the E-side prior parameters
-__global__ __launch_bounds__(RT, 4) void k_side(Dev d, uint32_t t, int nbP, int blk0) {
+__global__ __launch_bounds__(RT, 4) void k_side(Dev d, uint32_t t, int nbP, int blk0, RecDst rec) {
   __shared__ double buf[RT];
   const int tid = threadIdx.x, blk = blockIdx.x + blk0;   // one launch (blk0 = 0) or one launch per part
   // The small launches (P part, Esum: a few dozen workgroups) share the CUs with k_zalloc, whose older waves win the
@@ -139,10 +151,10 @@ __global__ __launch_bounds__(RT, 4) void k_side(Dev d, uint32_t t, int nbP, int 
     if (tid == 0) d.Esum[blk] = r;
   } else if (blk < d.N + nbP) {
     const long e = (long)(blk - d.N) * RT + tid;
-    if (e < (long)d.lenP) hyper_elem<0>(d, (int)e, t, d.P[e]);
+    if (e < (long)d.lenP) hyper_elem<0>(d, (int)e, t, d.P[e], rec.pp[0], rec.pp[1]);
   } else {
     const long e = (long)(blk - d.N - nbP) * RT + tid;
-    if (e < (long)d.lenE) hyper_elem<1>(d, (int)e, t, d.E[e]);
+    if (e < (long)d.lenE) hyper_elem<1>(d, (int)e, t, d.E[e], rec.pp[2], rec.pp[3]);
   }
 }
 
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(RT, 4) void k_side(Dev d, uint32_t t, int nbP, int 
 // sample_Pn_poisson R/sample_Pn.R:98-120 (dispatch :11-42); Psum[n] and the log-prior of column n
 // are reduced canonically (W = 64) over k.
 constexpr int PD_T = 128;
-__global__ __launch_bounds__(PD_T) void k_pdraw(Dev d, uint32_t t, int from_prior, int with_lp) {
+__global__ __launch_bounds__(PD_T) void k_pdraw(Dev d, uint32_t t, int from_prior, int with_lp, RecDst rec) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
   double* Pn = (double*)dyn;          // [K]
   double* lp = Pn + d.K;              // [K]
@@ -171,10 +183,13 @@ __global__ __launch_bounds__(PD_T) void k_pdraw(Dev d, uint32_t t, int from_prio
       x = rgamma(s, shape, rate);
     }
     d.P[e] = x;
+    if (rec.P) rec.P[e] = x;
     d.ZsumG[e] = 0;                    // consumed; k_zalloc accumulates the next one
     Pn[k] = x;
     if (with_lp) lp[k] = prior_logdens<0>(d, e, x, t);
   }
+  if (rec.A && tid == 0) rec.A[n] = a_n;                  // fixed rank: A and R never change after the constructor
+  if (rec.R && tid == 0 && n == 0) *rec.R = (double)*d.R;
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;
   if (wave && !with_lp) return;                           // the log-prior is then computed off the critical path (k_lpp)
@@ -188,7 +203,7 @@ __global__ __launch_bounds__(PD_T) void k_pdraw(Dev d, uint32_t t, int from_prio
 // ---- k_edraw: one lane per element (n,g) of E, flat column-major index e = n + N g ----
 // sample_En_poisson R/sample_En.R:97-119; log-prior partial per 256-element block (canonical tree)
 constexpr int ES_T = 256;
-__global__ __launch_bounds__(ES_T) void k_edraw(Dev d, uint32_t t, int from_prior, int with_lp) {
+__global__ __launch_bounds__(ES_T) void k_edraw(Dev d, uint32_t t, int from_prior, int with_lp, double* recE) {
   __shared__ double buf[ES_T];
   const int tid = threadIdx.x;
   const long e = (long)blockIdx.x * ES_T + tid;
@@ -207,6 +222,7 @@ __global__ __launch_bounds__(ES_T) void k_edraw(Dev d, uint32_t t, int from_prio
       x = rgamma(s, shape, rate);
     }
     d.E[e] = x;
+    if (recE) recE[e] = x;
     if (with_lp) lp = prior_logdens<1>(d, (int)e, x, t);
   }
   if (!with_lp) return;                                 // the log-prior is then computed off the critical path (k_lpe)
@@ -493,8 +509,10 @@ __global__ __launch_bounds__(RT) void k_reduce(Dev d, int row, int nblkE, const 
   }
 }
 // sum(A) (and the A-masked acceptance sum) of the iteration, on the main stream right after the rank update
-__global__ void k_sumA(Dev d, int row, const double* accPn) {
+__global__ void k_sumA(Dev d, int row, const double* accPn, RecDst rec) {
+  if (rec.A) for (int n = threadIdx.x; n < d.N; n += blockDim.x) rec.A[n] = d.A[n];
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (rec.R) *rec.R = (double)*d.R;
   double* o = d.raw + (size_t)row * 8;
   double sumA = 0.0;
   for (int n = 0; n < d.N; ++n) sumA = sumA + d.A[n];
