@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <map>
 #include <string>
 #include <vector>
 #include "kernels.h"
@@ -56,6 +58,7 @@ struct bnmf_handle {
   int z_grid = 0, z_zw = 8, z_ablate = 0; bool z_reg = false; size_t z_lds = 0; ZGeom zg{};
   hipEvent_t ev[2 * BNMF_NKERNEL]{};
   bool have_ev = false;
+  double* dMap = nullptr; size_t map_words = 0;   // scratch of bnmf_map (grown on demand)
 };
 
 static size_t id_len(const bnmf_handle* h, int id) {
@@ -316,6 +319,7 @@ int bnmf_destroy(bnmf_handle* h) {
   if (h->dProp) { hipFree(h->dProp); hipFree(h->dPart); hipFree(h->dAccPn); hipFree(h->dAccEpart); hipFree(h->dNzE); hipFree(h->dEt); hipFree(h->dMt); }
   if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); if (h->side) hipStreamDestroy(h->side); if (h->side2) hipStreamDestroy(h->side2);
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
+  if (h->dMap) hipFree(h->dMap);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -844,6 +848,103 @@ int bnmf_window(bnmf_handle* h, int id, int last_n, double* out) {
   const size_t n1 = (s0 + (size_t)last_n <= C) ? (size_t)last_n : C - s0;
   HIPCHK(hipMemcpy(out, a.ring + s0 * len, n1 * len * sizeof(double), hipMemcpyDeviceToHost));
   if (n1 < (size_t)last_n) HIPCHK(hipMemcpy(out + n1 * len, a.ring, ((size_t)last_n - n1) * len * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+
+// copy `n` consecutive samples (oldest first) of a ring to the host: at most two contiguous runs
+static int ring_read(const bnmf_handle* h, int id, int last_n, double* out) {
+  const Arr& a = h->arr[id];
+  const size_t len = id_len(h, id), C = (size_t)h->wcap, s0 = (size_t)(h->iter - last_n) % C;
+  const size_t n1 = (s0 + (size_t)last_n <= C) ? (size_t)last_n : C - s0;
+  HIPCHK(hipMemcpy(out, a.ring + s0 * len, n1 * len * sizeof(double), hipMemcpyDeviceToHost));
+  if (n1 < (size_t)last_n) HIPCHK(hipMemcpy(out + n1 * len, a.ring, ((size_t)last_n - n1) * len * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int bnmf_map(bnmf_handle* h, int last_n, double ci, double* P_mean, double* E_mean, double* A_mode, double* top_A,
+             double* P_lower, double* P_upper, double* E_lower, double* E_upper, int32_t* used, bnmf_map_info* info) {
+  if (!h || !P_mean || !E_mean || !A_mode || !info) return fail(BNMF_EINVAL, "bnmf_map: null argument");
+  const int W = h->cfg.window;
+  if (W <= 0) return fail(BNMF_ESTATE, "bnmf_map: the handle was created with window = 0");
+  if (last_n < 1 || last_n > W || last_n > h->iter) return fail(BNMF_ESIZE, "bnmf_map: last_n = %d but only min(window = %d, iter = %d) samples are kept", last_n, W, h->iter);
+  if (ci >= 1.0) return fail(BNMF_EINVAL, "bnmf_map: credible_interval must be below 1");
+  const int K = h->cfg.K, N = h->cfg.N, G = h->cfg.G;
+  const size_t lenP = (size_t)K * N, lenE = (size_t)N * G;
+  if (!h->arr[BNMF_P].ring || !h->arr[BNMF_E].ring || !h->arr[BNMF_A].ring) return fail(BNMF_ESTATE, "bnmf_map: nothing recorded yet");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->side));
+  HIPCHK(hipStreamSynchronize(h->side2));
+  // i. mode of A (get_mode): patterns as strings, most frequent first, ties in alphabetical order
+  std::vector<double> Aw((size_t)last_n * N);
+  if (int rc = ring_read(h, BNMF_A, last_n, Aw.data())) return rc;
+  std::vector<std::string> keys(last_n, std::string(N, '0'));
+  std::map<std::string, int> tab;
+  for (int s = 0; s < last_n; ++s) { for (int n = 0; n < N; ++n) if (Aw[(size_t)s * N + n] != 0.0) keys[s][n] = '1'; tab[keys[s]]++; }
+  std::vector<std::pair<std::string, int>> ord(tab.begin(), tab.end());        // std::map iterates alphabetically
+  std::stable_sort(ord.begin(), ord.end(), [](const auto& a, const auto& b) { return a.second > b.second; });
+  const std::string& mode = ord[0].first;
+  info->n_patterns = (int)ord.size();
+  for (int i = 0; i < 5; ++i) {
+    info->top_counts[i] = i < (int)ord.size() ? ord[i].second : 0;
+    if (top_A) for (int n = 0; n < N; ++n) top_A[(size_t)i * N + n] = i < (int)ord.size() ? (ord[i].first[n] == '1' ? 1.0 : 0.0) : std::nan("");
+  }
+  std::vector<int> slots;
+  for (int s = 0; s < last_n; ++s) {
+    const bool u = keys[s] == mode;
+    if (used) used[s] = u ? 1 : 0;
+    if (u) slots.push_back((int)((size_t)(h->iter - last_n + s) % (size_t)h->wcap));
+  }
+  const int nu = (int)slots.size();
+  info->n_used = nu; info->_pad = 0;
+  std::vector<double> Am(N);
+  for (int n = 0; n < N; ++n) Am[n] = A_mode[n] = mode[n] == '1' ? 1.0 : 0.0;
+  // ii-iii. renormalised means (and quantiles) on the device
+  const bool want_ci = ci > 0.0 && (P_lower || P_upper || E_lower || E_upper);
+  int kt = 0, jlo = 0, jhi = 0; double glo = 0.0, ghi = 0.0;
+  if (want_ci) {                                    // quantile type 7: h = (n-1) p, j = floor(h), g = h - j
+    const double plo = 0.5 - ci / 2.0, phi = 0.5 + ci / 2.0;
+    const double hl = (nu - 1) * plo, hh = (nu - 1) * phi;
+    jlo = (int)std::floor(hl); glo = hl - jlo; jhi = (int)std::floor(hh); ghi = hh - jhi;
+    kt = std::min(nu, std::max(jlo + 2, nu - jhi));
+    if ((size_t)kt * 2 * 64 * sizeof(double) > 160 * 1024)
+      return fail(BNMF_EINVAL, "bnmf_map: credible_interval %.3g over %d samples needs %d order statistics per element (device limit 160): take the window with bnmf_window", ci, nu, kt);
+  }
+  const size_t words = (size_t)nu * N + 3 * (lenP + lenE) + 2 * (size_t)G + N + ((size_t)nu + 1) / 2 + 8;
+  if (words > h->map_words) { if (h->dMap) HIPCHK(hipFree(h->dMap)); h->dMap = nullptr; HIPCHK(hipMalloc(&h->dMap, words * sizeof(double))); h->map_words = words; }
+  double* cs = h->dMap; double* mP = cs + (size_t)nu * N; double* loP = mP + lenP; double* hiP = loP + lenP;
+  double* mE = hiP + lenP; double* loE = mE + lenE; double* hiE = loE + lenE;
+  double* colsse = hiE + lenE; double* colkl = colsse + G; double* dA = colkl + G; int* dslots = (int*)(dA + N);
+  HIPCHK(hipMemcpyAsync(dslots, slots.data(), nu * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dA, Am.data(), N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_map_colsum, dim3(nu, N), dim3(64), 0, h->stream, (const double*)h->arr[BNMF_P].ring, lenP, K, N, (const int*)dslots, cs);
+  const size_t lds = (size_t)kt * 2 * 64 * sizeof(double);
+  if (lds > 64 * 1024) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_map_stats<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)k_map_stats<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  }
+  hipLaunchKernelGGL(k_map_stats<0>, dim3((unsigned)((lenP + 63) / 64)), dim3(64), lds, h->stream, (const double*)h->arr[BNMF_P].ring, lenP, K, N,
+                     (const int*)dslots, nu, (const double*)cs, kt, jlo, glo, jhi, ghi, mP, loP, hiP);
+  hipLaunchKernelGGL(k_map_stats<1>, dim3((unsigned)((lenE + 63) / 64)), dim3(64), lds, h->stream, (const double*)h->arr[BNMF_E].ring, lenE, K, N,
+                     (const int*)dslots, nu, (const double*)cs, kt, jlo, glo, jhi, ghi, mE, loE, hiE);
+  hipLaunchKernelGGL(k_map_fit, dim3((G + 3) / 4), dim3(256), 0, h->stream, (const int32_t*)h->dM, (const double*)mP, (const double*)dA, (const double*)mE, K, N, G, colsse, colkl);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(P_mean, mP, lenP * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(E_mean, mE, lenE * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (want_ci) {
+    if (P_lower) HIPCHK(hipMemcpyAsync(P_lower, loP, lenP * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (P_upper) HIPCHK(hipMemcpyAsync(P_upper, hiP, lenP * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (E_lower) HIPCHK(hipMemcpyAsync(E_lower, loE, lenE * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (E_upper) HIPCHK(hipMemcpyAsync(E_upper, hiE, lenE * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  std::vector<double> col(2 * (size_t)G);
+  HIPCHK(hipMemcpyAsync(col.data(), colsse, 2 * (size_t)G * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  double sse = 0.0, kl = 0.0;
+  for (int g = 0; g < G; ++g) { sse += col[g]; kl += col[(size_t)G + g]; }
+  info->rmse = std::sqrt(sse / ((double)K * (double)G));
+  info->kl = kl;
   return 0;
 }
 

@@ -558,6 +558,110 @@ __global__ void k_record(RecArgs a) {
   if (tid == 0 && a.Rdst) *a.Rdst = (double)*a.R;
 }
 
+
+// ---- MAP window statistics on the device: get_MAP_ (R/utils.R:194-288) ----
+// colSums(P) of every used sample (renormalize, R/helpers.R:35-49): one wave per (sample, factor)
+__global__ __launch_bounds__(64) void k_map_colsum(const double* ringP, size_t lenP, int K, int N, const int* slots, double* cs) {
+  const int s = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+  const double* Pn = ringP + (size_t)slots[s] * lenP + (size_t)K * n;
+  double acc = 0.0;
+  for (int k = lane; k < K; k += 64) acc = acc + Pn[k];
+  acc = wave_tree64(acc);
+  if (lane == 0) cs[(size_t)s * N + n] = acc;
+}
+// One lane per element of P (SIDE 0: x = P / colsum) or E (SIDE 1: x = E * colsum): mean over the used samples in
+// sample order, and the two type-7 quantiles (stats::quantile default) from the kt smallest / kt largest values.
+// The lane keeps both sets UNSORTED in LDS (arrays [kt][64], lane-private columns: conflict-free) with the current
+// worst member (value, position) in registers: a value that enters replaces the worst one and the set is re-scanned
+// with independent loads (a sorted insertion is a chain of dependent LDS round trips, and some lane of the wave
+// inserts at nearly every sample).  The two small sets are sorted once at the end.  kt = 0: mean only.
+BNMF_DEV void lane_sort(double* a, int n) {           // insertion sort of a[0], a[64], ... (n <= 160)
+  for (int i = 1; i < n; ++i) {
+    const double x = a[i * 64];
+    int j = i - 1;
+    while (j >= 0 && a[j * 64] > x) { a[(j + 1) * 64] = a[j * 64]; --j; }
+    a[(j + 1) * 64] = x;
+  }
+}
+template <int SIDE>
+__global__ __launch_bounds__(64) void k_map_stats(const double* ring, size_t len, int K, int N, const int* slots, int n_used,
+                                                  const double* cs, int kt, int jlo, double glo, int jhi, double ghi,
+                                                  double* mean, double* lower, double* upper) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const size_t e = (size_t)blockIdx.x * 64 + tid;
+  if (e >= len) return;
+  const int n = SIDE ? (int)(e % (size_t)N) : (int)(e / (size_t)K);
+  double* lo = (double*)smem + tid;                     // lo[i * 64]: the kt smallest so far
+  double* hi = (double*)smem + (size_t)kt * 64 + tid;   // hi[i * 64]: the kt largest so far
+  int cnt = 0, lop = 0, hip = 0;
+  double lov = 0.0, hiv = 0.0;                          // largest of the small set / smallest of the large set
+  double sum = 0.0;
+  for (int s0 = 0; s0 < n_used; s0 += 8) {
+    double v[8], c[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                       // 8 independent loads in flight per lane
+      const int s = min(s0 + j, n_used - 1);
+      v[j] = ring[(size_t)slots[s] * len + e];
+      c[j] = cs[(size_t)s * N + n];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (s0 + j >= n_used) break;
+      const double x = SIDE ? v[j] * c[j] : v[j] / c[j];
+      sum = sum + x;
+      if (kt == 0) continue;
+      if (cnt < kt) {                                   // filling: both sets hold everything seen so far
+        lo[cnt * 64] = x; hi[cnt * 64] = x;
+        if (cnt == 0 || x > lov) { lov = x; lop = cnt; }
+        if (cnt == 0 || x < hiv) { hiv = x; hip = cnt; }
+        ++cnt;
+      } else {
+        if (x < lov) {
+          lo[lop * 64] = x;
+          double m = lo[0]; int p = 0;
+          for (int i = 1; i < kt; ++i) { const double w = lo[i * 64]; if (w > m) { m = w; p = i; } }
+          lov = m; lop = p;
+        }
+        if (x > hiv) {
+          hi[hip * 64] = x;
+          double m = hi[0]; int p = 0;
+          for (int i = 1; i < kt; ++i) { const double w = hi[i * 64]; if (w < m) { m = w; p = i; } }
+          hiv = m; hip = p;
+        }
+      }
+    }
+  }
+  mean[e] = sum / (double)n_used;
+  if (kt) {
+    lane_sort(lo, cnt); lane_sort(hi, cnt);
+    const int base = n_used - cnt;                      // hi[i] is order statistic base + i
+    const int jl1 = min(jlo + 1, n_used - 1), jh1 = min(jhi + 1, n_used - 1);
+    lower[e] = (1.0 - glo) * lo[jlo * 64] + glo * lo[jl1 * 64];
+    upper[e] = (1.0 - ghi) * hi[(jhi - base) * 64] + ghi * hi[(jh1 - base) * 64];
+  }
+}
+// compute_metrics_(P = MAP$P, A = MAP$A, E = MAP$E, MAP = TRUE) (R/utils.R:412-455): per-column squared error and
+// padded KL of Mhat = P diag(A) E; one wave per column
+__global__ __launch_bounds__(256) void k_map_fit(const int32_t* M, const double* P, const double* A, const double* E, int K, int N, int G,
+                                                  double* colsse, double* colkl) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = blockIdx.x * 4 + wave;
+  if (g >= G) return;
+  double sse = 0.0, kl = 0.0;
+  for (int k = lane; k < K; k += 64) {
+    double c = 0.0;
+    for (int n = 0; n < N; ++n) c = c + (P[k + (size_t)K * n] * A[n]) * E[n + (size_t)N * g];
+    const double m = (double)M[k + (size_t)K * g];
+    const double d = c - m;
+    sse = sse + d * d;
+    const double mt = m < 1e-6 ? 1e-6 : m, mh = c < 1e-6 ? 1e-6 : c;
+    kl = kl + mt * dlog(mt / mh);
+  }
+  sse = wave_tree64(sse); kl = wave_tree64(kl);
+  if (lane == 0) { colsse[g] = sse; colkl[g] = kl; }
+}
+
 // ---- constructor draws of the prior parameters from the hyper-priors ----
 // init_prior_params_ R/sample_priors.R:15-141 (all three families are rgamma(shape, rate) draws
 // for the Gamma / Exponential priors).  redraw[n] != 0: column n (P side) / row n (E side) missing.

@@ -45,8 +45,13 @@ class BnmfConfig(C.Structure):
 
 
 # every symbol include/bnmf.h declares (checked by tests/test_abi.py)
+class BnmfMapInfo(C.Structure):
+    _fields_ = [("n_used", C.c_int32), ("n_patterns", C.c_int32), ("top_counts", C.c_int32 * 5), ("_pad", C.c_int32),
+                ("rmse", C.c_double), ("kl", C.c_double)]
+
+
 ABI_SYMBOLS = ["bnmf_create", "bnmf_destroy", "bnmf_set_array", "bnmf_get_array", "bnmf_get_array_i32",
-               "bnmf_init", "bnmf_run", "bnmf_window", "bnmf_get_iter", "bnmf_profile",
+               "bnmf_init", "bnmf_run", "bnmf_window", "bnmf_map", "bnmf_get_iter", "bnmf_profile",
                "bnmf_kernel_name", "bnmf_test_math", "bnmf_test_sampler", "bnmf_test_philox",
                "bnmf_device_info", "bnmf_device_count", "bnmf_last_error", "bnmf_version"]
 
@@ -67,6 +72,7 @@ def lib():
         L.bnmf_init.argtypes = [C.c_void_p, dp]
         L.bnmf_run.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
         L.bnmf_window.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
+        L.bnmf_map.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, dp, dp, dp, dp, dp, dp, dp, ip, C.POINTER(BnmfMapInfo)]
         L.bnmf_get_iter.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.bnmf_profile.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
         L.bnmf_kernel_name.restype = C.c_char_p
@@ -216,6 +222,24 @@ class Engine:
         out = np.empty((last_n, int(np.prod(shp))))
         _chk(lib().bnmf_window(self._h, IDS[name], last_n, _dp(out)))
         return [out[i].reshape(shp, order="F") for i in range(last_n)]
+
+    def map(self, last_n, credible_interval=0.95):
+        """get_MAP_ over the last `last_n` recorded samples, on the device (one C-ABI call)."""
+        K, G, N = self.K, self.G, self.N
+        Pm, Em, Am, top = np.empty(K * N), np.empty(N * G), np.empty(N), np.empty(5 * N)
+        ci = credible_interval is not None and credible_interval > 0
+        Pl, Pu, El, Eu = (np.empty(K * N), np.empty(K * N), np.empty(N * G), np.empty(N * G)) if ci else (None,) * 4
+        used = np.empty(last_n, dtype=np.int32)
+        info = BnmfMapInfo()
+        _chk(lib().bnmf_map(self._h, last_n, float(credible_interval) if ci else 0.0, _dp(Pm), _dp(Em), _dp(Am), _dp(top),
+                            *[_dp(a) if a is not None else None for a in (Pl, Pu, El, Eu)],
+                            used.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(info)))
+        f = lambda a, shp: None if a is None else a.reshape(shp, order="F")   # noqa: E731
+        npat = min(info.n_patterns, 5)
+        return dict(P=f(Pm, (K, N)), E=f(Em, (N, G)), A=Am.reshape(1, N), used=used.astype(bool),
+                    P_lower=f(Pl, (K, N)), P_upper=f(Pu, (K, N)), E_lower=f(El, (N, G)), E_upper=f(Eu, (N, G)),
+                    top_A=top.reshape(5, N)[:npat], top_counts=[int(c) for c in info.top_counts][:npat],
+                    n_used=info.n_used, n_patterns=info.n_patterns, rmse=info.rmse, kl=info.kl)
 
     @property
     def iter(self):

@@ -51,7 +51,8 @@ def renormalize(P, E):
 def get_mode(matrix_list):
     """get_mode (R/helpers.R:63-79): most frequent matrix by its pasted string."""
     keys = ["".join(str(int(v)) if float(v).is_integer() else str(v) for v in np.ravel(m, order="F")) for m in matrix_list]
-    counts = Counter(keys).most_common()
+    # sort(table(.), decreasing = TRUE): table() orders the patterns alphabetically and the sort is stable
+    counts = sorted(Counter(keys).items(), key=lambda kv: (-kv[1], kv[0]))
     mode = counts[0][0]
     idx = [i for i, k in enumerate(keys) if k == mode]
     return dict(matrix=matrix_list[idx[0]], top_counts=counts[:5], idx=idx)
@@ -64,7 +65,7 @@ class bayesNMF_sampler:
                  MH=None, convergence_control=None, prop_temp=0.2, post_warmup=None,
                  output_dir=None, overwrite=False, hyperprior_params=None, init_prior_params=None,
                  init_params=None, verbosity=1, periodic_save=True, save_all_samples=False,
-                 seed=1, chain_id=0, device=0, save_Z=False, engine_factory=None):
+                 seed=1, chain_id=0, device=0, save_Z=False, engine_factory=None, intermediate_credible_intervals=False):
         if MH is None:
             MH = likelihood == "poisson" and prior in ("truncnormal", "exponential")
         cc = dict(convergence_control) if convergence_control is not None else new_convergence_control()
@@ -97,7 +98,8 @@ class bayesNMF_sampler:
         self.dims = dict(K=data.shape[0], N=int(rank.max()), G=data.shape[1])
         self.specs = dict(rank=rank, likelihood=likelihood, prior=prior, MH=bool(MH), learning_rank=learning_rank,
                           convergence_control=cc, output_dir=final_dir, overwrite=overwrite, verbosity=verbosity,
-                          periodic_save=periodic_save, save_all_samples=save_all_samples)
+                          periodic_save=periodic_save, save_all_samples=save_all_samples,
+                          intermediate_credible_intervals=intermediate_credible_intervals)
         if learning_rank:
             self.specs["prop_temp"] = prop_temp
             self.specs["rank_method"] = rank_method
@@ -109,6 +111,7 @@ class bayesNMF_sampler:
         self.reference_comparison = dict(reference_P=None, assignments=None, keep_sigs=None, idxs=None, votes=None,
                                          summary=None, plots={}, label_switching_df=None)
         self.time = {}
+        self._block_hook = None          # multi-chain launcher: called after every block (multichain.ChainSync.block)
         self.acceptance_rates = dict(P_acceptance_rate=None, E_acceptance_rate=None)
         self.log_con = open(os.path.join(final_dir, "log.txt"), "w")
         self.log("Initialized sampler", verbosity=1)
@@ -227,6 +230,25 @@ class bayesNMF_sampler:
         """get_MAP_ (R/utils.R:194-288) over the window state$MAP_idx of recorded samples."""
         cc = self.specs["convergence_control"]
         n = min(cc["MAP_over"], self.state["iter"])
+        first_iter = self.state["iter"] - n + 1
+        if hasattr(self._chain, "map"):
+            # on-device window statistics: one C-ABI call returns K*N + N*G means (+ credible bounds), no window copy
+            try:
+                r = self._chain.map(n, credible_interval)
+            except Exception as ex:     # e.g. a credible interval that needs more order statistics than the device keeps
+                if "bnmf_window" not in str(ex):
+                    raise
+                r = None
+            if r is not None:
+                keep = np.where(np.ravel(r["A"]) == 1)[0] if final else np.arange(self.dims["N"])
+                counts = [("".join(str(int(v)) for v in row), c) for row, c in zip(r["top_A"], r["top_counts"])]
+                self.MAP = dict(P=r["P"][:, keep], A=r["A"][:, keep], E=r["E"][keep, :],
+                                idx=[first_iter + i for i in np.where(r["used"])[0]], A_counts=counts, keep_sigs=keep,
+                                RMSE=r["rmse"], KL=r["kl"])
+                if r["P_lower"] is not None:
+                    self.credible_intervals = dict(P=dict(lower=r["P_lower"][:, keep], upper=r["P_upper"][:, keep]),
+                                                   E=dict(lower=r["E_lower"][keep, :], upper=r["E_upper"][keep, :]))
+                return self.MAP
         A_list = self._chain.window("A", n)
         mode = get_mode(A_list)
         idx = mode["idx"]
@@ -235,9 +257,10 @@ class bayesNMF_sampler:
         rs = [renormalize(Ps[i], Es[i]) for i in idx]
         Pm = np.mean([r[0][:, keep] for r in rs], axis=0)
         Em = np.mean([r[1][keep, :] for r in rs], axis=0)
-        first_iter = self.state["iter"] - n + 1
         self.MAP = dict(P=Pm, A=np.asarray(mode["matrix"]).reshape(1, -1)[:, keep], E=Em,
                         idx=[first_iter + i for i in idx], A_counts=mode["top_counts"], keep_sigs=keep)
+        if not credible_interval:
+            return self.MAP
         probs = [0.5 - credible_interval / 2, 0.5 + credible_interval / 2]
         Parr = np.stack([r[0][:, keep] for r in rs], axis=2)
         Earr = np.stack([r[1][keep, :] for r in rs], axis=2)
@@ -252,20 +275,23 @@ class bayesNMF_sampler:
         P, A, E = self.MAP["P"], self.MAP["A"], self.MAP["E"]
         if final:
             A = np.ones((1, P.shape[1]))
-        Mhat = (P * np.ravel(A)[None, :]) @ E
         sm = self.state["sample_metrics"]
         win = sm[sm["iter"].isin(self.MAP["idx"])]
         ll, lpost = float(win["loglikelihood"].mean()), float(win["logposterior"].mean())
         n_params = float(np.sum(A) * (G + K))
-        Mt, Mh = np.maximum(self.data, 1e-6), np.maximum(Mhat, 1e-6)
-        row = dict(iter=self.state["iter"], RMSE=float(np.sqrt(np.mean((Mhat - self.data) ** 2))),
-                   KL=float(np.sum(Mt * np.log(Mt / Mh))), loglikelihood=ll, logposterior=lpost, n_params=n_params,
+        if "RMSE" in self.MAP:                      # computed on the device with the window statistics
+            rmse, kl = float(self.MAP["RMSE"]), float(self.MAP["KL"])
+        else:
+            Mhat = (P * np.ravel(A)[None, :]) @ E
+            Mt, Mh = np.maximum(self.data, 1e-6), np.maximum(Mhat, 1e-6)
+            rmse, kl = float(np.sqrt(np.mean((Mhat - self.data) ** 2))), float(np.sum(Mt * np.log(Mt / Mh)))
+        row = dict(iter=self.state["iter"], RMSE=rmse, KL=kl, loglikelihood=ll, logposterior=lpost, n_params=n_params,
                    BIC=-2 * ll + n_params * np.log(G), rank=float(np.sum(self.MAP["A"])),
                    MAP_A_counts=float(self.MAP["A_counts"][0][1]),
                    mean_temp=float(np.mean(self.temperature_schedule[np.asarray(self.MAP["idx"]) - 1])))
-        if self.specs["MH"]:
-            row["P_mean_acceptance_rate"] = float(win["P_mean_acceptance_rate"].mean())
-            row["E_mean_acceptance_rate"] = float(win["E_mean_acceptance_rate"].mean())
+        if self.specs["MH"]:                        # compute_metrics_ uses the CURRENT acceptance matrices (R/utils.R:444-452)
+            row["P_mean_acceptance_rate"] = float(sm["P_mean_acceptance_rate"].iloc[-1])
+            row["E_mean_acceptance_rate"] = float(sm["E_mean_acceptance_rate"].iloc[-1])
         df = pd.DataFrame([row])
         self.state["MAP_metrics"] = df if self.state["MAP_metrics"].empty else \
             pd.concat([self.state["MAP_metrics"], df], ignore_index=True)
@@ -275,7 +301,12 @@ class bayesNMF_sampler:
         self.log(f"iter = {self.state['iter']}", verbosity=1)
         self.state["indent"] = 2
         self.log("Computing MAP", verbosity=1)
-        self.get_MAP(final=final)
+        # The reference recomputes the credible intervals at EVERY check (credible_intervals starts as list(), not NULL:
+        # R/bayesNMF_sampler.R:49, R/utils.R:269) although nothing reads them before the final MAP.  Here they are
+        # materialised at the final MAP and on every user call of get_MAP(); intermediate_credible_intervals=True
+        # restores the reference's every-check behaviour.
+        ci = 0.95 if (final or self.specs.get("intermediate_credible_intervals")) else None
+        self.get_MAP(final=final, credible_interval=ci)
         if self.specs["learning_rank"]:
             self.log("\n".join(f"{k}  {v}" for k, v in self.MAP["A_counts"]), verbosity=1)
         self.log("Checking convergence", verbosity=1)
@@ -311,6 +342,8 @@ class bayesNMF_sampler:
                 if self.specs["periodic_save"]:
                     self.log("Saving object", verbosity=1)
                     self.save_object()
+            if self._block_hook is not None:
+                self._block_hook(self, rows)
         if self.specs["MH"]:
             start_MH = time.time()
             self.time["warmup"] = (start_MH - start) / 60.0
@@ -329,6 +362,8 @@ class bayesNMF_sampler:
                     self._check(final=(done == pw))
                     if self.specs["periodic_save"]:
                         self.save_object()
+                if self._block_hook is not None:
+                    self._block_hook(self, rows)
             self.log(f"Additional {pw} MH samples done", verbosity=1)
             self.time["MH"] = (time.time() - start_MH) / 60.0
         else:
@@ -345,7 +380,7 @@ class bayesNMF_sampler:
 
     def save_object(self):
         """save_object (R/bayesNMF_sampler.R:414-416): sampler.rds -> sampler.pkl (fields, not the device handle)."""
-        keep = {k: v for k, v in self.__dict__.items() if k not in ("_chain", "log_con")}
+        keep = {k: v for k, v in self.__dict__.items() if k not in ("_chain", "log_con", "_block_hook")}
         with open(os.path.join(self.specs["output_dir"], "sampler.pkl"), "wb") as f:
             pickle.dump(keep, f)
 
@@ -362,9 +397,22 @@ class bayesNMF_sampler:
 def bayesNMF(data, rank, likelihood="poisson", prior="truncnormal", rank_method="SBFI", MH=None,
              convergence_control=None, prop_temp=0.2, post_warmup=None, output_dir=None, overwrite=False,
              hyperprior_params=None, init_prior_params=None, init_params=None, periodic_save=True,
-             save_all_samples=True, seed=1, chain_id=0, device=0, save_Z=False, engine_factory=None):
+             save_all_samples=True, seed=1, chain_id=0, device=0, save_Z=False, engine_factory=None,
+             intermediate_credible_intervals=False, n_chains=1, devices=None):
     """bayesNMF() (R/bayesNMF.R:24-138): build the sampler and run it; with rank_method = "BIC" run one
-    fixed-rank sampler per rank and return dict(results, best_rank, sampler)."""
+    fixed-rank sampler per rank and return dict(results, best_rank, sampler).
+
+    New optional trailing arguments: seed, chain_id, device, save_Z, and n_chains / devices:
+    n_chains > 1 runs independent replicas (chain_id = 0..n_chains-1 in the Philox key), chain c on
+    devices[c % len(devices)], and returns the list of samplers (multichain.run_chains)."""
+    if n_chains and n_chains > 1:
+        from .multichain import run_chains
+        kw = dict(likelihood=likelihood, prior=prior, rank_method=rank_method, MH=MH, convergence_control=convergence_control,
+                  prop_temp=prop_temp, post_warmup=post_warmup, output_dir=output_dir, overwrite=overwrite,
+                  hyperprior_params=hyperprior_params, init_prior_params=init_prior_params, init_params=init_params,
+                  periodic_save=periodic_save, save_all_samples=save_all_samples, seed=seed, save_Z=save_Z,
+                  engine_factory=engine_factory, intermediate_credible_intervals=intermediate_credible_intervals)
+        return run_chains(data, rank, n_chains=n_chains, devices=devices, **kw)
     if output_dir is None:
         output_dir = f"nmf_{likelihood}_{prior}"
     common = dict(likelihood=likelihood, prior=prior, rank_method=rank_method, MH=MH,
@@ -372,7 +420,7 @@ def bayesNMF(data, rank, likelihood="poisson", prior="truncnormal", rank_method=
                   overwrite=overwrite, hyperprior_params=hyperprior_params, init_prior_params=init_prior_params,
                   init_params=init_params, verbosity=1, periodic_save=periodic_save,
                   save_all_samples=save_all_samples, seed=seed, chain_id=chain_id, device=device, save_Z=save_Z,
-                  engine_factory=engine_factory)
+                  engine_factory=engine_factory, intermediate_credible_intervals=intermediate_credible_intervals)
     ranks = np.atleast_1d(np.asarray(rank, dtype=int))
     if ranks.size > 1 and rank_method == "BIC":
         results = []

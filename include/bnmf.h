@@ -101,6 +101,25 @@ int bnmf_run(bnmf_handle* h, int n_iter, int converged, double* metrics_rowmajor
  * out[last_n][len(id)] (record_sample, R/bayesNMF_sampler.R:651-672). */
 int bnmf_window(bnmf_handle* h, int id, int last_n, double* out);
 
+/* MAP estimate over the last `last_n` recorded samples, computed on the device (get_MAP_, R/utils.R:194-288;
+ * get_mode / renormalize, R/helpers.R:35-79): mode of A over the window (ties: alphabetically first pattern, as
+ * sort(table(.), decreasing = TRUE) gives); over the samples whose A equals the mode, P / colSums(P) and
+ * E * colSums(P) are averaged element-wise (P_mean K x N, E_mean N x G, every factor; `final = TRUE` of the
+ * reference is the caller dropping the factors with A_mode == 0); credible_interval in (0,1) also returns the
+ * quantile(., type 7) bounds at (1 -+ credible_interval) / 2 (any of the four pointers may be NULL; <= 0: none);
+ * used[last_n] flags the samples that entered (oldest first); top_A (5 x N, row-major) the most frequent patterns.
+ * info.rmse / info.kl are compute_metrics_(P = MAP$P, A = MAP$A, E = MAP$E, MAP = TRUE) (R/utils.R:412-455). */
+typedef struct {
+  int32_t n_used;          /* samples whose A equals the mode */
+  int32_t n_patterns;      /* distinct A patterns in the window */
+  int32_t top_counts[5];   /* counts of the (up to) five most frequent patterns, descending */
+  int32_t _pad;
+  double rmse, kl;
+} bnmf_map_info;
+int bnmf_map(bnmf_handle* h, int last_n, double credible_interval, double* P_mean, double* E_mean,
+             double* A_mode, double* top_A, double* P_lower, double* P_upper, double* E_lower,
+             double* E_upper, int32_t* used, bnmf_map_info* info);
+
 int bnmf_get_iter(bnmf_handle* h, int* iter);
 
 /* average device time (ms) of each kernel class over n_iter iterations, measured with HIP

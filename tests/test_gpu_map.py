@@ -1,0 +1,122 @@
+"""bnmf_map (on-device MAP window statistics) against a numpy restatement of get_MAP_
+(R/utils.R:194-288), get_mode and renormalize (R/helpers.R:35-79) evaluated on the same window of samples."""
+from collections import Counter
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12      # stated tolerance: fp64 sums in a different association order than numpy's
+
+
+def _np_map(e, n, ci, M):
+    A = e.window("A", n); P = e.window("P", n); E = e.window("E", n)
+    keys = ["".join(str(int(v)) for v in a.ravel()) for a in A]
+    tab = sorted(Counter(keys).items(), key=lambda kv: (-kv[1], kv[0]))      # sort(table(.), decreasing = TRUE)
+    mode = tab[0][0]
+    idx = [i for i, k in enumerate(keys) if k == mode]
+    Pn = np.stack([P[i] / P[i].sum(0)[None, :] for i in idx], axis=2)
+    En = np.stack([E[i] * P[i].sum(0)[:, None] for i in idx], axis=2)
+    Am = np.array([float(c) for c in mode])
+    out = dict(P=Pn.mean(2), E=En.mean(2), A=Am, idx=idx, tab=tab)
+    if ci:
+        pr = [0.5 - ci / 2, 0.5 + ci / 2]
+        out.update(P_lower=np.quantile(Pn, pr[0], axis=2), P_upper=np.quantile(Pn, pr[1], axis=2),
+                   E_lower=np.quantile(En, pr[0], axis=2), E_upper=np.quantile(En, pr[1], axis=2))
+    Mh = (out["P"] * Am[None, :]) @ out["E"]
+    out["rmse"] = np.sqrt(((Mh - M) ** 2).mean())
+    Mt = np.maximum(M, 1e-6)
+    out["kl"] = (Mt * np.log(Mt / np.maximum(Mh, 1e-6))).sum()
+    return out
+
+
+def _check(e, n, ci, M):
+    ref = _np_map(e, n, ci, M)
+    got = e.map(n, ci)
+    assert got["n_used"] == len(ref["idx"])
+    assert np.array_equal(np.where(got["used"])[0], ref["idx"])
+    assert np.array_equal(got["A"].ravel(), ref["A"])
+    assert got["top_counts"] == [c for _, c in ref["tab"][:5]]
+    assert ["".join(str(int(v)) for v in r) for r in got["top_A"]] == [k for k, _ in ref["tab"][:5]]
+    names = ["P", "E"] + (["P_lower", "P_upper", "E_lower", "E_upper"] if ci else [])
+    for nm in names:
+        assert np.allclose(got[nm], ref[nm], rtol=RTOL, atol=1e-300), (nm, np.abs(got[nm] / ref[nm] - 1).max())
+    assert np.isclose(got["rmse"], ref["rmse"], rtol=1e-11) and np.isclose(got["kl"], ref["kl"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("n,ci", [(200, 0.95), (37, 0.95), (5, 0.95), (2, 0.95), (1, 0.95), (200, 0.5), (200, None)])
+def test_map_fixed_rank(n, ci):
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    M, _, _ = synth_counts(96, 150, 4, 5)
+    e = Engine(M, 5, prior="gamma", seed=3, window=200)
+    apply_hyperprior_params(e, "gamma", M, 5)
+    e.init()
+    e.run(260)                                       # the ring has wrapped
+    _check(e, n, ci, M)
+    e.close()
+
+
+def test_map_learned_rank_mode_of_A():
+    """Several A patterns in the window: only the samples at the mode enter the means."""
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    M, _, _ = synth_counts(96, 64, 3, 9)
+    N = 8
+    temp = np.concatenate([np.zeros(3), 10.0 ** np.linspace(-6, -1, 120), np.ones(100)])
+    e = Engine(M, N, prior="gamma", learning_rank=True, seed=5, temperature=temp, window=100)
+    apply_hyperprior_params(e, "gamma", M, N)
+    e.init()
+    e.run(110)                                       # window = iterations 12..111 of the tempered phase: A still moves
+    pats = {tuple(a.ravel()) for a in e.window("A", 100)}
+    assert len(pats) > 1, "test needs more than one A pattern in the window"
+    _check(e, 100, 0.95, M)
+    _check(e, 40, 0.9, M)
+    e.close()
+
+
+def test_map_metric_config_size_matches_host_path():
+    """K = 96, G = 10,000, N = 20 with MAP_over = 1000 samples (the reference's default check): finite, normalised,
+    and equal to the host evaluation on a strided subset of elements."""
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    M, _, _ = synth_counts(96, 10000, 8, 20250218)
+    e = Engine(M, 20, prior="gamma", seed=1, window=1000)
+    apply_hyperprior_params(e, "gamma", M, 20)
+    e.init()
+    e.run(1100, metrics=False)
+    r = e.map(1000, 0.95)
+    assert r["n_used"] == 1000
+    assert np.allclose(r["P"].sum(0), 1.0, rtol=1e-12)
+    assert (r["E_lower"] <= r["E"]).all() and (r["E"] <= r["E_upper"]).all()
+    assert (r["P_lower"] <= r["P_upper"]).all()
+    P = np.stack(e.window("P", 1000), axis=2)
+    cs = P.sum(0)                                                  # N x samples
+    Pn = P / cs[None, :, :]
+    assert np.allclose(r["P"], Pn.mean(2), rtol=RTOL)
+    assert np.allclose(r["P_lower"], np.quantile(Pn, 0.025, axis=2), rtol=RTOL)
+    assert np.allclose(r["P_upper"], np.quantile(Pn, 0.975, axis=2), rtol=RTOL)
+    e.close()
+
+
+def test_bayesNMF_uses_device_map(tmp_path, monkeypatch):
+    """The bayesNMF() mirror computes its MAP / credible intervals through bnmf_map and agrees with the host path."""
+    from bayesnmf_amd.engine import Engine
+    from bayesnmf_amd.sampler import bayesNMF
+    from bayesnmf_amd.convergence import new_convergence_control
+    from bayesnmf_amd.setup import synth_counts
+    M, Pt, _ = synth_counts(96, 64, 4, 12)
+    cc = new_convergence_control(MAP_over=100, MAP_every=50, miniters=100, maxiters=300)
+    s = bayesNMF(M, 4, prior="gamma", convergence_control=cc, output_dir=str(tmp_path / "o"), periodic_save=False,
+                 save_all_samples=False)
+    assert "RMSE" in s.MAP                                          # came from the device
+    dev = dict(P=s.MAP["P"].copy(), E=s.MAP["E"].copy(), lo=s.credible_intervals["P"]["lower"].copy(),
+               hi=s.credible_intervals["E"]["upper"].copy())
+    monkeypatch.delattr(Engine, "map")
+    s.get_MAP(final=True)                                           # host path: window copy + numpy
+    assert "RMSE" not in s.MAP
+    assert np.allclose(dev["P"], s.MAP["P"], rtol=1e-12) and np.allclose(dev["E"], s.MAP["E"], rtol=1e-12)
+    assert np.allclose(dev["lo"], s.credible_intervals["P"]["lower"], rtol=1e-12)
+    assert np.allclose(dev["hi"], s.credible_intervals["E"]["upper"], rtol=1e-12)
+    s.close()
