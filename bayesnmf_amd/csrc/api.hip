@@ -48,9 +48,10 @@ struct bnmf_handle {
   int32_t *dM = nullptr, *dZsumK = nullptr, *dZsumG = nullptr, *dZ = nullptr;
   int* dR = nullptr; int* dRedraw = nullptr;
   double *dEsum = nullptr, *dPsum = nullptr, *dlpPn = nullptr, *dlpE = nullptr, *dcol = nullptr;
-  double *dLut = nullptr, *dTemp = nullptr, *dMetrics = nullptr, *dRaw = nullptr, *dRankCol = nullptr;
+  double *dLut = nullptr, *dTemp = nullptr, *dMetrics = nullptr, *dRaw = nullptr, *dRankCol = nullptr, *dRankMhat = nullptr;
+  uint32_t* dRankSync = nullptr; int rank_grid = 0; bool rank_reg = false;
   int32_t* dMt = nullptr; double* dEt = nullptr;
-  double *dProp = nullptr, *dPart = nullptr, *dAccPn = nullptr, *dAccEpart = nullptr; int* dNzE = nullptr; int mh_S = 1;
+  double *dMhat = nullptr, *dAccPn = nullptr, *dAccEpart = nullptr; int* dNzE = nullptr; int mh_S = 1; size_t mhe_lds = 0;
   size_t metrics_rows = 0;
   int maxM = 0, nblkE = 0;
   int wcap = 0;                        // ring capacity = window + 1: the hyper sweep of iteration t+1 is issued (and, in the
@@ -207,14 +208,31 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   h->nblkE = (int)((N * G + ES_T - 1) / ES_T);
   HIPCHK(hipMalloc(&h->dlpE, 3 * (size_t)h->nblkE * sizeof(double)));
   HIPCHK(hipMalloc(&h->dcol, 3 * 3 * G * sizeof(double)));   // per-column partials, 3 slots (t % 3)
-  if (cfg->learning_rank) HIPCHK(hipMalloc(&h->dRankCol, 2 * G * sizeof(double)));
+  if (cfg->learning_rank) {
+    HIPCHK(hipMalloc(&h->dRankCol, 2 * G * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dRankSync, 32));
+    HIPCHK(hipMemset(h->dRankSync, 0, 32));
+    // grid of the persistent rank sweep: co-resident by construction (at most one 512-lane workgroup per CU)
+    hipDeviceProp_t prop0;
+    HIPCHK(hipGetDeviceProperties(&prop0, cfg->device));
+    const long wg_needed = ((long)G + RK_W - 1) / RK_W;
+    h->rank_grid = (int)std::min<long>(wg_needed, prop0.multiProcessorCount);
+    const long cols_per_wave = ((long)G + (long)h->rank_grid * RK_W - 1) / ((long)h->rank_grid * RK_W);
+    h->rank_reg = K <= 128 && cols_per_wave <= RK_MAXC;
+    if (!h->rank_reg) HIPCHK(hipMalloc(&h->dRankMhat, K * G * sizeof(double)));
+  }
   if (cfg->MH || cfg->likelihood == BNMF_NORMAL) {
     h->mh_S = (int)((G + MH_SEG - 1) / MH_SEG);
-    HIPCHK(hipMalloc(&h->dProp, K * sizeof(double)));
-    HIPCHK(hipMalloc(&h->dPart, K * (size_t)h->mh_S * 4 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dMhat, K * G * sizeof(double)));          // rows of Mhat maintained by the P sweep
+    h->mhe_lds = 4 * (2 * N + K) * sizeof(double);                 // k_mh_ecol: per wave E column, A, Mhat column
+    if (h->mhe_lds > 64 * 1024) {
+      if (h->mhe_lds > 160 * 1024) return fail(BNMF_EINVAL, "bnmf_create: K = %zu too large for the column kernel of the MH / Normal models (LDS)", K);
+      HIPCHK(hipFuncSetAttribute((const void*)k_mh_ecol<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)k_mh_ecol<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
     HIPCHK(hipMalloc(&h->dAccPn, 3 * N * sizeof(double)));
     HIPCHK(hipMalloc(&h->dAccEpart, 3 * (size_t)h->nblkE * sizeof(double)));
-    HIPCHK(hipMalloc(&h->dNzE, N * sizeof(int)));
+    HIPCHK(hipMalloc(&h->dNzE, 2 * N * sizeof(int)));
     HIPCHK(hipMalloc(&h->dEt, N * G * sizeof(double)));
     HIPCHK(hipMalloc(&h->dMt, K * G * sizeof(int32_t)));
     {
@@ -315,8 +333,9 @@ int bnmf_destroy(bnmf_handle* h) {
   for (auto& a : h->arr) { if (a.d) hipFree(a.d); if (a.ring) hipFree(a.ring); }
   hipFree(h->dM); hipFree(h->dZsumK); hipFree(h->dZsumG); if (h->dZ) hipFree(h->dZ);
   hipFree(h->dR); hipFree(h->dRedraw); hipFree(h->dEsum); hipFree(h->dPsum); hipFree(h->dlpPn);
-  hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol);
-  if (h->dProp) { hipFree(h->dProp); hipFree(h->dPart); hipFree(h->dAccPn); hipFree(h->dAccEpart); hipFree(h->dNzE); hipFree(h->dEt); hipFree(h->dMt); }
+  hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol); if (h->dRankMhat) hipFree(h->dRankMhat); if (h->dRankSync) hipFree(h->dRankSync);
+  if (h->dMhat) hipFree(h->dMhat); if (h->dAccPn) hipFree(h->dAccPn); if (h->dAccEpart) hipFree(h->dAccEpart); if (h->dNzE) hipFree(h->dNzE);
+  if (h->dEt) hipFree(h->dEt); if (h->dMt) hipFree(h->dMt);
   if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); if (h->side) hipStreamDestroy(h->side); if (h->side2) hipStreamDestroy(h->side2);
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
   if (h->dMap) hipFree(h->dMap);
@@ -553,16 +572,14 @@ static int launch_zalloc(bnmf_handle* h, uint32_t t) {
     default: return sz ? launch_zalloc_t<true, 64>(h, t) : launch_zalloc_t<false, 64>(h, t);
   }
 }
-// sample_R then sample_An for n = 1..N (R/sample_params.R:67-74); 2 launches per factor
+// sample_R then sample_An for n = 1..N (R/sample_params.R:67-74): one persistent launch for the N sequential updates
 static void launch_rank(bnmf_handle* h, uint32_t t) {
-  const int N = h->cfg.N, G = h->cfg.G;
+  const int N = h->cfg.N;
   hipLaunchKernelGGL(k_rank_R, dim3(1), dim3(64), 0, h->stream, h->dev, t, 0);
-  int grid = (G + 3) / 4; if (grid > 2048) grid = 2048;
-  const size_t lds = 4 * 2 * (size_t)N * sizeof(double);
-  for (int n = 0; n < N; ++n) {
-    hipLaunchKernelGGL(k_rank_ll, dim3(grid), dim3(RK_T), lds, h->stream, h->dev, n, h->dRankCol, h->dRankCol + G);
-    hipLaunchKernelGGL(k_rank_decide, dim3(1), dim3(RT), 0, h->stream, h->dev, t, n, h->dRankCol, h->dRankCol + G);
-  }
+  hipMemsetAsync(h->dRankSync, 0, 16, h->stream);          // the barrier counter (the time-out flag at +16 is sticky)
+  const size_t lds = (size_t)N * sizeof(double);
+  if (h->rank_reg) hipLaunchKernelGGL(k_rank_sweep<true>, dim3(h->rank_grid), dim3(RK_T), lds, h->stream, h->dev, t, h->dRankCol, (unsigned*)h->dRankSync, (int*)(h->dRankSync + 4), h->dRankMhat);
+  else hipLaunchKernelGGL(k_rank_sweep<false>, dim3(h->rank_grid), dim3(RK_T), lds, h->stream, h->dev, t, h->dRankCol, (unsigned*)h->dRankSync, (int*)(h->dRankSync + 4), h->dRankMhat);
 }
 // ids recorded per iteration (names(self$params) + names(self$prior_params), R/bayesNMF_sampler.R:245-252)
 static std::vector<int> recorded_ids(const bnmf_handle* h) {
@@ -638,21 +655,17 @@ static void flush_reduce(bnmf_handle* h, Timer& tm) {
 // P and E updates of the MH models (R/sample_params.R:56-64 with sample_Pn/_En -> *_normal -> MH_*_poisson)
 static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged) {
   const int K = h->cfg.K, N = h->cfg.N, G = h->cfg.G, S = h->mh_S;
-  hipMemsetAsync(h->dNzE, 0, N * sizeof(int), h->stream);
+  const bool normal = h->cfg.likelihood == BNMF_NORMAL;
+  const int mhstep = (h->cfg.MH && converged && !normal) ? 1 : 0;
+  hipMemsetAsync(h->dNzE, 0, 2 * N * sizeof(int), h->stream);           // nzE[N], nzP[N]
   hipLaunchKernelGGL(k_mh_nz, dim3(N), dim3(256), 0, h->stream, h->dev, h->dNzE);
-  const int nb = (K * S + 3) / 4;
-  const size_t lds = 4 * (size_t)N * sizeof(double);
   double* accP = h->arr[BNMF_ACC_P].d; double* accE = h->arr[BNMF_ACC_E].d;
-  for (int n = 0; n < N; ++n) {
-    hipLaunchKernelGGL(k_mh_prow_partial<0>, dim3(nb), dim3(MHP_T), lds, h->stream, h->dev, n, S, (const double*)h->dProp, (const int*)h->dNzE, h->dPart);
-    hipLaunchKernelGGL(k_mh_prow_finish<0>, dim3((K + 63) / 64), dim3(64), 0, h->stream, h->dev, t, n, S, converged, h->dProp, (const int*)h->dNzE, (const double*)h->dPart, accP);
-    if (converged) {
-      hipLaunchKernelGGL(k_mh_prow_partial<1>, dim3(nb), dim3(MHP_T), lds, h->stream, h->dev, n, S, (const double*)h->dProp, (const int*)h->dNzE, h->dPart);
-      hipLaunchKernelGGL(k_mh_prow_finish<1>, dim3((K + 63) / 64), dim3(64), 0, h->stream, h->dev, t, n, S, converged, h->dProp, (const int*)h->dNzE, (const double*)h->dPart, accP);
-    }
-  }
+  const size_t ldsP = (4 * (size_t)S + N + 2) * sizeof(double);
+  if (normal) hipLaunchKernelGGL(k_mh_prow<true>, dim3(K), dim3(MHP_T), ldsP, h->stream, h->dev, t, mhstep, S, (const int*)h->dNzE, accP, h->dMhat);
+  else hipLaunchKernelGGL(k_mh_prow<false>, dim3(K), dim3(MHP_T), ldsP, h->stream, h->dev, t, mhstep, S, (const int*)h->dNzE, accP, h->dMhat);
+  hipLaunchKernelGGL(k_mh_nzp, dim3(N), dim3(64), 0, h->stream, h->dev, h->dNzE + N);
   int grid = (G + 3) / 4; if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(k_mh_ecol<false>, dim3(grid), dim3(MHE_T), 4 * 2 * (size_t)N * sizeof(double), h->stream, h->dev, t, converged, accE, 0);
+  hipLaunchKernelGGL(k_mh_ecol<false>, dim3(grid), dim3(MHE_T), h->mhe_lds, h->stream, h->dev, t, mhstep, (const int*)(h->dNzE + N), accE, 0);
 }
 static void launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells) {
   const int draw_sig = h->cfg.likelihood == BNMF_NORMAL ? 1 : 0;
@@ -660,7 +673,7 @@ static void launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells) {
   const int N = h->cfg.N, G = h->cfg.G;
   if (cells) {
     int grid = (G + 3) / 4; if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(k_mh_ecol<true>, dim3(grid), dim3(MHE_T), 4 * 2 * (size_t)N * sizeof(double), h->stream, h->dev, t, 0, h->arr[BNMF_ACC_E].d, draw_sig);
+    hipLaunchKernelGGL(k_mh_ecol<true>, dim3(grid), dim3(MHE_T), h->mhe_lds, h->stream, h->dev, t, 0, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
   }
   hipLaunchKernelGGL(k_lp_p, dim3(N), dim3(64), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_P].d, accPn_slot(h, t));
   hipLaunchKernelGGL(k_lp_e, dim3(h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_E].d, accEp_slot(h, t));
@@ -817,6 +830,11 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->side));
   HIPCHK(hipStreamSynchronize(h->side2));
+  if (h->dRankSync) {
+    int err = 0;
+    HIPCHK(hipMemcpy(&err, h->dRankSync + 4, sizeof(int), hipMemcpyDeviceToHost));
+    if (err) return fail(BNMF_EHIP, "bnmf_run: the grid barrier of the rank sweep timed out (workgroups not co-resident?)");
+  }
   return 0;
 }
 int bnmf_run(bnmf_handle* h, int n_iter, int converged, double* metrics) {

@@ -2,21 +2,19 @@
 //
 // sample_Pn -> sample_Pn_normal(as_proposal = TRUE) -> MH_Pn_poisson (R/sample_Pn.R:11-42, :54-87,
 // :132-187, :199-248) and the E mirror (R/sample_En.R).  Factors are updated for n = 1..N in order and
-// every evaluation uses a FRESH Mhat = P diag(A) E of the current state (as get_Mhat() does), so no
-// K x G matrix is kept.
-//   P side: the conditional of row k needs sums over all columns g -> k_mh_prow_partial (one wave per
-//           (row, 512-column segment), lanes 64-strided over g) + k_mh_prow_finish (one lane per row:
-//           segments added in ascending order, draw / accept).  2 launches per factor before
-//           convergence, 4 after.
+// Mhat = P diag(A) E follows the current state (see the stream spec in DESIGN.md).
+//   P side: the conditional of row k needs sums over all columns g, but rows are independent within the sweep
+//           -> ONE launch, one 1024-lane workgroup per row doing all N sequential updates (k_mh_prow).
 //   E side: the conditional of E[n,g] needs sums over k only -> ONE launch, one wave per column doing
 //           all N sequential updates locally (k_mh_ecol), followed by the column's metric terms.
+//   Mhat is maintained incrementally inside each sweep (fresh at its start): O(N K G) per iteration.
 // All sums follow the canonical orders of the stream spec, so proposals and accept/reject masks are
 // bit-identical to the oracle.
 #pragma once
 
 namespace bnmf {
 
-constexpr int MH_SEG = 512;
+constexpr int MH_SEG = 320;             // columns per segment of the canonical row sums (5 per lane)
 
 BNMF_DEV double dpois_log(int m, double lam, double lgf) {      // get_loglik_ poisson branch R/utils.R:98-106
   const double mh = lam < 1e-6 ? 1e-6 : lam;
@@ -57,89 +55,134 @@ __global__ void k_mh_nz(Dev d, int* nzE) {
   }
   if (c) atomicAdd(&nzE[n], c);
 }
+// nzP[n] = number of non-zero entries in column n of P (all(P[,n] == 0) test of sample_En_normal :56), after the P sweep
+__global__ void k_mh_nzp(Dev d, int* nzP) {
+  const int n = blockIdx.x;
+  int c = 0;
+  for (int k = threadIdx.x; k < d.K; k += blockDim.x) c += d.P[k + (size_t)d.K * n] != 0.0 ? 1 : 0;
+  if (c) atomicAdd(&nzP[n], c);
+}
 
-// MODE 0: partial sums of num1, den for the proposal of column n;  MODE 1: partial sums of the four
-// log-likelihood rows of the MH ratio (needs prop[k]).  One wave per (row k, segment s).
-constexpr int MHP_T = 256;
-template <int MODE>
-__global__ __launch_bounds__(MHP_T) void k_mh_prow_partial(Dev d, int n, int S, const double* prop, const int* nzE, double* part) {
+// ---- P side: ONE launch, one workgroup of 1024 lanes per row k ----
+// Within the P sweep the rows of P are mutually independent (Mhat[k, .] depends on P[k, .] only), so row k runs its
+// N sequential factor updates alone: the reductions over the G columns are workgroup reductions, not grid-wide ones.
+// The row's Mhat lives in `mhrow` (global scratch [K][G], L2-resident) and is maintained incrementally (stream spec:
+// fresh at the start of the sweep, then Mhat_no_n = Mhat - (P[k,n] A[n]) E[n,g] and Mhat = Mhat_no_n + (P_new A[n]) E).
+// Canonical row sums: segments of MH_SEG = 320 columns (lane l of the owning wave adds columns l, l+64, ... of the
+// segment, then the wave tree), segments added in ascending order by lane 0.  Segment s belongs to wave s % 16; a
+// lane owns the same cells for the whole sweep, so Mhat needs no synchronisation.
+constexpr int MHP_T = 1024;
+constexpr int MHP_W = MHP_T / 64;
+constexpr int MH_CPL = MH_SEG / 64;                       // cells per lane and segment
+template <bool NORMAL>
+__global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int mhstep, int S, const int* nzE, double* accP, double* mhrow) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = d.K, G = d.G, N = d.N;
-  const int item = blockIdx.x * (MHP_T / 64) + wave;
-  if (item >= K * S) return;
-  const double a_n = d.A[n];
-  if (a_n == 0.0 || (MODE == 0 && nzE[n] == 0)) return;  // prior draw: no sums needed
-  const int k = item / S, s = item - k * S;
-  double* pa = (double*)smem + (size_t)wave * N;       // [N] P[k,j] * A[j] of this row
-  for (int j = lane; j < N; j += 64) pa[j] = d.P[k + (size_t)K * j] * d.A[j];
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  const double pn_prop = MODE == 1 ? prop[k] * a_n : 0.0;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  const int gbeg = s * MH_SEG, gend = min(G, gbeg + MH_SEG);
-  for (int g = gbeg + lane; g < gend; g += 64) {
-    const double* Eg = d.Et + g;                      // E[j, g] = Eg[G j]: coalesced over the lanes' columns
-    const int m = d.Mt[g + (size_t)G * k];
-    if (MODE == 0) {
-      double mh = 0.0, mno = 0.0;
-      for (int j = 0; j < N; ++j) { const double term = pa[j] * Eg[(size_t)G * j]; mh = mh + term; mno = mno + (j == n ? 0.0 * Eg[(size_t)G * j] : term); }
-      const double en = Eg[(size_t)G * n];
-      const double V = d.likelihood == BNMF_NORMAL ? d.sigmasq[g] : mh;   // sigmasq_kg: Mhat (proposal) or sigmasq_g :137-147
-      a0 = a0 + en * (((double)m - mno) / V);           // :155-161
-      a1 = a1 + (a_n * (en * en)) * (1.0 / V);           // :163-169
-    } else {
-      double m0 = 0.0, m1 = 0.0;
-      for (int j = 0; j < N; ++j) { const double e = Eg[(size_t)G * j]; m0 = m0 + pa[j] * e; m1 = m1 + (j == n ? pn_prop : pa[j]) * e; }
-      const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
-      const double lgf = d.lgfact[mi];
-      a0 = a0 + dpois_log(m, m1, lgf);                                  // loglik_poisson_new :216-218
-      a1 = a1 + dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);         // loglik_normal_old  :219-224
-      a2 = a2 + dpois_log(m, m0, lgf);                                  // loglik_poisson_old :213-215
-      a3 = a3 + dnorm_log((double)m, m1, m0 < 1.0 ? 1.0 : m0);         // loglik_normal_new  :225-231
+  const int K = d.K, G = d.G, N = d.N, k = blockIdx.x;
+  double* part = (double*)smem;                         // [4][S] segment partial sums
+  double* pa = part + 4 * (size_t)S;                    // [N] P[k,j] * A[j]
+  double* bc = pa + N;                                  // [2] broadcast: proposal, accept flag
+  double* row = mhrow + (size_t)k * G;
+  const int32_t* Mk = d.Mt + (size_t)G * k;             // M[k, g] at Mt[g + G k]
+  for (int j = tid; j < N; j += MHP_T) pa[j] = d.P[k + (size_t)K * j] * d.A[j];
+  __syncthreads();
+  // fresh Mhat of the row (factor order), by the lane that owns the cell
+  for (int s = wave; s < S; s += MHP_W) {
+    const int g0 = s * MH_SEG, gend = min(G, g0 + MH_SEG);
+    for (int g = g0 + lane; g < gend; g += 64) {
+      double c = 0.0;
+      for (int j = 0; j < N; ++j) c = c + pa[j] * d.Et[g + (size_t)G * j];
+      row[g] = c;
     }
   }
-  a0 = wave_tree64(a0); a1 = wave_tree64(a1);
-  if (MODE == 1) { a2 = wave_tree64(a2); a3 = wave_tree64(a3); }
-  if (lane == 0) { double* o = part + ((size_t)k * S + s) * 4; o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; }
-}
-template <int MODE>
-__global__ void k_mh_prow_finish(Dev d, uint32_t t, int n, int S, int converged, double* prop, const int* nzE, const double* part, double* accP) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= d.K) return;
-  const int e = k + d.K * n;
-  const double a_n = d.A[n];
-  if (MODE == 0) {
-    if (a_n == 0.0) { d.P[e] = prior_draw<0>(d, e, t); return; }        // sample_Pn :12
+  for (int n = 0; n < N; ++n) {
+    const int e = k + K * n;
+    const double a_n = d.A[n];
+    if (a_n == 0.0) { if (tid == 0) d.P[e] = prior_draw<0>(d, e, t); continue; }          // sample_Pn :12
     const bool allzero = nzE[n] == 0;
-    double num1 = 0.0, den = 0.0;
-    if (!allzero) for (int s = 0; s < S; ++s) { num1 = num1 + part[((size_t)k * S + s) * 4]; den = den + part[((size_t)k * S + s) * 4 + 1]; }
-    const double pr = mh_prior_or_cond<0>(d, e, t, allzero, num1, den);
-    prop[k] = pr;
-    if (!converged) { d.P[e] = pr; if (accP) accP[e] = 1.0; }            // MH_Pn_poisson :201-204 (plain Gibbs for the Normal likelihood)
-  } else {
-    if (a_n == 0.0) return;
-    double A_ = 0.0, B_ = 0.0, C_ = 0.0, D_ = 0.0;
-    for (int s = 0; s < S; ++s) { const double* q = part + ((size_t)k * S + s) * 4; A_ = A_ + q[0]; B_ = B_ + q[1]; C_ = C_ + q[2]; D_ = D_ + q[3]; }
-    double ratio = dexp((A_ + B_) - (C_ + D_));
-    if (ratio > 1.0) ratio = 1.0;                                         // pmin(accept_ratio, 1) :239
-    accP[e] = ratio;
-    Stream s(d.k0, d.k1, BNMF_V_MHU_P, (uint32_t)e, t);
-    const double u = runif(s);
-    if (u < ratio) d.P[e] = prop[k];
+    const double pold = pa[n];                                                             // P[k,n] * A[n]
+    const double* En = d.Et + (size_t)G * n;
+    if (!allzero) {
+      for (int s = wave; s < S; s += MHP_W) {
+        const int g0 = s * MH_SEG, gend = min(G, g0 + MH_SEG);
+        double a0 = 0.0, a1 = 0.0;
+        for (int g = g0 + lane; g < gend; g += 64) {
+          const double en = En[g];
+          const double mh = row[g];
+          const double mno = mh - pold * en;                                               // Mhat_no_n
+          const double V = NORMAL ? d.sigmasq[g] : mh;                                     // sigmasq_kg :137-147
+          a0 = a0 + en * (((double)Mk[g] - mno) / V);                                      // :155-161
+          a1 = a1 + (a_n * (en * en)) * (1.0 / V);                                         // :163-169
+        }
+        a0 = wave_tree64(a0); a1 = wave_tree64(a1);
+        if (lane == 0) { part[s] = a0; part[S + s] = a1; }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double num1 = 0.0, den = 0.0;
+      if (!allzero) for (int s = 0; s < S; ++s) { num1 = num1 + part[s]; den = den + part[S + s]; }
+      bc[0] = mh_prior_or_cond<0>(d, e, t, allzero, num1, den);
+    }
+    __syncthreads();
+    const double pr = bc[0];
+    const double pnew = pr * a_n;
+    bool take = true;
+    if (mhstep) {                                                                          // MH_Pn_poisson :206-247
+      for (int s = wave; s < S; s += MHP_W) {
+        const int g0 = s * MH_SEG, gend = min(G, g0 + MH_SEG);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int g = g0 + lane; g < gend; g += 64) {
+          const double en = En[g];
+          const double m0 = row[g], m1 = (m0 - pold * en) + pnew * en;
+          const int m = Mk[g];
+          const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
+          const double lgf = d.lgfact[mi];
+          a0 = a0 + dpois_log(m, m1, lgf);                                                 // loglik_poisson_new :216-218
+          a1 = a1 + dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);                        // loglik_normal_old  :219-224
+          a2 = a2 + dpois_log(m, m0, lgf);                                                 // loglik_poisson_old :213-215
+          a3 = a3 + dnorm_log((double)m, m1, m0 < 1.0 ? 1.0 : m0);                        // loglik_normal_new  :225-231
+        }
+        a0 = wave_tree64(a0); a1 = wave_tree64(a1); a2 = wave_tree64(a2); a3 = wave_tree64(a3);
+        if (lane == 0) { part[s] = a0; part[S + s] = a1; part[2 * S + s] = a2; part[3 * S + s] = a3; }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double A_ = 0.0, B_ = 0.0, C_ = 0.0, D_ = 0.0;
+        for (int s = 0; s < S; ++s) { A_ = A_ + part[s]; B_ = B_ + part[S + s]; C_ = C_ + part[2 * S + s]; D_ = D_ + part[3 * S + s]; }
+        double ratio = dexp((A_ + B_) - (C_ + D_));
+        if (ratio > 1.0) ratio = 1.0;                                                      // pmin(accept_ratio, 1) :239
+        accP[e] = ratio;
+        Stream su(d.k0, d.k1, BNMF_V_MHU_P, (uint32_t)e, t);
+        bc[1] = (runif(su) < ratio) ? 1.0 : 0.0;
+      }
+      __syncthreads();
+      take = bc[1] != 0.0;
+    } else if (tid == 0 && accP) accP[e] = 1.0;                                            // :201-204
+    if (take) {
+      for (int s = wave; s < S; s += MHP_W) {
+        const int g0 = s * MH_SEG, gend = min(G, g0 + MH_SEG);
+        for (int g = g0 + lane; g < gend; g += 64) { const double en = En[g]; row[g] = (row[g] - pold * en) + pnew * en; }
+      }
+      if (tid == 0) { d.P[e] = pr; pa[n] = pnew; }
+    }
+    __syncthreads();                                      // part / bc are reused by the next factor
   }
 }
 
-// E side: one wave per column, all factors in order; METRICS_ONLY skips the updates (iteration 1).
+// ---- E side: one wave per column, all factors in order; METRICS_ONLY skips the updates (iteration 1) ----
+// The column's Mhat[., g] lives in the wave's LDS array mhc[K] (entry kk belongs to lane kk & 63) and is maintained
+// incrementally like the rows of the P side.
 constexpr int MHE_T = 256;
 template <bool METRICS_ONLY>
-__global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int converged, double* accE, int draw_sig) {
+__global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int mhstep, const int* nzP, double* accE, int draw_sig) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = d.K, G = d.G, N = d.N;
   const int KR = (K + 63) >> 6;
-  double* ec = (double*)smem + (size_t)wave * 2 * N;     // [N] current column of E
-  double* av = ec + N;                                     // [N] A
+  double* ec = (double*)smem + (size_t)wave * (2 * N + K);   // [N] current column of E
+  double* av = ec + N;                                        // [N] A
+  double* mhc = av + N;                                       // [K] Mhat[., g]
   const int gw = blockIdx.x * (MHE_T / 64) + wave, nw = gridDim.x * (MHE_T / 64);
   for (int g = gw; g < G; g += nw) {
     for (int j = lane; j < N; j += 64) { ec[j] = d.E[j + (size_t)N * g]; av[j] = d.A[j]; }
@@ -148,59 +191,73 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int conver
     const bool normal = d.likelihood == BNMF_NORMAL;
     double sg_col = normal ? d.sigmasq[g] : 1.0;
     if (!METRICS_ONLY) {
+      for (int r = 0; r < KR; ++r) {                          // fresh Mhat of the column
+        const int kk = (r << 6) + lane;
+        if (kk < K) {
+          double c = 0.0;
+          for (int j = 0; j < N; ++j) c = c + (d.P[kk + (size_t)K * j] * av[j]) * ec[j];
+          mhc[kk] = c;
+        }
+      }
       for (int n = 0; n < N; ++n) {
         const int e = n + N * g;
         const double a_n = av[n];
-        double enew;
-        if (a_n == 0.0) enew = prior_draw<1>(d, e, t);                    // sample_En :12
-        else {
-          double s1 = 0.0, s2 = 0.0;
-          bool anynz = false;
+        if (a_n == 0.0) {                                                                  // sample_En :12
+          const double x = prior_draw<1>(d, e, t);
+          if (lane == 0) { ec[n] = x; d.E[e] = x; }
+          continue;
+        }
+        const bool allzero = nzP[n] == 0;
+        const double eold = ec[n];
+        const double* Pn = d.P + (size_t)K * n;
+        double s1 = 0.0, s2 = 0.0;
+        if (!allzero) {
           for (int r = 0; r < KR; ++r) {
             const int kk = (r << 6) + lane;
             if (kk < K) {
-              const double pn = d.P[kk + (size_t)K * n];
-              anynz = anynz || (pn != 0.0);
-              double mh = 0.0, mno = 0.0;
-              for (int j = 0; j < N; ++j) { const double term = (d.P[kk + (size_t)K * j] * av[j]) * ec[j]; mh = mh + term; mno = mno + (j == n ? (d.P[kk + (size_t)K * j] * 0.0) * ec[j] : term); }
-              const int m = d.M[kk + (size_t)K * g];
+              const double pn = Pn[kk];
+              const double mh = mhc[kk];
+              const double mno = mh - (pn * a_n) * eold;
               const double V = normal ? sg_col : mh;
-              s1 = s1 + pn * (((double)m - mno) / V);
+              s1 = s1 + pn * (((double)d.M[kk + (size_t)K * g] - mno) / V);
               s2 = s2 + (a_n * (pn * pn)) * (1.0 / V);
             }
           }
-          const bool allzero = __ballot(anynz) == 0ull;
           s1 = __shfl(wave_tree64(s1), 0, 64); s2 = __shfl(wave_tree64(s2), 0, 64);
-          const double pr = mh_prior_or_cond<1>(d, e, t, allzero, allzero ? 0.0 : s1, allzero ? 0.0 : s2);
-          if (!converged) { enew = pr; if (lane == 0 && accE) accE[e] = 1.0; }
-          else {
-            const double eold = ec[n];
-            double A_ = 0.0, B_ = 0.0, C_ = 0.0, D_ = 0.0;
-            for (int r = 0; r < KR; ++r) {
-              const int kk = (r << 6) + lane;
-              if (kk < K) {
-                double m0 = 0.0, m1 = 0.0;
-                for (int j = 0; j < N; ++j) { const double pa = d.P[kk + (size_t)K * j] * av[j]; m0 = m0 + pa * ec[j]; m1 = m1 + pa * (j == n ? pr : ec[j]); }
-                const int m = d.M[kk + (size_t)K * g];
-                const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
-                const double lgf = d.lgfact[mi];
-                A_ = A_ + dpois_log(m, m1, lgf);
-                B_ = B_ + dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);
-                C_ = C_ + dpois_log(m, m0, lgf);
-                D_ = D_ + dnorm_log((double)m, m1, m0 < 1.0 ? 1.0 : m0);
-              }
-            }
-            A_ = __shfl(wave_tree64(A_), 0, 64); B_ = __shfl(wave_tree64(B_), 0, 64);
-            C_ = __shfl(wave_tree64(C_), 0, 64); D_ = __shfl(wave_tree64(D_), 0, 64);
-            double ratio = dexp((A_ + B_) - (C_ + D_));
-            if (ratio > 1.0) ratio = 1.0;
-            if (lane == 0) accE[e] = ratio;
-            Stream s(d.k0, d.k1, BNMF_V_MHU_E, (uint32_t)e, t);
-            const double u = runif(s);
-            enew = (u < ratio) ? pr : eold;
-          }
         }
-        if (lane == 0) { ec[n] = enew; d.E[e] = enew; }
+        const double pr = mh_prior_or_cond<1>(d, e, t, allzero, s1, s2);
+        bool take = true;
+        if (mhstep) {
+          double A_ = 0.0, B_ = 0.0, C_ = 0.0, D_ = 0.0;
+          for (int r = 0; r < KR; ++r) {
+            const int kk = (r << 6) + lane;
+            if (kk < K) {
+              const double pna = Pn[kk] * a_n;
+              const double m0 = mhc[kk], m1 = (m0 - pna * eold) + pna * pr;
+              const int m = d.M[kk + (size_t)K * g];
+              const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
+              const double lgf = d.lgfact[mi];
+              A_ = A_ + dpois_log(m, m1, lgf);
+              B_ = B_ + dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);
+              C_ = C_ + dpois_log(m, m0, lgf);
+              D_ = D_ + dnorm_log((double)m, m1, m0 < 1.0 ? 1.0 : m0);
+            }
+          }
+          A_ = __shfl(wave_tree64(A_), 0, 64); B_ = __shfl(wave_tree64(B_), 0, 64);
+          C_ = __shfl(wave_tree64(C_), 0, 64); D_ = __shfl(wave_tree64(D_), 0, 64);
+          double ratio = dexp((A_ + B_) - (C_ + D_));
+          if (ratio > 1.0) ratio = 1.0;
+          if (lane == 0) accE[e] = ratio;
+          Stream su(d.k0, d.k1, BNMF_V_MHU_E, (uint32_t)e, t);
+          take = runif(su) < ratio;
+        } else if (lane == 0 && accE) accE[e] = 1.0;
+        if (take) {
+          for (int r = 0; r < KR; ++r) {
+            const int kk = (r << 6) + lane;
+            if (kk < K) { const double pna = Pn[kk] * a_n; mhc[kk] = (mhc[kk] - pna * eold) + pna * pr; }
+          }
+          if (lane == 0) { ec[n] = pr; d.E[e] = pr; }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }

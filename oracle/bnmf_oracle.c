@@ -417,9 +417,25 @@ static double pois_ll_cell(int32_t m, double mhat) {
   double mh = mhat < 1e-6 ? 1e-6 : mhat;
   return ((double)m * orc_log(mh) - mh) - orc_lgamma((double)m + 1.0);
 }
-/* sample_An R/sample_params.R:101-166: for n = 1..N in order, two full Poisson log-likelihoods
- * (get_loglik(A = A0), get_loglik(A = A1), each with a fresh Mhat = P diag(A^j) E as in
- * get_Mhat_ R/utils.R:29-49), reduced canonically (64-strided over k, then 1024-strided over g). */
+/* sample_An R/sample_params.R:101-166, for n = 1..N in order.  R evaluates two full log-likelihoods per factor,
+ * get_loglik(A = A0) and get_loglik(A = A1), each from a BLAS product P diag(A^j) E.  Stream spec (same conditional,
+ * O(N K G) instead of O(N^2 K G)): Mhat = P diag(A) E is computed fresh (factor order, as get_Mhat_ R/utils.R:29-49)
+ * once at the start of the rank sweep and then maintained per cell; for factor n only the ALTERNATIVE state is
+ * evaluated, alt = Mhat -/+ P[k,n] E[n,g] (A[n] = 1 / 0 now), the log-likelihood of the current state being the one
+ * carried from the previous decision.  Sums: per column 64-strided over k + tree; blocks of 64 columns (W = 64);
+ * W = 1024 over the blocks. */
+static double ll_cell_rank(const orc_handle* o, int32_t m, double mhat, long g) {
+  if (o->cfg.likelihood == LIK_NORMAL) return dnorm_log_fwd((double)m, mhat, o->a[ID_SIGMASQ].p[g]);
+  return pois_ll_cell(m, mhat);
+}
+static double hsum_cols(const double* col, long G) {
+  long nb = (G + 63) / 64;
+  double* blk = (double*)malloc(8 * nb);
+  for (long b = 0; b < nb; ++b) blk[b] = orc_canon_sum(col + 64 * b, G - 64 * b < 64 ? G - 64 * b : 64, 1, 64);
+  double r = orc_canon_sum(blk, nb, 1, 1024);
+  free(blk);
+  return r;
+}
 static void sample_A(orc_handle* o, uint32_t t, int from_prior) {
   const long K = o->cfg.K, G = o->cfg.G, N = o->cfg.N;
   double pi1 = prior_prob_1((double)o->R, (double)N);
@@ -428,30 +444,35 @@ static void sample_A(orc_handle* o, uint32_t t, int from_prior) {
     return;
   }
   double T = temp_at(o, (int)t);
-  double* col0 = (double*)malloc(8 * G * 2);
-  double* col1 = col0 + G;
+  double* mh = (double*)malloc(8 * K * G);     /* [k + K g] */
+  double* col = (double*)malloc(8 * G);
+#pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
+  for (long g = 0; g < G; ++g) {
+    double l[4096];
+    for (long k = 0; k < K; ++k) {
+      double c = 0.0;
+      for (long j = 0; j < N; ++j) c = c + (AR(ID_P)[k + K * j] * AR(ID_A)[j]) * AR(ID_E)[j + N * g];
+      mh[k + K * g] = c;
+      l[k] = ll_cell_rank(o, o->M[k + K * g], c, g);
+    }
+    col[g] = orc_canon_sum(l, K, 1, 64);
+  }
+  double ll_cur = hsum_cols(col, G);
   for (long n = 0; n < N; ++n) {
     double a_old = AR(ID_A)[n];
 #pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
     for (long g = 0; g < G; ++g) {
-      double l0[4096], l1[4096];
+      double l[4096];
+      double en = AR(ID_E)[n + N * g];
       for (long k = 0; k < K; ++k) {
-        double c0 = 0.0, c1 = 0.0;
-        for (long j = 0; j < N; ++j) {
-          double pe = AR(ID_P)[k + K * j];
-          double e = AR(ID_E)[j + N * g];
-          double a0 = (j == n) ? 0.0 : AR(ID_A)[j], a1 = (j == n) ? 1.0 : AR(ID_A)[j];
-          c0 = c0 + (pe * a0) * e;
-          c1 = c1 + (pe * a1) * e;
-        }
-        int32_t m = o->M[k + K * g];
-        if (o->cfg.likelihood == LIK_NORMAL) { double sg = AR(ID_SIGMASQ)[g]; l0[k] = dnorm_log_fwd((double)m, c0, sg); l1[k] = dnorm_log_fwd((double)m, c1, sg); }
-        else { l0[k] = pois_ll_cell(m, c0); l1[k] = pois_ll_cell(m, c1); }
+        double tt = AR(ID_P)[k + K * n] * en;
+        double alt = (a_old == 1.0) ? mh[k + K * g] - tt : mh[k + K * g] + tt;
+        l[k] = ll_cell_rank(o, o->M[k + K * g], alt, g);
       }
-      col0[g] = orc_canon_sum(l0, K, 1, 64);
-      col1[g] = orc_canon_sum(l1, K, 1, 64);
+      col[g] = orc_canon_sum(l, K, 1, 64);
     }
-    double ll0 = orc_canon_sum(col0, G, 1, 1024), ll1 = orc_canon_sum(col1, G, 1, 1024);
+    double ll_alt = hsum_cols(col, G);
+    double ll0 = (a_old == 1.0) ? ll_alt : ll_cur, ll1 = (a_old == 1.0) ? ll_cur : ll_alt;
     double sumA = 0.0;
     for (long j = 0; j < N; ++j) sumA = sumA + AR(ID_A)[j];
     double sumA0 = sumA - a_old, sumA1 = sumA0 + 1.0;
@@ -471,18 +492,35 @@ static void sample_A(orc_handle* o, uint32_t t, int from_prior) {
       else if (lp1 > lp0) p = 1.0; else if (lp1 < lp0) p = 0.0; else p = 0.5;
     }
     orc_stream s = ST(o, V_A, (uint32_t)n, t);
-    AR(ID_A)[n] = (orc_runif(&s) < p) ? 1.0 : 0.0;
+    double a_new = (orc_runif(&s) < p) ? 1.0 : 0.0;
+    if (a_new != a_old) {
+#pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
+      for (long g = 0; g < G; ++g) {
+        double en = AR(ID_E)[n + N * g];
+        for (long k = 0; k < K; ++k) {
+          double tt = AR(ID_P)[k + K * n] * en;
+          mh[k + K * g] = (a_old == 1.0) ? mh[k + K * g] - tt : mh[k + K * g] + tt;
+        }
+      }
+      ll_cur = ll_alt;
+    }
+    AR(ID_A)[n] = a_new;
   }
-  free(col0);
+  free(mh); free(col);
 }
 
-/* ================= Poisson likelihood with Metropolis-Hastings (truncnormal / exponential prior) =====
- * sample_Pn -> sample_Pn_normal(as_proposal = TRUE) -> MH_Pn_poisson (R/sample_Pn.R:11-42, :54-87,
- * :132-187, :199-248) and the E mirror (R/sample_En.R).  Columns/rows are updated for n = 1..N in order;
- * every evaluation uses a FRESH Mhat = P diag(A) E of the current state, as get_Mhat() does.
- * Canonical sums: over k (column sums) 64-strided + tree; over g (row sums) segments of 512 columns,
- * each 64-strided + tree, segments added in ascending order. */
-#define ORC_SEG 512
+/* ================= Poisson likelihood with Metropolis-Hastings (truncnormal / exponential prior), and the
+ * Normal likelihood (plain Gibbs) =====
+ * sample_Pn -> sample_Pn_normal(as_proposal) -> MH_Pn_poisson (R/sample_Pn.R:11-42, :54-87, :132-187, :199-248) and
+ * the E mirror (R/sample_En.R); sample_sigmasq R/sample_params.R:275-286.  Columns/rows are updated for n = 1..N in
+ * order.  R recomputes Mhat = P diag(A) E (and Mhat with A[n] = 0) by BLAS products at every step.  Stream spec (same
+ * conditionals, O(N K G) instead of O(N^2 K G)): Mhat is computed fresh (factor order) at the start of the P sweep
+ * and again at the start of the E sweep, then maintained per cell: Mhat_no_n = Mhat - (P[k,n] A[n]) E[n,g], and after
+ * the update of factor n, Mhat = Mhat_no_n + (P_new[k,n] A[n]) E[n,g].  Rows of P are mutually independent within the
+ * P sweep, columns of E within the E sweep.
+ * Canonical sums: over k (column sums) 64-strided + tree; over g (row sums) segments of 320 columns, each
+ * 64-strided + tree, segments added in ascending order. */
+#define ORC_SEG 320
 static double canon_rowsum(const double* x /* G values */, long G) {
   double acc = 0.0;
   for (long s0 = 0; s0 < G; s0 += ORC_SEG) {
@@ -524,115 +562,140 @@ static void mh_prior_or_cond(orc_handle* o, int side, long e, uint32_t t, int us
   orc_stream s = ST(o, side ? V_E : V_P, (uint32_t)e, t);
   *out = orc_rtnorm0(&s, mu, sqrt(var));
 }
-static void sample_P_mh(orc_handle* o, uint32_t t) {
+/* P sweep: rows are independent, so each row k runs its N sequential updates on its own maintained Mhat[k, .] */
+static void sample_P_seq(orc_handle* o, uint32_t t) {
   const long K = o->cfg.K, G = o->cfg.G, N = o->cfg.N;
+  const int normal = o->cfg.likelihood == LIK_NORMAL;
+  const int mhstep = o->cfg.MH && o->converged && !normal;       /* true accept/reject (MH_Pn_poisson :206-247) */
   double* P = AR(ID_P);
-  double* acc = ensure(o, ID_ACC_P);
-  double* tmp = (double*)malloc(8 * G * 6 * (size_t)(o->cfg.nthreads > 0 ? o->cfg.nthreads : 1));
-  double* prop = (double*)malloc(8 * K);
-  for (long n = 0; n < N; ++n) {
-    double a_n = AR(ID_A)[n];
-    if (a_n == 0.0) { for (long k = 0; k < K; ++k) P[k + K * n] = prior_draw(o, 0, k + K * n, t); continue; }   /* sample_Pn :12 */
-    int allzero = 1;
-    for (long g = 0; g < G; ++g) if (AR(ID_E)[n + N * g] != 0.0) { allzero = 0; break; }
-#pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
-    for (long k = 0; k < K; ++k) {
-      int tid = 0;
+  double* acc = o->cfg.MH ? ensure(o, ID_ACC_P) : NULL;
+  const int nth = o->cfg.nthreads > 0 ? o->cfg.nthreads : 1;
+  double* tmp = (double*)malloc(8 * (size_t)G * 7 * (size_t)nth);
+  int* allzero = (int*)malloc(sizeof(int) * N);
+  for (long n = 0; n < N; ++n) {                                    /* all(E[n,] == 0): E is fixed during the P sweep */
+    allzero[n] = 1;
+    for (long g = 0; g < G; ++g) if (AR(ID_E)[n + N * g] != 0.0) { allzero[n] = 0; break; }
+  }
+#pragma omp parallel for schedule(static) num_threads(nth)
+  for (long k = 0; k < K; ++k) {
+    int tid = 0;
 #ifdef _OPENMP
-      tid = omp_get_thread_num();
+    tid = omp_get_thread_num();
 #endif
-      double* x1 = tmp + (size_t)tid * 6 * G; double* x2 = x1 + G;
+    double* row = tmp + (size_t)tid * 7 * G; double* x1 = row + G; double* x2 = x1 + G; double* y = x2 + G;
+    for (long g = 0; g < G; ++g) row[g] = mhat_cell(o, k, g, -1, NULL, 0);         /* fresh at the start of the sweep */
+    for (long n = 0; n < N; ++n) {
+      const long e = k + K * n;
+      const double a_n = AR(ID_A)[n];
+      if (a_n == 0.0) { P[e] = prior_draw(o, 0, e, t); continue; }                /* sample_Pn :12; term of Mhat is 0 */
+      const double pa = P[e] * a_n;
       double num1 = 0.0, den = 0.0;
-      if (!allzero) {
+      if (!allzero[n]) {
         for (long g = 0; g < G; ++g) {
-          double mh = mhat_cell(o, k, g, -1, NULL, 0), mno = mhat_cell(o, k, g, n, NULL, 0);
           double en = AR(ID_E)[n + N * g];
-          x1[g] = en * (((double)o->M[k + K * g] - mno) / mh);        /* :155-161 */
-          x2[g] = (a_n * (en * en)) * (1.0 / mh);                      /* :163-169 */
+          double mno = row[g] - pa * en;                                           /* Mhat_no_n */
+          double V = normal ? AR(ID_SIGMASQ)[g] : row[g];                          /* sigmasq_kg :137-147 */
+          x1[g] = en * (((double)o->M[k + K * g] - mno) / V);                      /* :155-161 */
+          x2[g] = (a_n * (en * en)) * (1.0 / V);                                   /* :163-169 */
         }
         num1 = canon_rowsum(x1, G); den = canon_rowsum(x2, G);
       }
-      mh_prior_or_cond(o, 0, k + K * n, t, allzero, num1, den, &prop[k]);
-    }
-    if (!o->converged) {                                               /* MH_Pn_poisson :201-204 */
-      for (long k = 0; k < K; ++k) { P[k + K * n] = prop[k]; acc[k + K * n] = 1.0; }
-      continue;
-    }
-#pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
-    for (long k = 0; k < K; ++k) {
-      int tid = 0;
-#ifdef _OPENMP
-      tid = omp_get_thread_num();
-#endif
-      double* y = tmp + (size_t)tid * 6 * G;
-      for (long g = 0; g < G; ++g) {
-        double m0 = mhat_cell(o, k, g, -1, NULL, 0), m1 = mhat_cell(o, k, g, -1, &prop[k], n);
-        int32_t m = o->M[k + K * g];
-        y[g] = dpois_log(m, m1);                                       /* loglik_poisson_new :216-218 */
-        y[G + g] = dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);     /* loglik_normal_old :219-224 */
-        y[2 * G + g] = dpois_log(m, m0);                               /* loglik_poisson_old :213-215 */
-        y[3 * G + g] = dnorm_log((double)m, m1, m0 < 1.0 ? 1.0 : m0); /* loglik_normal_new :225-231 */
+      double pr;
+      mh_prior_or_cond(o, 0, e, t, allzero[n], num1, den, &pr);
+      const double pra = pr * a_n;
+      int take = 1;
+      if (!mhstep) { if (acc) acc[e] = 1.0; }                                      /* MH_Pn_poisson :201-204 / plain Gibbs */
+      else {
+        for (long g = 0; g < G; ++g) {
+          double en = AR(ID_E)[n + N * g];
+          double m0 = row[g], m1 = (m0 - pa * en) + pra * en;
+          int32_t m = o->M[k + K * g];
+          y[g] = dpois_log(m, m1);                                       /* loglik_poisson_new :216-218 */
+          y[G + g] = dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);     /* loglik_normal_old :219-224 */
+          y[2 * G + g] = dpois_log(m, m0);                               /* loglik_poisson_old :213-215 */
+          y[3 * G + g] = dnorm_log((double)m, m1, m0 < 1.0 ? 1.0 : m0); /* loglik_normal_new :225-231 */
+        }
+        double A_ = canon_rowsum(y, G), B_ = canon_rowsum(y + G, G), C_ = canon_rowsum(y + 2 * G, G), D_ = canon_rowsum(y + 3 * G, G);
+        double ratio = orc_exp((A_ + B_) - (C_ + D_));
+        if (ratio > 1.0) ratio = 1.0;                                    /* pmin(accept_ratio, 1) :239 */
+        acc[e] = ratio;
+        orc_stream s = ST(o, V_MHU_P, (uint32_t)e, t);
+        take = orc_runif(&s) < ratio;
       }
-      double A_ = canon_rowsum(y, G), B_ = canon_rowsum(y + G, G), C_ = canon_rowsum(y + 2 * G, G), D_ = canon_rowsum(y + 3 * G, G);
-      double ratio = orc_exp((A_ + B_) - (C_ + D_));
-      if (ratio > 1.0) ratio = 1.0;                                    /* pmin(accept_ratio, 1) :239 */
-      acc[k + K * n] = ratio;
-      orc_stream s = ST(o, V_MHU_P, (uint32_t)(k + K * n), t);
-      double u = orc_runif(&s);
-      prop[k] = (u < ratio) ? prop[k] : P[k + K * n];
+      if (take) {
+        P[e] = pr;
+        for (long g = 0; g < G; ++g) { double en = AR(ID_E)[n + N * g]; row[g] = (row[g] - pa * en) + pra * en; }
+      }
     }
-    for (long k = 0; k < K; ++k) P[k + K * n] = prop[k];
   }
-  free(tmp); free(prop);
+  free(tmp); free(allzero);
 }
-static void sample_E_mh(orc_handle* o, uint32_t t) {
+/* E sweep: columns are independent; column g keeps Mhat[., g] */
+static void sample_E_seq(orc_handle* o, uint32_t t) {
   const long K = o->cfg.K, G = o->cfg.G, N = o->cfg.N;
+  const int normal = o->cfg.likelihood == LIK_NORMAL;
+  const int mhstep = o->cfg.MH && o->converged && !normal;
   double* E = AR(ID_E);
-  double* acc = ensure(o, ID_ACC_E);
-  for (long n = 0; n < N; ++n) {
-    double a_n = AR(ID_A)[n];
-    int allzero = 1;
-    for (long k = 0; k < K; ++k) if (AR(ID_P)[k + K * n] != 0.0) { allzero = 0; break; }
+  double* acc = o->cfg.MH ? ensure(o, ID_ACC_E) : NULL;
+  int* allzero = (int*)malloc(sizeof(int) * N);
+  for (long n = 0; n < N; ++n) {                                    /* all(P[,n] == 0): P is fixed during the E sweep */
+    allzero[n] = 1;
+    for (long k = 0; k < K; ++k) if (AR(ID_P)[k + K * n] != 0.0) { allzero[n] = 0; break; }
+  }
 #pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
-    for (long g = 0; g < G; ++g) {
-      long e = n + N * g;
+  for (long g = 0; g < G; ++g) {
+    double mhc[4096], x1[4096], x2[4096], y[4 * 4096];
+    for (long k = 0; k < K; ++k) mhc[k] = mhat_cell(o, k, g, -1, NULL, 0);
+    const double sg = normal ? AR(ID_SIGMASQ)[g] : 1.0;
+    for (long n = 0; n < N; ++n) {
+      const long e = n + N * g;
+      const double a_n = AR(ID_A)[n];
       if (a_n == 0.0) { E[e] = prior_draw(o, 1, e, t); continue; }     /* sample_En :12 */
-      double x1[4096], x2[4096], y[4 * 4096];
+      const double eold = E[e];
       double num1 = 0.0, den = 0.0;
-      if (!allzero) {
+      if (!allzero[n]) {
         for (long k = 0; k < K; ++k) {
-          double mh = mhat_cell(o, k, g, -1, NULL, 0), mno = mhat_cell(o, k, g, n, NULL, 0);
           double pn = AR(ID_P)[k + K * n];
-          x1[k] = pn * (((double)o->M[k + K * g] - mno) / mh);
-          x2[k] = (a_n * (pn * pn)) * (1.0 / mh);
+          double mno = mhc[k] - (pn * a_n) * eold;
+          double V = normal ? sg : mhc[k];
+          x1[k] = pn * (((double)o->M[k + K * g] - mno) / V);
+          x2[k] = (a_n * (pn * pn)) * (1.0 / V);
         }
         num1 = orc_canon_sum(x1, K, 1, 64); den = orc_canon_sum(x2, K, 1, 64);
       }
-      double prop;
-      mh_prior_or_cond(o, 1, e, t, allzero, num1, den, &prop);
-      if (!o->converged) { E[e] = prop; acc[e] = 1.0; continue; }
-      double eold = E[e];
-      for (long k = 0; k < K; ++k) {
-        double m0 = mhat_cell(o, k, g, -1, NULL, 0);
-        E[e] = prop;
-        double m1 = mhat_cell(o, k, g, -1, NULL, 0);
-        E[e] = eold;
-        int32_t m = o->M[k + K * g];
-        y[k] = dpois_log(m, m1);
-        y[K + k] = dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);
-        y[2 * K + k] = dpois_log(m, m0);
-        y[3 * K + k] = dnorm_log((double)m, m1, m0 < 1.0 ? 1.0 : m0);
+      double pr;
+      mh_prior_or_cond(o, 1, e, t, allzero[n], num1, den, &pr);
+      int take = 1;
+      if (!mhstep) { if (acc) acc[e] = 1.0; }
+      else {
+        for (long k = 0; k < K; ++k) {
+          double pna = AR(ID_P)[k + K * n] * a_n;
+          double m0 = mhc[k], m1 = (m0 - pna * eold) + pna * pr;
+          int32_t m = o->M[k + K * g];
+          y[k] = dpois_log(m, m1);
+          y[K + k] = dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);
+          y[2 * K + k] = dpois_log(m, m0);
+          y[3 * K + k] = dnorm_log((double)m, m1, m0 < 1.0 ? 1.0 : m0);
+        }
+        double A_ = orc_canon_sum(y, K, 1, 64), B_ = orc_canon_sum(y + K, K, 1, 64), C_ = orc_canon_sum(y + 2 * K, K, 1, 64), D_ = orc_canon_sum(y + 3 * K, K, 1, 64);
+        double ratio = orc_exp((A_ + B_) - (C_ + D_));
+        if (ratio > 1.0) ratio = 1.0;
+        acc[e] = ratio;
+        orc_stream s = ST(o, V_MHU_E, (uint32_t)e, t);
+        take = orc_runif(&s) < ratio;
       }
-      double A_ = orc_canon_sum(y, K, 1, 64), B_ = orc_canon_sum(y + K, K, 1, 64), C_ = orc_canon_sum(y + 2 * K, K, 1, 64), D_ = orc_canon_sum(y + 3 * K, K, 1, 64);
-      double ratio = orc_exp((A_ + B_) - (C_ + D_));
-      if (ratio > 1.0) ratio = 1.0;
-      acc[e] = ratio;
-      orc_stream s = ST(o, V_MHU_E, (uint32_t)e, t);
-      double u = orc_runif(&s);
-      E[e] = (u < ratio) ? prop : eold;
+      if (take) {
+        E[e] = pr;
+        for (long k = 0; k < K; ++k) { double pna = AR(ID_P)[k + K * n] * a_n; mhc[k] = (mhc[k] - pna * eold) + pna * pr; }
+      }
     }
   }
+  free(allzero);
 }
+static void sample_P_mh(orc_handle* o, uint32_t t) { sample_P_seq(o, t); }
+static void sample_E_mh(orc_handle* o, uint32_t t) { sample_E_seq(o, t); }
+static void sample_P_normal(orc_handle* o, uint32_t t) { sample_P_seq(o, t); }
+static void sample_E_normal(orc_handle* o, uint32_t t) { sample_E_seq(o, t); }
 /* per-cell metric terms for the models without Z (fresh Mhat) */
 static void metrics_cells_mh(orc_handle* o) {
   const long K = o->cfg.K, G = o->cfg.G;
@@ -646,72 +709,7 @@ static void metrics_cells_mh(orc_handle* o) {
   }
 }
 
-/* ================= Normal likelihood (priors truncnormal / exponential), plain Gibbs =================
- * sample_Pn_normal(as_proposal = FALSE) R/sample_Pn.R:54-87 with sigmasq_kg = sigmasq_g (:140-147),
- * the E mirror R/sample_En.R:54-86, and sample_sigmasq R/sample_params.R:275-286. */
-static void sample_P_normal(orc_handle* o, uint32_t t) {
-  const long K = o->cfg.K, G = o->cfg.G, N = o->cfg.N;
-  double* P = AR(ID_P);
-  double* tmp = (double*)malloc(8 * G * 2 * (size_t)(o->cfg.nthreads > 0 ? o->cfg.nthreads : 1));
-  for (long n = 0; n < N; ++n) {
-    double a_n = AR(ID_A)[n];
-    if (a_n == 0.0) { for (long k = 0; k < K; ++k) P[k + K * n] = prior_draw(o, 0, k + K * n, t); continue; }
-    int allzero = 1;
-    for (long g = 0; g < G; ++g) if (AR(ID_E)[n + N * g] != 0.0) { allzero = 0; break; }
-    double* newcol = (double*)malloc(8 * K);
-#pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
-    for (long k = 0; k < K; ++k) {
-      int tid = 0;
-#ifdef _OPENMP
-      tid = omp_get_thread_num();
-#endif
-      double* x1 = tmp + (size_t)tid * 2 * G; double* x2 = x1 + G;
-      double num1 = 0.0, den = 0.0;
-      if (!allzero) {
-        for (long g = 0; g < G; ++g) {
-          double mno = mhat_cell(o, k, g, n, NULL, 0), sg = AR(ID_SIGMASQ)[g];
-          double en = AR(ID_E)[n + N * g];
-          x1[g] = en * (((double)o->M[k + K * g] - mno) / sg);
-          x2[g] = (a_n * (en * en)) * (1.0 / sg);
-        }
-        num1 = canon_rowsum(x1, G); den = canon_rowsum(x2, G);
-      }
-      mh_prior_or_cond(o, 0, k + K * n, t, allzero, num1, den, &newcol[k]);
-    }
-    for (long k = 0; k < K; ++k) P[k + K * n] = newcol[k];
-    free(newcol);
-  }
-  free(tmp);
-}
-static void sample_E_normal(orc_handle* o, uint32_t t) {
-  const long K = o->cfg.K, G = o->cfg.G, N = o->cfg.N;
-  double* E = AR(ID_E);
-  for (long n = 0; n < N; ++n) {
-    double a_n = AR(ID_A)[n];
-    int allzero = 1;
-    for (long k = 0; k < K; ++k) if (AR(ID_P)[k + K * n] != 0.0) { allzero = 0; break; }
-#pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
-    for (long g = 0; g < G; ++g) {
-      long e = n + N * g;
-      if (a_n == 0.0) { E[e] = prior_draw(o, 1, e, t); continue; }
-      double x1[4096], x2[4096];
-      double num1 = 0.0, den = 0.0;
-      if (!allzero) {
-        double sg = AR(ID_SIGMASQ)[g];
-        for (long k = 0; k < K; ++k) {
-          double mno = mhat_cell(o, k, g, n, NULL, 0);
-          double pn = AR(ID_P)[k + K * n];
-          x1[k] = pn * (((double)o->M[k + K * g] - mno) / sg);
-          x2[k] = (a_n * (pn * pn)) * (1.0 / sg);
-        }
-        num1 = orc_canon_sum(x1, K, 1, 64); den = orc_canon_sum(x2, K, 1, 64);
-      }
-      double v;
-      mh_prior_or_cond(o, 1, e, t, allzero, num1, den, &v);
-      E[e] = v;
-    }
-  }
-}
+/* ================= Normal likelihood: sample_sigmasq R/sample_params.R:275-286 and its metrics ================= */
 static void sample_sigmasq(orc_handle* o, uint32_t t) {
   const long K = o->cfg.K, G = o->cfg.G;
 #pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)

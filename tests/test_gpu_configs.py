@@ -51,6 +51,29 @@ def test_config4_learned_rank_N50_bitexact():
     assert saw_zero, "the run never excluded a factor: the zero-probability path was not exercised"
 
 
+@pytest.mark.parametrize("K,G,N,lik,prior,MH", [(200, 30, 6, "poisson", "gamma", False), (130, 700, 5, "poisson", "truncnormal", True),
+                                                 (70, 40, 4, "normal", "exponential", False)])
+def test_rank_sweep_general_path_bitexact(K, G, N, lik, prior, MH):
+    """The persistent rank sweep outside its register-resident fast path (K > 128: Mhat in global scratch), with the
+    MH and Normal models (Normal log-likelihood in sample_An), and G spanning several 320-column segments."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    rng = np.random.default_rng(K)
+    M = rng.poisson(rng.gamma(1.0, 15.0, size=(K, G))).astype(np.int32)
+    temp = _temp_schedule(100)
+    kw = dict(likelihood=lik, MH=MH, learning_rank=True, seed=17, temperature=temp)
+    o = _mk(O.Oracle, M, N, prior, nthreads=8, **kw)
+    e = _mk(Engine, M, N, prior, **kw)
+    o.init(); e.init()
+    for step in range(3):
+        mo, me = o.run(15), e.run(15)
+        assert np.array_equal(o.get("A"), e.get("A")), step
+        for nm in ("P", "E"):
+            assert np.array_equal(o.get(nm).view(np.uint64), e.get(nm).view(np.uint64)), (nm, step)
+        assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), step
+    e.close()
+
+
 def test_config4_full_size_properties():
     """Config 4 at full size (K = 96, G = 10,000, N = 50, SBFI): sum_n Z = M for every cell, Z = 0 wherever
     A[n] = 0, marginals consistent."""
