@@ -49,7 +49,7 @@ struct bnmf_handle {
   int* dR = nullptr; int* dRedraw = nullptr;
   double *dEsum = nullptr, *dPsum = nullptr, *dlpPn = nullptr, *dlpE = nullptr, *dcol = nullptr;
   double *dLut = nullptr, *dTemp = nullptr, *dMetrics = nullptr, *dRaw = nullptr, *dRankCol = nullptr, *dRankMhat = nullptr;
-  uint32_t* dRankSync = nullptr; int rank_grid = 0; bool rank_reg = false;
+  uint32_t* dRankSync = nullptr; int rank_grid = 0; bool rank_reg = false; void* dRankDbg = nullptr;
   int32_t* dMt = nullptr; double* dEt = nullptr;
   double *dMhat = nullptr, *dAccPn = nullptr, *dAccEpart = nullptr; int* dNzE = nullptr; int mh_S = 1; size_t mhe_lds = 0;
   size_t metrics_rows = 0;
@@ -209,17 +209,39 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   HIPCHK(hipMalloc(&h->dlpE, 3 * (size_t)h->nblkE * sizeof(double)));
   HIPCHK(hipMalloc(&h->dcol, 3 * 3 * G * sizeof(double)));   // per-column partials, 3 slots (t % 3)
   if (cfg->learning_rank) {
-    HIPCHK(hipMalloc(&h->dRankCol, 2 * G * sizeof(double)));
+    const size_t gran_words = 2 * 2 * ((G + RK_MAXC - 1) / RK_MAXC);        // [2 parities][2 granules per block sum]
+    HIPCHK(hipMalloc(&h->dRankCol, gran_words * sizeof(double)));
+    HIPCHK(hipMemset(h->dRankCol, 0, gran_words * sizeof(double)));           // tag 0 is never used
+    if (((size_t)N + (G + RK_MAXC - 1) / RK_MAXC) * sizeof(double) > 60 * 1024) {
+      HIPCHK(hipFuncSetAttribute((const void*)k_rank_sweep<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)k_rank_sweep<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)k_rank_sweep<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)k_rank_sweep<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    }
     HIPCHK(hipMalloc(&h->dRankSync, 32));
     HIPCHK(hipMemset(h->dRankSync, 0, 32));
-    // grid of the persistent rank sweep: co-resident by construction (at most one 512-lane workgroup per CU)
+    // grid of the persistent rank sweep: co-resident by construction (one 512-lane workgroup per CU)
     hipDeviceProp_t prop0;
     HIPCHK(hipGetDeviceProperties(&prop0, cfg->device));
-    const long wg_needed = ((long)G + RK_W - 1) / RK_W;
-    h->rank_grid = (int)std::min<long>(wg_needed, prop0.multiProcessorCount);
-    const long cols_per_wave = ((long)G + (long)h->rank_grid * RK_W - 1) / ((long)h->rank_grid * RK_W);
-    h->rank_reg = K <= 128 && cols_per_wave <= RK_MAXC;
+    const long NB = ((long)G + RK_MAXC - 1) / RK_MAXC;                 // blocks of 8 columns, one wave each
+    const long wg_needed = (NB + RK_W - 1) / RK_W;
+    // every workgroup of the sweep waits for all others: the grid must be co-resident.  Ask the runtime how many
+    // workgroups of each variant fit a CU (registers, LDS); where the answer is SGPR-limited (>= 6 per CU) the query can
+    // be one high (MI355X_MICROARCH.md), so one is kept in reserve there; never plan more than two per CU.  Should the
+    // grid still not be co-resident, the bounded spins time out and bnmf_run reports it (no hang).
+    const size_t rlds = ((size_t)N + NB) * sizeof(double);
+    auto fit = [&](const void* fn) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, RK_T, rlds) != hipSuccess || nb < 1) nb = 1;
+      return std::min(1, nb >= 6 ? nb - 1 : nb);          // one per CU: even compute times, and co-resident with margin
+    };
+    const bool nrm0 = cfg->likelihood == BNMF_NORMAL;
+    const long cap_reg = (long)fit(nrm0 ? (const void*)k_rank_sweep<true, true> : (const void*)k_rank_sweep<true, false>) * prop0.multiProcessorCount;
+    const long cap_gen = (long)fit(nrm0 ? (const void*)k_rank_sweep<false, true> : (const void*)k_rank_sweep<false, false>) * prop0.multiProcessorCount;
+    h->rank_reg = K <= 128 && wg_needed <= cap_reg;
+    h->rank_grid = (int)std::min<long>(wg_needed, h->rank_reg ? cap_reg : cap_gen);
     if (!h->rank_reg) HIPCHK(hipMalloc(&h->dRankMhat, K * G * sizeof(double)));
+    if (getenv("BNMF_RANKDBG")) { HIPCHK(hipMalloc(&h->dRankDbg, (size_t)h->rank_grid * 16 * 8 * 8)); HIPCHK(hipMemset(h->dRankDbg, 0, (size_t)h->rank_grid * 16 * 8 * 8)); }   // diagnostics only
   }
   if (cfg->MH || cfg->likelihood == BNMF_NORMAL) {
     h->mh_S = (int)((G + MH_SEG - 1) / MH_SEG);
@@ -426,6 +448,11 @@ int bnmf_get_array_i32(bnmf_handle* h, int id, int32_t* out, size_t n) {
   return 0;
 }
 
+int bnmf_debug_rank(bnmf_handle* h, unsigned long long* out, size_t n) {   // diagnostics: phase time stamps of k_rank_sweep
+  if (!h || !h->dRankDbg) return fail(BNMF_ESTATE, "BNMF_RANKDBG not set");
+  HIPCHK(hipMemcpy(out, h->dRankDbg, n * 8, hipMemcpyDeviceToHost));
+  return h->rank_grid;
+}
 int bnmf_get_iter(bnmf_handle* h, int* iter) { if (!h || !iter) return fail(BNMF_EINVAL, "null"); *iter = h->iter; return 0; }
 
 }  // extern "C"
@@ -575,11 +602,15 @@ static int launch_zalloc(bnmf_handle* h, uint32_t t) {
 // sample_R then sample_An for n = 1..N (R/sample_params.R:67-74): one persistent launch for the N sequential updates
 static void launch_rank(bnmf_handle* h, uint32_t t) {
   const int N = h->cfg.N;
-  hipLaunchKernelGGL(k_rank_R, dim3(1), dim3(64), 0, h->stream, h->dev, t, 0);
-  hipMemsetAsync(h->dRankSync, 0, 16, h->stream);          // the barrier counter (the time-out flag at +16 is sticky)
-  const size_t lds = (size_t)N * sizeof(double);
-  if (h->rank_reg) hipLaunchKernelGGL(k_rank_sweep<true>, dim3(h->rank_grid), dim3(RK_T), lds, h->stream, h->dev, t, h->dRankCol, (unsigned*)h->dRankSync, (int*)(h->dRankSync + 4), h->dRankMhat);
-  else hipLaunchKernelGGL(k_rank_sweep<false>, dim3(h->rank_grid), dim3(RK_T), lds, h->stream, h->dev, t, h->dRankCol, (unsigned*)h->dRankSync, (int*)(h->dRankSync + 4), h->dRankMhat);
+  hipLaunchKernelGGL(k_rank_R, dim3(1), dim3(64), (size_t)(N + 1) * sizeof(double), h->stream, h->dev, t, 0);
+  const int NB = (h->cfg.G + RK_MAXC - 1) / RK_MAXC;
+  const size_t lds = ((size_t)N + NB) * sizeof(double);
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(h->rank_grid), dim3(RK_T), lds, h->stream, h->dev, t, (unsigned long long*)h->dRankCol, NB, (int*)(h->dRankSync + 4), h->dRankMhat, (unsigned long long*)h->dRankDbg);
+  };
+  const bool nrm = h->cfg.likelihood == BNMF_NORMAL;
+  if (h->rank_reg) { if (nrm) go(k_rank_sweep<true, true>); else go(k_rank_sweep<true, false>); }
+  else { if (nrm) go(k_rank_sweep<false, true>); else go(k_rank_sweep<false, false>); }
 }
 // ids recorded per iteration (names(self$params) + names(self$prior_params), R/bayesNMF_sampler.R:245-252)
 static std::vector<int> recorded_ids(const bnmf_handle* h) {
@@ -791,7 +822,7 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
   launch_edraw(h, 1u, haveE ? 2 : 1, false);                // (iteration 1 is recorded by k_record below, every model)
   launch_side(h, 2u, tm);
   if (!haveA && c.learning_rank) {                            // R ~ Uniform{0..N}, A[n] ~ Bernoulli(pi(R))
-    hipLaunchKernelGGL(k_rank_R, dim3(1), dim3(64), 0, h->stream, h->dev, 1u, 1);
+    hipLaunchKernelGGL(k_rank_R, dim3(1), dim3(64), (size_t)(N + 1) * sizeof(double), h->stream, h->dev, 1u, 1);
     hipLaunchKernelGGL(k_rank_Aprior, dim3((N + 63) / 64), dim3(64), 0, h->stream, h->dev, 1u);
   }
   if (c.MH || c.likelihood == BNMF_NORMAL) launch_mh_metrics(h, 1u, true);

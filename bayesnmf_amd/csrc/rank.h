@@ -23,29 +23,31 @@ BNMF_DEV double temp_at(const Dev& d, uint32_t t) {
   return d.temperature[i];
 }
 
-// sample_R :217-241 (one lane; N+1 weights)
-__global__ void k_rank_R(Dev d, uint32_t t, int from_prior) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int N = d.N;
+// sample_R :217-241: the N+1 weights are evaluated one per lane, then added and scanned in r order by lane 0
+__global__ __launch_bounds__(64) void k_rank_R(Dev d, uint32_t t, int from_prior) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* w = (double*)smem;                             // [N+1]
+  if (blockIdx.x != 0) return;
+  const int N = d.N, lane = threadIdx.x;
   Stream s(d.k0, d.k1, BNMF_V_R, 0u, t);
   const double u = runif(s);
-  if (from_prior) { int r = (int)(u * (double)(N + 1)); if (r > N) r = N; *d.R = r; return; }
+  if (from_prior) { if (lane == 0) { int r = (int)(u * (double)(N + 1)); if (r > N) r = N; *d.R = r; } return; }
   const double T = temp_at(d, t);
   double sumA = 0.0;
   for (int n = 0; n < N; ++n) sumA = sumA + d.A[n];
-  double tot = 0.0;
-  for (int r = 0; r <= N; ++r) {
+  for (int r = lane; r <= N; r += 64) {
     const double p1 = prior_prob_1((double)r, (double)N);
-    tot = tot + dexp(T * (sumA * dlog(p1) + ((double)N - sumA) * dlog(1.0 - p1)));
+    w[r] = dexp(T * (sumA * dlog(p1) + ((double)N - sumA) * dlog(1.0 - p1)));
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (lane != 0) return;
+  double tot = 0.0;
+  for (int r = 0; r <= N; ++r) tot = tot + w[r];
   const double target = u * tot;
   double cum = 0.0;
   int pick = N;
-  for (int r = 0; r <= N; ++r) {
-    const double p1 = prior_prob_1((double)r, (double)N);
-    cum = cum + dexp(T * (sumA * dlog(p1) + ((double)N - sumA) * dlog(1.0 - p1)));
-    if (target < cum) { pick = r; break; }
-  }
+  for (int r = 0; r <= N; ++r) { cum = cum + w[r]; if (target < cum) { pick = r; break; } }
   *d.R = pick;
 }
 // sample_An(from_prior = TRUE) :102-106
@@ -59,49 +61,59 @@ __global__ void k_rank_Aprior(Dev d, uint32_t t) {
 
 // ---- the rank sweep: sample_An for n = 1..N in ONE persistent launch ----
 // Every decision needs a sum over ALL cells, so the factors are separated by a grid-wide barrier (hand-written:
-// agent-scope release / monotonic counter / acquire, bounded spin; the grid is sized to be co-resident, one
-// workgroup per CU).  Stream spec: Mhat fresh at the start of the sweep, then maintained per cell; for factor n only
+// tagged-granule all-gather, bounded spin; the grid is sized to be co-resident: 512-lane workgroups, one per CU,
+// which also keeps the waves' compute time even).  Stream spec: Mhat fresh at the start of the sweep, then maintained per cell; for factor n only
 // the alternative state alt = Mhat -/+ P[k,n] E[n,g] is evaluated, the log-likelihood of the current state is carried.
-// Per-column sums (64-strided over k + tree) go to colbuf[parity][g]; after the barrier every workgroup reduces them
-// canonically (W = 1024 over g) and takes the same tempered Bernoulli decision.
+// Per-column sums (64-strided over k + tree) are added in blocks of 8 consecutive columns (one wave owns whole
+// blocks) into blkbuf[parity][b]; after the barrier every workgroup reduces the block sums canonically (W = 1024)
+// and takes the same tempered Bernoulli decision.
 constexpr int RK_T = 512;
 constexpr int RK_W = RK_T / 64;
-constexpr int RK_MAXC = 8;                                // columns per wave kept in registers (REG variant)
-constexpr unsigned RK_SPIN_LIMIT = 1u << 24;
+constexpr int RK_MAXC = 8;                                // columns per block = columns per wave kept in registers (REG variant)
+constexpr unsigned RK_SPIN_LIMIT = 1u << 22;
 
-BNMF_DEV double rank_cell_ll(const Dev& d, int m, double c, double sg) {
+BNMF_DEV double rank_cell_ll(const Dev& d, int m, double c, double sg, double lgf) {
   if (d.likelihood == BNMF_NORMAL) {
     const double sd = dsqrt(sg);
     const double z = ((double)m - c) / sd;
     return (-0.91893853320467274178 - dlog(sd)) - 0.5 * (z * z);
   }
-  const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
   const double h = c < 1e-6 ? 1e-6 : c;
-  return ((double)m * dlog(h) - h) - d.lgfact[mi];
+  return ((double)m * dlog(h) - h) - lgf;
 }
-// grid barrier number `phase` (1, 2, ...): every workgroup arrives once per phase.  Returns false on time-out.
-BNMF_DEV bool rank_grid_sync(unsigned* counter, unsigned phase, unsigned nwg, int* err, int tid) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's stores have left
+BNMF_DEV double rank_lgf(const Dev& d, int m) { return d.lgfact[m < 0 ? 0 : (m > d.maxM ? d.maxM : m)]; }
+// All-gather of the block sums without a separate barrier: a value is published as two 8-byte granules
+// {tag, low word}, {tag, high word} (one agent-scope relaxed store each: write-through, never torn), tag = a number
+// unique to (iteration, phase).  Every workgroup sweeps all granules with agent-scope relaxed loads (which bypass
+// its L1) until every tag matches, and rebuilds the doubles in LDS: the data is its own flag, no fences needed.
+// Bounded: a time-out sets *err and makes every workgroup leave.
+BNMF_DEV void rank_publish(unsigned long long* gran, int b, unsigned tag, double v) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+  __hip_atomic_store(gran + 2 * (size_t)b, ((unsigned long long)tag << 32) | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(gran + 2 * (size_t)b + 1, ((unsigned long long)tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+BNMF_DEV bool rank_gather(const unsigned long long* gran, int NB, unsigned tag, double* vals /* LDS [NB] */, int* err, int tid) {
+  __shared__ int bad_s;
+  if (tid == 0) bad_s = 0;
   __syncthreads();
-  __shared__ int ok_s;
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned target = phase * nwg;
+  bool bad = false;
+  for (int b = tid; b < NB; b += RK_T) {
     unsigned spins = 0;
-    bool ok = true;
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > RK_SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
+    for (;;) {
+      const unsigned long long g0 = __hip_atomic_load(gran + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long g1 = __hip_atomic_load(gran + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag) {
+        vals[b] = __longlong_as_double((long long)((g0 & 0xFFFFFFFFull) | (g1 << 32)));
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > RK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { bad = true; break; }
     }
-    if (!ok) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ok_s = ok ? 1 : 0;
+    if (bad) break;
   }
+  if (bad) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bad_s = 1; }
   __syncthreads();
-  return ok_s != 0;
+  return bad_s == 0;
 }
 // canonical W = 1024 sum of x[0..L) by a 512-lane workgroup: lane i owns accumulators i and i + 512
 BNMF_DEV double canon1024_by512(const double* x, long L, double* buf, int tid) {
@@ -115,23 +127,18 @@ BNMF_DEV double canon1024_by512(const double* x, long L, double* buf, int tid) {
   __syncthreads();
   return r;
 }
-// tempered Bernoulli of sample_An :108-166 from the two log-likelihoods; A still holds the old value of factor n
-BNMF_DEV double rank_decide(const Dev& d, uint32_t t, int n, double ll0, double ll1, const double* A) {
-  const int N = d.N, K = d.K, G = d.G;
-  const double pi1 = prior_prob_1((double)*d.R, (double)N);
-  const double T = temp_at(d, t);
-  const double a_old = A[n];
-  double sumA = 0.0;
-  for (int j = 0; j < N; ++j) sumA = sumA + A[j];
+// tempered Bernoulli of sample_An :108-166 from the two log-likelihoods (the sweep's constants are hoisted by the caller)
+struct RankConst { double l1mp, lpi, lgG, T; };
+BNMF_DEV double rank_decide(const Dev& d, uint32_t t, int n, double ll0, double ll1, double a_old, double sumA, const RankConst& rc) {
+  const int K = d.K, G = d.G;
   const double sumA0 = sumA - a_old, sumA1 = sumA0 + 1.0;
   double s0 = ll0, s1 = ll1;
   if (d.rank_method == BNMF_SBFI) {
-    const double lg = dlog((double)G);
-    s0 = ll0 - (sumA0 * (double)(G + K)) * lg / 2.0;
-    s1 = ll1 - (sumA1 * (double)(G + K)) * lg / 2.0;
+    s0 = ll0 - (sumA0 * (double)(G + K)) * rc.lgG / 2.0;
+    s1 = ll1 - (sumA1 * (double)(G + K)) * rc.lgG / 2.0;
   }
-  const double lp0 = dlog(1.0 - pi1) + T * s0;
-  const double lp1 = dlog(pi1) + T * s1;
+  const double lp0 = rc.l1mp + rc.T * s0;
+  const double lp1 = rc.lpi + rc.T * s1;
   const double hi = lp0 > lp1 ? lp0 : lp1, lo = lp0 > lp1 ? lp1 : lp0;
   const double lse = hi + dlog(1.0 + dexp(lo - hi));            // sumLog :199-206
   double p = dexp(lp1 - lse);
@@ -143,10 +150,10 @@ BNMF_DEV double rank_decide(const Dev& d, uint32_t t, int n, double ll0, double 
   return (runif(s) < p) ? 1.0 : 0.0;
 }
 
-// REG: the wave's cells (<= RK_MAXC columns x 2 row passes, K <= 128) stay in registers for the whole sweep;
-// otherwise Mhat lives in the global scratch mhg[k + K g].
-template <bool REG>
-__global__ __launch_bounds__(RK_T) void k_rank_sweep(Dev d, uint32_t t, double* colbuf /* [2][G] */, unsigned* counter, int* err, double* mhg) {
+// REG: one block of 8 columns per wave, its cells (8 columns x 2 row passes, K <= 128) in registers for the whole
+// sweep; otherwise a wave walks its blocks b = w, w + Wt, ... and Mhat lives in the global scratch mhg[k + K g].
+template <bool REG, bool NORMAL>
+__global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsigned long long* granbuf /* [2][2 NB] */, int NB, int* err, double* mhg, unsigned long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double buf[RK_T];
   __shared__ double bc[2];
@@ -154,142 +161,174 @@ __global__ __launch_bounds__(RK_T) void k_rank_sweep(Dev d, uint32_t t, double* 
   const int K = d.K, G = d.G, N = d.N;
   const int KR = (K + 63) >> 6;
   const int wg = blockIdx.x * RK_W + wave, Wt = gridDim.x * RK_W;
-  const unsigned nwg = gridDim.x;
+  constexpr bool normal = NORMAL;
+  const unsigned tag0 = t * (unsigned)(N + 2);           // tags of this launch: tag0 + phase, unique over the chain
   // the workgroup's own copy of A: every workgroup takes every decision itself, so A is never read across
   // workgroups inside the launch (the global A is written for the kernels that follow)
   double* Ash = (double*)smem;                           // [N]
+  double* vals = Ash + N;                                // [NB] gathered block sums
   for (int j = tid; j < N; j += RK_T) Ash[j] = d.A[j];
   __syncthreads();
-  double mh[REG ? RK_MAXC : 1][2];
+  double mh[REG ? RK_MAXC : 1][2], sgc[(REG && NORMAL) ? RK_MAXC : 1];
   int mm[REG ? RK_MAXC : 1][2];
   // ---- phase 0: fresh Mhat and the log-likelihood of the current state
-  double* col = colbuf;
+  unsigned long long* gran = granbuf;
+  unsigned phase = 1;
   if (REG) {
+    double bs = 0.0;
 #pragma unroll
     for (int c = 0; c < RK_MAXC; ++c) {
-      const int g = wg + c * Wt;
+      const int g = wg * RK_MAXC + c;
+      if (NORMAL) sgc[c] = 1.0;
+      mh[c][0] = mh[c][1] = 0.0; mm[c][0] = mm[c][1] = 0;   // cells beyond G / K: harmless values (mm indexes the lgamma table)
       if (g < G) {
-        const double sg = d.likelihood == BNMF_NORMAL ? d.sigmasq[g] : 1.0;
+        const double sg = normal ? d.sigmasq[g] : 1.0;
+        if (NORMAL) sgc[c] = sg;
         double acc = 0.0;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           const int kk = (r << 6) + lane;
-          mh[c][r] = 0.0; mm[c][r] = 0;
           if (kk < K) {
             double cc = 0.0;
             for (int j = 0; j < N; ++j) cc = cc + (d.P[kk + (size_t)K * j] * Ash[j]) * d.E[j + (size_t)N * g];
             const int m = d.M[kk + (size_t)K * g];
             mh[c][r] = cc; mm[c][r] = m;
-            acc = acc + rank_cell_ll(d, m, cc, sg);
+            acc = acc + rank_cell_ll(d, m, cc, sg, rank_lgf(d, m));
           }
         }
-        acc = wave_tree64(acc);
-        if (lane == 0) col[g] = acc;
+        bs = bs + wave_tree64(acc);                      // lane 0: block sum, columns in ascending order
       }
     }
+    if (lane == 0 && wg < NB) rank_publish(gran, wg, tag0 + phase, bs);
   } else {
-    for (int g = wg; g < G; g += Wt) {
-      const double sg = d.likelihood == BNMF_NORMAL ? d.sigmasq[g] : 1.0;
-      double acc = 0.0;
-      for (int r = 0; r < KR; ++r) {
-        const int kk = (r << 6) + lane;
-        if (kk < K) {
-          double cc = 0.0;
-          for (int j = 0; j < N; ++j) cc = cc + (d.P[kk + (size_t)K * j] * Ash[j]) * d.E[j + (size_t)N * g];
-          mhg[kk + (size_t)K * g] = cc;
-          acc = acc + rank_cell_ll(d, d.M[kk + (size_t)K * g], cc, sg);
+    for (int b = wg; b < NB; b += Wt) {
+      double bs = 0.0;
+      for (int c = 0; c < RK_MAXC; ++c) {
+        const int g = b * RK_MAXC + c;
+        if (g >= G) break;
+        const double sg = normal ? d.sigmasq[g] : 1.0;
+        double acc = 0.0;
+        for (int r = 0; r < KR; ++r) {
+          const int kk = (r << 6) + lane;
+          if (kk < K) {
+            double cc = 0.0;
+            for (int j = 0; j < N; ++j) cc = cc + (d.P[kk + (size_t)K * j] * Ash[j]) * d.E[j + (size_t)N * g];
+            mhg[kk + (size_t)K * g] = cc;
+            const int m = d.M[kk + (size_t)K * g];
+            acc = acc + rank_cell_ll(d, m, cc, sg, rank_lgf(d, m));
+          }
         }
+        bs = bs + wave_tree64(acc);
       }
-      acc = wave_tree64(acc);
-      if (lane == 0) col[g] = acc;
+      if (lane == 0) rank_publish(gran, b, tag0 + phase, bs);
     }
   }
-  unsigned phase = 1;
-  if (!rank_grid_sync(counter, phase, nwg, err, tid)) return;
-  double ll_cur = canon1024_by512(col, G, buf, tid);
-  if (tid == 0) bc[0] = ll_cur;
-  __syncthreads();
-  ll_cur = bc[0];
+  if (!rank_gather(gran, NB, tag0 + phase, vals, err, tid)) return;
+  double ll_cur = canon1024_by512(vals, NB, buf, tid);  // valid on thread 0, which carries it
+  RankConst rc{};
+  double sumA = 0.0;
+  if (tid == 0) {
+    const double pi1 = prior_prob_1((double)*d.R, (double)N);
+    rc.l1mp = dlog(1.0 - pi1); rc.lpi = dlog(pi1); rc.lgG = dlog((double)G); rc.T = temp_at(d, t);
+    for (int j = 0; j < N; ++j) sumA = sumA + Ash[j];
+  }
   // ---- factors in order
   for (int n = 0; n < N; ++n) {
     const double a_old = Ash[n];
-    col = colbuf + (size_t)((n + 1) & 1) * G;
+    gran = granbuf + (size_t)((n + 1) & 1) * 2 * NB;
+    ++phase;
     const double* Pn = d.P + (size_t)K * n;
+    double p0 = 0.0, p1 = 0.0, en_[REG ? RK_MAXC : 1];
     if (REG) {
-      const double p0 = lane < K ? Pn[lane] : 0.0, p1 = 64 + lane < K ? Pn[64 + lane] : 0.0;
+      p0 = lane < K ? Pn[lane] : 0.0; p1 = 64 + lane < K ? Pn[64 + lane] : 0.0;
+#pragma unroll
+      for (int c = 0; c < RK_MAXC; ++c) { const int g = wg * RK_MAXC + c; en_[c] = g < G ? d.E[n + (size_t)N * g] : 0.0; }
+      double bs = 0.0;
+      {
 #pragma unroll
       for (int c = 0; c < RK_MAXC; ++c) {
-        const int g = wg + c * Wt;
+        const int g = wg * RK_MAXC + c;
         if (g < G) {
-          const double sg = d.likelihood == BNMF_NORMAL ? d.sigmasq[g] : 1.0;
-          const double en = d.E[n + (size_t)N * g];
           double acc = 0.0;
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
             const int kk = (r << 6) + lane;
             if (kk < K) {
-              const double tt = (r ? p1 : p0) * en;
+              const double tt = (r ? p1 : p0) * en_[c];
               const double alt = (a_old == 1.0) ? mh[c][r] - tt : mh[c][r] + tt;
-              acc = acc + rank_cell_ll(d, mm[c][r], alt, sg);
+              acc = acc + rank_cell_ll(d, mm[c][r], alt, NORMAL ? sgc[c] : 1.0, NORMAL ? 0.0 : rank_lgf(d, mm[c][r]));
             }
           }
-          acc = wave_tree64(acc);
-          if (lane == 0) col[g] = acc;
+          bs = bs + wave_tree64(acc);
         }
       }
+      }
+      if (lane == 0 && wg < NB) rank_publish(gran, wg, tag0 + phase, bs);
     } else {
-      for (int g = wg; g < G; g += Wt) {
-        const double sg = d.likelihood == BNMF_NORMAL ? d.sigmasq[g] : 1.0;
-        const double en = d.E[n + (size_t)N * g];
-        double acc = 0.0;
-        for (int r = 0; r < KR; ++r) {
-          const int kk = (r << 6) + lane;
-          if (kk < K) {
-            const double tt = Pn[kk] * en;
-            const double cur = mhg[kk + (size_t)K * g];
-            const double alt = (a_old == 1.0) ? cur - tt : cur + tt;
-            acc = acc + rank_cell_ll(d, d.M[kk + (size_t)K * g], alt, sg);
+      for (int b = wg; b < NB; b += Wt) {
+        double bs = 0.0;
+        for (int c = 0; c < RK_MAXC; ++c) {
+          const int g = b * RK_MAXC + c;
+          if (g >= G) break;
+          const double sg = normal ? d.sigmasq[g] : 1.0;
+          const double en = d.E[n + (size_t)N * g];
+          double acc = 0.0;
+          for (int r = 0; r < KR; ++r) {
+            const int kk = (r << 6) + lane;
+            if (kk < K) {
+              const double tt = Pn[kk] * en;
+              const double cur = mhg[kk + (size_t)K * g];
+              const double alt = (a_old == 1.0) ? cur - tt : cur + tt;
+              const int m = d.M[kk + (size_t)K * g];
+              acc = acc + rank_cell_ll(d, m, alt, sg, rank_lgf(d, m));
+            }
           }
+          bs = bs + wave_tree64(acc);
         }
-        acc = wave_tree64(acc);
-        if (lane == 0) col[g] = acc;
+        if (lane == 0) rank_publish(gran, b, tag0 + phase, bs);
       }
     }
-    ++phase;
-    if (!rank_grid_sync(counter, phase, nwg, err, tid)) return;
-    const double ll_alt = canon1024_by512(col, G, buf, tid);
+#define RKSTAMP(i) if (dbg && tid == 0 && n < 16) dbg[(blockIdx.x * 16 + n) * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
+    RKSTAMP(0);
+    if (!rank_gather(gran, NB, tag0 + phase, vals, err, tid)) return;
+    RKSTAMP(1);
+    const double ll_alt = canon1024_by512(vals, NB, buf, tid);
+    RKSTAMP(2);
     if (tid == 0) {
       const double ll0 = (a_old == 1.0) ? ll_alt : ll_cur, ll1 = (a_old == 1.0) ? ll_cur : ll_alt;
-      bc[0] = rank_decide(d, t, n, ll0, ll1, Ash);
-      bc[1] = ll_alt;
+      const double a_new = rank_decide(d, t, n, ll0, ll1, a_old, sumA, rc);
+      if (a_new != a_old) { ll_cur = ll_alt; sumA = (sumA - a_old) + a_new; }
+      bc[0] = a_new;
     }
+    RKSTAMP(3);
     __syncthreads();
     const double a_new = bc[0];
     if (a_new != a_old) {
-      ll_cur = bc[1];
       if (REG) {
-        const double p0 = lane < K ? Pn[lane] : 0.0, p1 = 64 + lane < K ? Pn[64 + lane] : 0.0;
 #pragma unroll
         for (int c = 0; c < RK_MAXC; ++c) {
-          const int g = wg + c * Wt;
+          const int g = wg * RK_MAXC + c;
           if (g < G) {
-            const double en = d.E[n + (size_t)N * g];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) { const double tt = (r ? p1 : p0) * en; mh[c][r] = (a_old == 1.0) ? mh[c][r] - tt : mh[c][r] + tt; }
+            for (int r = 0; r < 2; ++r) { const double tt = (r ? p1 : p0) * en_[c]; mh[c][r] = (a_old == 1.0) ? mh[c][r] - tt : mh[c][r] + tt; }
           }
         }
       } else {
-        for (int g = wg; g < G; g += Wt) {
-          const double en = d.E[n + (size_t)N * g];
-          for (int r = 0; r < KR; ++r) {
-            const int kk = (r << 6) + lane;
-            if (kk < K) { const double tt = Pn[kk] * en; const double cur = mhg[kk + (size_t)K * g]; mhg[kk + (size_t)K * g] = (a_old == 1.0) ? cur - tt : cur + tt; }
+        for (int b = wg; b < NB; b += Wt)
+          for (int c = 0; c < RK_MAXC; ++c) {
+            const int g = b * RK_MAXC + c;
+            if (g >= G) break;
+            const double en = d.E[n + (size_t)N * g];
+            for (int r = 0; r < KR; ++r) {
+              const int kk = (r << 6) + lane;
+              if (kk < K) { const double tt = Pn[kk] * en; const double cur = mhg[kk + (size_t)K * g]; mhg[kk + (size_t)K * g] = (a_old == 1.0) ? cur - tt : cur + tt; }
+            }
           }
-        }
       }
     }
     if (tid == 0) { Ash[n] = a_new; if (blockIdx.x == 0) d.A[n] = a_new; }
     __syncthreads();
+    RKSTAMP(4);
   }
 }
 

@@ -422,16 +422,16 @@ static double pois_ll_cell(int32_t m, double mhat) {
  * O(N K G) instead of O(N^2 K G)): Mhat = P diag(A) E is computed fresh (factor order, as get_Mhat_ R/utils.R:29-49)
  * once at the start of the rank sweep and then maintained per cell; for factor n only the ALTERNATIVE state is
  * evaluated, alt = Mhat -/+ P[k,n] E[n,g] (A[n] = 1 / 0 now), the log-likelihood of the current state being the one
- * carried from the previous decision.  Sums: per column 64-strided over k + tree; blocks of 64 columns (W = 64);
- * W = 1024 over the blocks. */
+ * carried from the previous decision.  Sums: per column 64-strided over k + tree; the column sums are added in blocks
+ * of 8 consecutive columns (sequentially, ascending); W = 1024 over the blocks. */
 static double ll_cell_rank(const orc_handle* o, int32_t m, double mhat, long g) {
   if (o->cfg.likelihood == LIK_NORMAL) return dnorm_log_fwd((double)m, mhat, o->a[ID_SIGMASQ].p[g]);
   return pois_ll_cell(m, mhat);
 }
 static double hsum_cols(const double* col, long G) {
-  long nb = (G + 63) / 64;
+  long nb = (G + 7) / 8;
   double* blk = (double*)malloc(8 * nb);
-  for (long b = 0; b < nb; ++b) blk[b] = orc_canon_sum(col + 64 * b, G - 64 * b < 64 ? G - 64 * b : 64, 1, 64);
+  for (long b = 0; b < nb; ++b) { double a = 0.0; for (long g = 8 * b; g < 8 * b + 8 && g < G; ++g) a = a + col[g]; blk[b] = a; }
   double r = orc_canon_sum(blk, nb, 1, 1024);
   free(blk);
   return r;

@@ -1,0 +1,22 @@
+import os, sys, ctypes as C
+os.environ["BNMF_RANKDBG"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from bayesnmf_amd import Engine, engine
+from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+M, _, _ = synth_counts(96, 10000, 12, 20250222)
+e = Engine(M, 50, prior="gamma", seed=1, learning_rank=True, temperature=np.ones(8000), window=10)
+apply_hyperprior_params(e, "gamma", M, 50); e.init(); e.run(5, metrics=False)
+L = engine.lib(); L.bnmf_debug_rank.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]
+n = 313 * 16 * 8
+buf = np.zeros(n, dtype=np.uint64)
+g = L.bnmf_debug_rank(e._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), n)
+d = buf[:g * 16 * 8].reshape(g, 16, 8).astype(np.float64) / 100.0   # us
+t0 = d[:, :, 0].min()
+for n_ in range(1, 8):
+    s = d[:, n_, :]
+    prev_end = d[:, n_ - 1, 4]
+    print(f"factor {n_}: compute {np.median(s[:,0]-prev_end):5.2f} (max {np.max(s[:,0]-prev_end):5.2f})  gather {np.median(s[:,1]-s[:,0]):5.2f} (min {np.min(s[:,1]-s[:,0]):5.2f})  "
+          f"tree {np.median(s[:,2]-s[:,1]):5.2f}  decide {np.median(s[:,3]-s[:,2]):5.2f}  tail {np.median(s[:,4]-s[:,3]):5.2f}  "
+          f"publish spread {np.max(s[:,0])-np.min(s[:,0]):5.2f}  phase {np.median(s[:,4]-prev_end):5.2f}")
+e.close()
