@@ -60,6 +60,8 @@ struct bnmf_handle {
   hipEvent_t ev[2 * BNMF_NKERNEL]{};
   bool have_ev = false;
   double* dMap = nullptr; size_t map_words = 0;   // scratch of bnmf_map (grown on demand)
+  std::vector<double> hist;                       // [wcap][4]: loglikelihood, logposterior, P / E mean acceptance of the last iterations
+  std::vector<double> temp_host;                  // temperature schedule (host copy, for the convergence rule)
 };
 
 static size_t id_len(const bnmf_handle* h, int id) {
@@ -267,6 +269,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   if (cfg->n_temperature > 0 && cfg->temperature) {
     HIPCHK(hipMalloc(&h->dTemp, cfg->n_temperature * sizeof(double)));
     HIPCHK(hipMemcpy(h->dTemp, cfg->temperature, cfg->n_temperature * sizeof(double), hipMemcpyHostToDevice));
+    h->temp_host.assign(cfg->temperature, cfg->temperature + cfg->n_temperature);
   } else h->cfg.n_temperature = 0;
   h->cfg.temperature = nullptr;
   h->metrics_rows = 1024;
@@ -833,10 +836,13 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
   hipEventRecord(h->ev_z, h->side); hipStreamWaitEvent(h->stream, h->ev_z, 0);
   hipLaunchKernelGGL(k_compose, dim3(1), dim3(64), 0, h->stream, h->dev, 1, 1u);
   HIPCHK(hipGetLastError());
-  if (metrics_row1) HIPCHK(hipMemcpyAsync(metrics_row1, h->dMetrics, BNMF_NMETRIC * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  double row1[BNMF_NMETRIC];
+  HIPCHK(hipMemcpyAsync(row1, h->dMetrics, BNMF_NMETRIC * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->side));
   HIPCHK(hipStreamSynchronize(h->side2));
+  if (metrics_row1) memcpy(metrics_row1, row1, sizeof row1);
+  if (h->wcap > 0) { h->hist.assign((size_t)h->wcap * 4, std::nan("")); h->hist[0] = row1[3]; h->hist[1] = row1[4]; h->hist[2] = row1[9]; h->hist[3] = row1[10]; }
   h->inited = true;
   return 0;
 }
@@ -857,10 +863,20 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
   hipEventRecord(h->ev_z, h->side); hipStreamWaitEvent(h->stream, h->ev_z, 0);   // last k_reduce done
   hipLaunchKernelGGL(k_compose, dim3((n_iter + 63) / 64), dim3(64), 0, h->stream, h->dev, n_iter, t0);
   HIPCHK(hipGetLastError());
+  std::vector<double> own;
+  if (!metrics && h->wcap > 0) { own.resize((size_t)n_iter * BNMF_NMETRIC); metrics = own.data(); }
   if (metrics) HIPCHK(hipMemcpyAsync(metrics, h->dMetrics, (size_t)n_iter * BNMF_NMETRIC * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->side));
   HIPCHK(hipStreamSynchronize(h->side2));
+  if (h->wcap > 0 && metrics) {                             // loglik / logpost of the recorded iterations (MAP metrics are window means)
+    if (h->hist.size() != (size_t)h->wcap * 4) h->hist.assign((size_t)h->wcap * 4, std::nan(""));
+    for (int i = 0; i < n_iter; ++i) {
+      const double* r = metrics + (size_t)i * BNMF_NMETRIC;
+      double* d = h->hist.data() + (size_t)((t0 + i - 1) % (uint32_t)h->wcap) * 4;
+      d[0] = r[3]; d[1] = r[4]; d[2] = r[9]; d[3] = r[10];
+    }
+  }
   if (h->dRankSync) {
     int err = 0;
     HIPCHK(hipMemcpy(&err, h->dRankSync + 4, sizeof(int), hipMemcpyDeviceToHost));
@@ -913,7 +929,7 @@ static int ring_read(const bnmf_handle* h, int id, int last_n, double* out) {
 
 int bnmf_map(bnmf_handle* h, int last_n, double ci, double* P_mean, double* E_mean, double* A_mode, double* top_A,
              double* P_lower, double* P_upper, double* E_lower, double* E_upper, int32_t* used, bnmf_map_info* info) {
-  if (!h || !P_mean || !E_mean || !A_mode || !info) return fail(BNMF_EINVAL, "bnmf_map: null argument");
+  if (!h || !A_mode || !info) return fail(BNMF_EINVAL, "bnmf_map: null argument");
   const int W = h->cfg.window;
   if (W <= 0) return fail(BNMF_ESTATE, "bnmf_map: the handle was created with window = 0");
   if (last_n < 1 || last_n > W || last_n > h->iter) return fail(BNMF_ESIZE, "bnmf_map: last_n = %d but only min(window = %d, iter = %d) samples are kept", last_n, W, h->iter);
@@ -979,8 +995,8 @@ int bnmf_map(bnmf_handle* h, int last_n, double ci, double* P_mean, double* E_me
                      (const int*)dslots, nu, (const double*)cs, kt, jlo, glo, jhi, ghi, mE, loE, hiE);
   hipLaunchKernelGGL(k_map_fit, dim3((G + 3) / 4), dim3(256), 0, h->stream, (const int32_t*)h->dM, (const double*)mP, (const double*)dA, (const double*)mE, K, N, G, colsse, colkl);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(P_mean, mP, lenP * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(E_mean, mE, lenE * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (P_mean) HIPCHK(hipMemcpyAsync(P_mean, mP, lenP * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (E_mean) HIPCHK(hipMemcpyAsync(E_mean, mE, lenE * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (want_ci) {
     if (P_lower) HIPCHK(hipMemcpyAsync(P_lower, loP, lenP * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (P_upper) HIPCHK(hipMemcpyAsync(P_upper, hiP, lenP * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -994,6 +1010,75 @@ int bnmf_map(bnmf_handle* h, int last_n, double ci, double* P_mean, double* E_me
   for (int g = 0; g < G; ++g) { sse += col[g]; kl += col[(size_t)G + g]; }
   info->rmse = std::sqrt(sse / ((double)K * (double)G));
   info->kl = kl;
+  return 0;
+}
+
+// The sampling loop up to convergence as ONE call: blocks of iterations up to the next MAP check, get_MAP_ on the device,
+// update_MAP_metrics_ (R/utils.R:356-397) and check_convergence_ (R/convergence.R:60-154) here on the host side of the ABI.
+int bnmf_run_until(bnmf_handle* h, const bnmf_convergence_control* cc, bnmf_convergence_state* st, double* metrics, int cap_rows,
+                   int* n_rows, double* map_rows, int cap_checks, int* n_checks) {
+  if (!h || !cc || !st || !metrics || !n_rows || !map_rows || !n_checks) return fail(BNMF_EINVAL, "bnmf_run_until: null argument");
+  if (!h->inited) return fail(BNMF_ESTATE, "bnmf_run_until: call bnmf_init first");
+  if (h->cfg.window < cc->MAP_over) return fail(BNMF_ESTATE, "bnmf_run_until: the handle keeps %d samples, MAP_over = %d", h->cfg.window, cc->MAP_over);
+  if (cc->MAP_every < 1 || cc->MAP_over < 1 || cc->metric < 0 || cc->metric > 4) return fail(BNMF_EINVAL, "bnmf_run_until: bad convergence control");
+  const int K = h->cfg.K, G = h->cfg.G, N = h->cfg.N;
+  *n_rows = 0; *n_checks = 0;
+  std::vector<double> Am(N);
+  std::vector<int32_t> used(cc->MAP_over);
+  Timer tm{h, false};
+  while (!st->converged && h->iter < cc->maxiters) {      // R/bayesNMF_sampler.R:268
+    const int it0 = h->iter;
+    int nxt = (it0 / cc->MAP_every + 1) * cc->MAP_every;
+    if (nxt > cc->maxiters) nxt = cc->maxiters;
+    const int n = nxt - it0;
+    if (*n_rows + n > cap_rows) return fail(BNMF_ESIZE, "bnmf_run_until: metrics buffer too small (%d rows)", cap_rows);
+    if (int rc = run_impl(h, n, 0, metrics + (size_t)*n_rows * BNMF_NMETRIC, tm)) return rc;
+    const double* lastrow = metrics + (size_t)(*n_rows + n - 1) * BNMF_NMETRIC;
+    *n_rows += n;
+    const int it = h->iter;
+    const int over = cc->MAP_over > cc->MAP_every ? cc->MAP_over : cc->MAP_every;
+    if (!((it % cc->MAP_every == 0 && it >= over) || it >= cc->maxiters)) continue;      // :288-296
+    if (*n_checks >= cap_checks) return fail(BNMF_ESIZE, "bnmf_run_until: MAP-metrics buffer too small (%d rows)", cap_checks);
+    const int win = it < cc->MAP_over ? it : cc->MAP_over;
+    bnmf_map_info info;
+    if (int rc = bnmf_map(h, win, 0.0, nullptr, nullptr, Am.data(), nullptr, nullptr, nullptr, nullptr, nullptr, used.data(), &info)) return rc;
+    // update_MAP_metrics_: loglikelihood / logposterior are means of the per-sample values over the whole window
+    double ll = 0.0, lp = 0.0, mt = 0.0, sumA = 0.0;
+    for (int i = it - win + 1; i <= it; ++i) {
+      const double* hrow = h->hist.data() + (size_t)((i - 1) % h->wcap) * 4;
+      ll += hrow[0]; lp += hrow[1];
+      mt += h->temp_host.empty() ? 1.0 : h->temp_host[std::min<size_t>((size_t)i - 1, h->temp_host.size() - 1)];
+    }
+    ll /= win; lp /= win; mt /= win;
+    for (int j = 0; j < N; ++j) sumA += Am[j];
+    const double n_params = sumA * (double)(G + K);
+    double* mr = map_rows + (size_t)*n_checks * BNMF_NMAPROW;
+    mr[0] = it; mr[1] = info.rmse; mr[2] = info.kl; mr[3] = ll; mr[4] = lp; mr[5] = n_params;
+    mr[6] = -2.0 * ll + n_params * std::log((double)G); mr[7] = sumA; mr[8] = info.top_counts[0]; mr[9] = mt;
+    mr[10] = lastrow[9]; mr[11] = lastrow[10];            // compute_metrics_ uses the CURRENT acceptance matrices
+    // check_convergence_
+    static const int col_of[5] = {3, 4, 1, 2, 6};
+    double m = mr[col_of[cc->metric]];
+    if (cc->metric <= 1) m = -m;
+    if (!st->have_prev) { st->prev_MAP_metric = m + 1.0; st->best_MAP_metric = m + 1.0; st->inarow_na = st->inarow_no_change = st->inarow_no_best = 0; st->have_prev = 1; }
+    const double pc = (m - st->prev_MAP_metric) / st->prev_MAP_metric;
+    st->prev_percent_change = pc; st->prev_MAP_metric = m;
+    if (pc != pc) { st->inarow_no_change = 0; st->inarow_no_best = 0; st->inarow_na += 1; }
+    else if (std::fabs(pc) < cc->tol) { st->inarow_no_change += 1; st->inarow_na = 0; }
+    else { st->inarow_no_change = 0; st->inarow_na = 0; }
+    bool temps_one = true;                                  // temperature_schedule[(iter - MAP_over):iter] == 1 (R drops index 0)
+    for (int i = std::max(it - cc->MAP_over, 1); i <= it && temps_one; ++i)
+      temps_one = h->temp_host.empty() || h->temp_host[std::min<size_t>((size_t)i - 1, h->temp_host.size() - 1)] == 1.0;
+    if (temps_one && it >= cc->miniters) {
+      if (m < st->best_MAP_metric) { st->best_MAP_metric = m; st->best_iter = it; st->inarow_no_best = 0; }
+      else st->inarow_no_best += 1;
+      if (st->inarow_no_change >= cc->Ninarow_nochange) { st->converged = 1; st->why = 1; }
+      else if (st->inarow_no_best >= cc->Ninarow_nobest) { st->converged = 1; st->why = 2; }
+      else if (it >= cc->maxiters) { st->converged = 1; st->why = 3; }
+    }
+    mr[12] = pc; mr[13] = st->inarow_no_change; mr[14] = st->inarow_no_best; mr[15] = st->inarow_na; mr[16] = st->converged;
+    *n_checks += 1; st->n_checks += 1;
+  }
   return 0;
 }
 

@@ -50,8 +50,23 @@ class BnmfMapInfo(C.Structure):
                 ("rmse", C.c_double), ("kl", C.c_double)]
 
 
+class BnmfConvergenceControl(C.Structure):
+    _fields_ = [("MAP_over", C.c_int32), ("MAP_every", C.c_int32), ("Ninarow_nochange", C.c_int32), ("Ninarow_nobest", C.c_int32),
+                ("miniters", C.c_int32), ("maxiters", C.c_int32), ("metric", C.c_int32), ("_pad", C.c_int32), ("tol", C.c_double)]
+
+
+class BnmfConvergenceState(C.Structure):
+    _fields_ = [("converged", C.c_int32), ("why", C.c_int32), ("best_iter", C.c_int32), ("inarow_na", C.c_int32),
+                ("inarow_no_change", C.c_int32), ("inarow_no_best", C.c_int32), ("have_prev", C.c_int32), ("n_checks", C.c_int32),
+                ("prev_MAP_metric", C.c_double), ("best_MAP_metric", C.c_double), ("prev_percent_change", C.c_double)]
+
+
+NMAPROW = 17
+CC_METRICS = ["loglikelihood", "logposterior", "RMSE", "KL", "BIC"]
+WHY = {0: None, 1: "no change", 2: "no best", 3: "max iters"}
+
 ABI_SYMBOLS = ["bnmf_create", "bnmf_destroy", "bnmf_set_array", "bnmf_get_array", "bnmf_get_array_i32",
-               "bnmf_init", "bnmf_run", "bnmf_window", "bnmf_map", "bnmf_get_iter", "bnmf_profile",
+               "bnmf_init", "bnmf_run", "bnmf_window", "bnmf_map", "bnmf_run_until", "bnmf_get_iter", "bnmf_profile",
                "bnmf_kernel_name", "bnmf_test_math", "bnmf_test_sampler", "bnmf_test_philox",
                "bnmf_device_info", "bnmf_device_count", "bnmf_last_error", "bnmf_version"]
 
@@ -73,6 +88,8 @@ def lib():
         L.bnmf_run.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
         L.bnmf_window.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
         L.bnmf_map.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, dp, dp, dp, dp, dp, dp, dp, ip, C.POINTER(BnmfMapInfo)]
+        L.bnmf_run_until.argtypes = [C.c_void_p, C.POINTER(BnmfConvergenceControl), C.POINTER(BnmfConvergenceState), dp, C.c_int,
+                                     C.POINTER(C.c_int), dp, C.c_int, C.POINTER(C.c_int)]
         L.bnmf_get_iter.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.bnmf_profile.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
         L.bnmf_kernel_name.restype = C.c_char_p
@@ -222,6 +239,19 @@ class Engine:
         out = np.empty((last_n, int(np.prod(shp))))
         _chk(lib().bnmf_window(self._h, IDS[name], last_n, _dp(out)))
         return [out[i].reshape(shp, order="F") for i in range(last_n)]
+
+    def run_until(self, cc, state=None):
+        """Warm-up to convergence in one C-ABI call.  cc: new_convergence_control() dict; state: BnmfConvergenceState to
+        continue from (None = fresh).  Returns (metrics rows, MAP rows [n_checks x NMAPROW], state)."""
+        c = BnmfConvergenceControl(cc["MAP_over"], cc["MAP_every"], cc["Ninarow_nochange"], cc["Ninarow_nobest"], cc["miniters"],
+                                   cc["maxiters"], CC_METRICS.index(cc["metric"]), 0, cc["tol"])
+        st = state or BnmfConvergenceState()
+        cap_rows = max(cc["maxiters"] - self.iter, 0) + 1
+        cap_checks = cap_rows // cc["MAP_every"] + 2
+        rows, maps = np.empty((cap_rows, NMETRIC)), np.empty((cap_checks, NMAPROW))
+        nr, nc = C.c_int(), C.c_int()
+        _chk(lib().bnmf_run_until(self._h, C.byref(c), C.byref(st), _dp(rows), cap_rows, C.byref(nr), _dp(maps), cap_checks, C.byref(nc)))
+        return rows[:nr.value].copy(), maps[:nc.value].copy(), st
 
     def map(self, last_n, credible_interval=0.95):
         """get_MAP_ over the last `last_n` recorded samples, on the device (one C-ABI call)."""

@@ -65,7 +65,8 @@ class bayesNMF_sampler:
                  MH=None, convergence_control=None, prop_temp=0.2, post_warmup=None,
                  output_dir=None, overwrite=False, hyperprior_params=None, init_prior_params=None,
                  init_params=None, verbosity=1, periodic_save=True, save_all_samples=False,
-                 seed=1, chain_id=0, device=0, save_Z=False, engine_factory=None, intermediate_credible_intervals=False):
+                 seed=1, chain_id=0, device=0, save_Z=False, engine_factory=None, intermediate_credible_intervals=False,
+                 engine_side_convergence=True):
         if MH is None:
             MH = likelihood == "poisson" and prior in ("truncnormal", "exponential")
         cc = dict(convergence_control) if convergence_control is not None else new_convergence_control()
@@ -99,7 +100,8 @@ class bayesNMF_sampler:
         self.specs = dict(rank=rank, likelihood=likelihood, prior=prior, MH=bool(MH), learning_rank=learning_rank,
                           convergence_control=cc, output_dir=final_dir, overwrite=overwrite, verbosity=verbosity,
                           periodic_save=periodic_save, save_all_samples=save_all_samples,
-                          intermediate_credible_intervals=intermediate_credible_intervals)
+                          intermediate_credible_intervals=intermediate_credible_intervals,
+                          engine_side_convergence=engine_side_convergence)
         if learning_rank:
             self.specs["prop_temp"] = prop_temp
             self.specs["rank_method"] = rank_method
@@ -276,7 +278,10 @@ class bayesNMF_sampler:
         if final:
             A = np.ones((1, P.shape[1]))
         sm = self.state["sample_metrics"]
-        win = sm[sm["iter"].isin(self.MAP["idx"])]
+        cc_ = self.specs["convergence_control"]
+        n_win = min(cc_["MAP_over"], self.state["iter"])
+        window = np.arange(self.state["iter"] - n_win + 1, self.state["iter"] + 1)   # state$MAP_idx: the whole window, not MAP$idx
+        win = sm[sm["iter"].isin(window)]
         ll, lpost = float(win["loglikelihood"].mean()), float(win["logposterior"].mean())
         n_params = float(np.sum(A) * (G + K))
         if "RMSE" in self.MAP:                      # computed on the device with the window statistics
@@ -288,7 +293,7 @@ class bayesNMF_sampler:
         row = dict(iter=self.state["iter"], RMSE=rmse, KL=kl, loglikelihood=ll, logposterior=lpost, n_params=n_params,
                    BIC=-2 * ll + n_params * np.log(G), rank=float(np.sum(self.MAP["A"])),
                    MAP_A_counts=float(self.MAP["A_counts"][0][1]),
-                   mean_temp=float(np.mean(self.temperature_schedule[np.asarray(self.MAP["idx"]) - 1])))
+                   mean_temp=float(np.mean(self.temperature_schedule[window - 1])))
         if self.specs["MH"]:                        # compute_metrics_ uses the CURRENT acceptance matrices (R/utils.R:444-452)
             row["P_mean_acceptance_rate"] = float(sm["P_mean_acceptance_rate"].iloc[-1])
             row["E_mean_acceptance_rate"] = float(sm["E_mean_acceptance_rate"].iloc[-1])
@@ -324,6 +329,9 @@ class bayesNMF_sampler:
         self.log("Starting Gibbs sampler", verbosity=1)
         start = time.time()
         self.state["indent"] = 1
+        if (hasattr(self._chain, "run_until") and self._block_hook is None and not self.specs["periodic_save"]
+                and not self.specs["save_all_samples"] and self.specs.get("engine_side_convergence", True)):
+            self._run_until_on_engine(cc)
         while not self.state["converged"] and self.state["iter"] < cc["maxiters"]:
             it = self.state["iter"]
             nxt = (it // cc["MAP_every"] + 1) * cc["MAP_every"]
@@ -378,6 +386,43 @@ class bayesNMF_sampler:
         self.save_object()
         return self
 
+    def _run_until_on_engine(self, cc):
+        """The warm-up loop (blocks, MAP, MAP metrics, convergence bookkeeping) as one engine call (SURVEY.md 8 f2);
+        the R6-style state, both metric tables and the log lines are rebuilt from what it returns."""
+        from .engine import WHY
+        rows, maps, st = self._chain.run_until(cc)
+        if len(rows):
+            self._append_metrics(rows)
+            self.state["iter"] = int(rows[-1, 0])
+        names = ["iter", "RMSE", "KL", "loglikelihood", "logposterior", "n_params", "BIC", "rank", "MAP_A_counts", "mean_temp",
+                 "P_mean_acceptance_rate", "E_mean_acceptance_rate"]
+        flip = -1 if cc["metric"] in ("loglikelihood", "logposterior") else 1
+        for r in maps:
+            row = dict(zip(names, r[:12]))
+            if not self.specs["MH"]:
+                row.pop("P_mean_acceptance_rate"); row.pop("E_mean_acceptance_rate")
+            df = pd.DataFrame([row])
+            self.state["MAP_metrics"] = df if self.state["MAP_metrics"].empty else pd.concat([self.state["MAP_metrics"], df], ignore_index=True)
+            m = flip * row[cc["metric"]]
+            pcs = "NA" if np.isnan(r[12]) else f"{flip * round(r[12] * 100, 2)}"
+            self.log(f"iter = {int(r[0])}", verbosity=1)
+            self.state["indent"] = 2
+            self.log("Computing MAP", verbosity=1)
+            self.log("Checking convergence", verbosity=1)
+            self.log(f"{cc['metric']} = {round(m, 2)} | {pcs}% change | {int(r[13])} no change | {int(r[14])} no best | {int(r[15])} NA", verbosity=1)
+            self.state["indent"] = 1
+        if st.have_prev:
+            self.state.update(prev_MAP_metric=st.prev_MAP_metric, best_MAP_metric=st.best_MAP_metric,
+                              prev_percent_change=st.prev_percent_change, inarow_na=st.inarow_na,
+                              inarow_no_change=st.inarow_no_change, inarow_no_best=st.inarow_no_best)
+            if st.best_iter:
+                self.state["best_iter"] = st.best_iter
+        if st.converged:
+            self.state["converged"] = True
+            self.state["why"] = WHY[st.why]
+            self.state["converged_iter"] = self.state["iter"]
+            self.log(f"Converged at {self.state['iter']} due to {self.state['why']}", verbosity=1)
+
     def save_object(self):
         """save_object (R/bayesNMF_sampler.R:414-416): sampler.rds -> sampler.pkl (fields, not the device handle)."""
         keep = {k: v for k, v in self.__dict__.items() if k not in ("_chain", "log_con", "_block_hook")}
@@ -398,7 +443,7 @@ def bayesNMF(data, rank, likelihood="poisson", prior="truncnormal", rank_method=
              convergence_control=None, prop_temp=0.2, post_warmup=None, output_dir=None, overwrite=False,
              hyperprior_params=None, init_prior_params=None, init_params=None, periodic_save=True,
              save_all_samples=True, seed=1, chain_id=0, device=0, save_Z=False, engine_factory=None,
-             intermediate_credible_intervals=False, n_chains=1, devices=None):
+             intermediate_credible_intervals=False, n_chains=1, devices=None, engine_side_convergence=True):
     """bayesNMF() (R/bayesNMF.R:24-138): build the sampler and run it; with rank_method = "BIC" run one
     fixed-rank sampler per rank and return dict(results, best_rank, sampler).
 
@@ -411,7 +456,8 @@ def bayesNMF(data, rank, likelihood="poisson", prior="truncnormal", rank_method=
                   prop_temp=prop_temp, post_warmup=post_warmup, output_dir=output_dir, overwrite=overwrite,
                   hyperprior_params=hyperprior_params, init_prior_params=init_prior_params, init_params=init_params,
                   periodic_save=periodic_save, save_all_samples=save_all_samples, seed=seed, save_Z=save_Z,
-                  engine_factory=engine_factory, intermediate_credible_intervals=intermediate_credible_intervals)
+                  engine_factory=engine_factory, intermediate_credible_intervals=intermediate_credible_intervals,
+                  engine_side_convergence=engine_side_convergence)
         return run_chains(data, rank, n_chains=n_chains, devices=devices, **kw)
     if output_dir is None:
         output_dir = f"nmf_{likelihood}_{prior}"
@@ -420,15 +466,31 @@ def bayesNMF(data, rank, likelihood="poisson", prior="truncnormal", rank_method=
                   overwrite=overwrite, hyperprior_params=hyperprior_params, init_prior_params=init_prior_params,
                   init_params=init_params, verbosity=1, periodic_save=periodic_save,
                   save_all_samples=save_all_samples, seed=seed, chain_id=chain_id, device=device, save_Z=save_Z,
-                  engine_factory=engine_factory, intermediate_credible_intervals=intermediate_credible_intervals)
+                  engine_factory=engine_factory, intermediate_credible_intervals=intermediate_credible_intervals,
+                  engine_side_convergence=engine_side_convergence)
     ranks = np.atleast_1d(np.asarray(rank, dtype=int))
     if ranks.size > 1 and rank_method == "BIC":
-        results = []
-        for k in ranks:
-            s = bayesNMF_sampler(data, int(k), output_dir=os.path.join(output_dir, f"rank_{k}"), **common)
+        # One fixed-rank sampler per rank (R/bayesNMF.R:66-126).  The reference runs them one after the other; they are
+        # independent, so here they run concurrently, one host thread per sampler, spread over the visible GPUs
+        # (SURVEY.md 8 f2); `devices` picks the GPUs, default all of them.
+        import concurrent.futures as cf
+        if devices is None:
+            try:
+                from .engine import device_count
+                devices = list(range(max(1, device_count()))) if engine_factory is None else [device]
+            except Exception:  # noqa: BLE001
+                devices = [device]
+        common.pop("device")
+
+        def one(i_k):
+            i, k = i_k
+            s = bayesNMF_sampler(data, int(k), output_dir=os.path.join(output_dir, f"rank_{k}"), device=devices[i % len(devices)], **common)
             s.run_gibbs_sampler()
             bic = float(s.state["MAP_metrics"].iloc[-1]["BIC"])
-            results.append(dict(rank=int(k), dir=s.specs["output_dir"], BIC=bic, time=s.time["total"], sampler=s))
+            return dict(rank=int(k), dir=s.specs["output_dir"], BIC=bic, time=s.time["total"], sampler=s)
+
+        with cf.ThreadPoolExecutor(max_workers=max(1, min(len(ranks), 4 * len(devices)))) as ex:
+            results = list(ex.map(one, enumerate(ranks)))
         best = min(results, key=lambda r: r["BIC"])
         return dict(results=pd.DataFrame([{k: v for k, v in r.items() if k != "sampler"} for r in results]).sort_values("BIC"),
                     best_rank=best["rank"], sampler=best["sampler"])

@@ -120,6 +120,30 @@ int bnmf_map(bnmf_handle* h, int last_n, double credible_interval, double* P_mea
              double* A_mode, double* top_A, double* P_lower, double* P_upper, double* E_lower,
              double* E_upper, int32_t* used, bnmf_map_info* info);
 
+/* The sampling loop up to convergence as ONE call (run_gibbs_sampler, R/bayesNMF_sampler.R:268-330, warm-up part):
+ * blocks of iterations up to the next MAP check; at a check get_MAP_ over the last MAP_over samples on the device,
+ * update_MAP_metrics_ (R/utils.R:356-397) and check_convergence_ (R/convergence.R:60-154).
+ *   metrics  [cap_rows][BNMF_NMETRIC]   one row per iteration run (n_rows returned)
+ *   map_rows [cap_checks][BNMF_NMAPROW] one row per check: iter, RMSE, KL, loglikelihood, logposterior, n_params, BIC,
+ *            rank, MAP_A_counts, mean_temp, P/E_mean_acceptance_rate (state$MAP_metrics columns), then percent change,
+ *            inarow_no_change, inarow_no_best, inarow_na, converged after that check.
+ * `st` carries state$prev_MAP_metric ... between calls (zero-initialise it for a fresh chain). */
+#define BNMF_NMAPROW 17
+typedef struct {
+  int32_t MAP_over, MAP_every, Ninarow_nochange, Ninarow_nobest, miniters, maxiters;
+  int32_t metric;                /* 0 loglikelihood, 1 logposterior, 2 RMSE, 3 KL, 4 BIC */
+  int32_t _pad;
+  double tol;
+} bnmf_convergence_control;
+typedef struct {
+  int32_t converged, why /* 0 -, 1 "no change", 2 "no best", 3 "max iters" */, best_iter, inarow_na, inarow_no_change,
+          inarow_no_best, have_prev, n_checks;
+  double prev_MAP_metric, best_MAP_metric, prev_percent_change;
+} bnmf_convergence_state;
+int bnmf_run_until(bnmf_handle* h, const bnmf_convergence_control* cc, bnmf_convergence_state* st,
+                   double* metrics_rowmajor, int cap_rows, int* n_rows, double* map_rows, int cap_checks,
+                   int* n_checks);
+
 int bnmf_get_iter(bnmf_handle* h, int* iter);
 
 /* average device time (ms) of each kernel class over n_iter iterations, measured with HIP

@@ -167,3 +167,17 @@ def test_model_check_errors(tmp_path):
         bayesNMF_sampler(M, 2, prior="truncnormal", MH=False, output_dir=str(tmp_path / "b"), engine_factory=_OracleChain)
     with pytest.raises(ValueError, match="with `likelihood = 'normal'`"):
         bayesNMF_sampler(M, 2, likelihood="normal", prior="gamma", MH=False, output_dir=str(tmp_path / "c"), engine_factory=_OracleChain)
+
+
+def test_BIC_sweep_concurrent_fixed_rank_chains(tmp_path):
+    """rank_method = "BIC" (R/bayesNMF.R:66-126): one fixed-rank sampler per rank, run concurrently; the best BIC wins."""
+    from bayesnmf_amd.sampler import bayesNMF
+    from bayesnmf_amd.convergence import new_convergence_control
+    from bayesnmf_amd.setup import synth_counts
+    M, _, _ = synth_counts(24, 40, 2, 5, mean_total=2500)
+    cc = new_convergence_control(MAP_over=30, MAP_every=15, miniters=45, maxiters=90)
+    r = bayesNMF(M, range(1, 4), likelihood="poisson", prior="gamma", rank_method="BIC", convergence_control=cc,
+                 output_dir=str(tmp_path / "bic"), periodic_save=False, save_all_samples=False, engine_factory=_OracleChain)
+    assert set(r) == {"results", "best_rank", "sampler"} and list(r["results"]["rank"].sort_values()) == [1, 2, 3]
+    assert r["best_rank"] == 2 and r["sampler"].dims["N"] == 2
+    assert r["results"].iloc[0]["BIC"] == r["results"]["BIC"].min()

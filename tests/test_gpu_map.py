@@ -120,3 +120,36 @@ def test_bayesNMF_uses_device_map(tmp_path, monkeypatch):
     assert np.allclose(dev["lo"], s.credible_intervals["P"]["lower"], rtol=1e-12)
     assert np.allclose(dev["hi"], s.credible_intervals["E"]["upper"], rtol=1e-12)
     s.close()
+
+
+@pytest.mark.parametrize("model", ["gamma_fixed", "gamma_rank", "truncnormal_mh"])
+def test_run_until_matches_blockwise_loop(model, tmp_path):
+    """f2: the warm-up loop on the engine side (bnmf_run_until: blocks, MAP, MAP metrics, check_convergence_) gives the
+    same chain, the same MAP-metrics table and the same stopping point as the block-by-block host loop."""
+    from bayesnmf_amd.sampler import bayesNMF
+    from bayesnmf_amd.convergence import new_convergence_control
+    from bayesnmf_amd.setup import synth_counts
+    M, _, _ = synth_counts(96, 64, 3, 21)
+    if model == "gamma_fixed":
+        kw, rank = dict(prior="gamma"), 3
+        cc = new_convergence_control(MAP_over=100, MAP_every=50, miniters=100, maxiters=600)
+    elif model == "gamma_rank":
+        kw, rank = dict(prior="gamma", prop_temp=0.3), range(1, 7)
+        cc = new_convergence_control(MAP_over=60, MAP_every=30, miniters=90, maxiters=420, tol=0.01)
+    else:
+        kw, rank = dict(prior="truncnormal", post_warmup=40), 3
+        cc = new_convergence_control(MAP_over=60, MAP_every=30, miniters=90, maxiters=300, tol=0.01)
+    res = []
+    for eng in (True, False):
+        s = bayesNMF(M, rank, convergence_control=cc, output_dir=str(tmp_path / f"o{int(eng)}"), periodic_save=False,
+                     save_all_samples=False, seed=5, engine_side_convergence=eng, **kw)
+        res.append(dict(iter=s.state["iter"], why=s.state.get("why"), sm=s.state["sample_metrics"].to_numpy(),
+                        mm=s.state["MAP_metrics"].to_numpy(), cols=list(s.state["MAP_metrics"].columns), P=s.MAP["P"].copy(),
+                        st={k: s.state.get(k) for k in ("inarow_no_change", "inarow_no_best", "inarow_na", "best_iter", "converged_iter")}))
+        s.close()
+    a, b = res
+    assert a["iter"] == b["iter"] and a["why"] == b["why"] and a["st"] == b["st"]
+    assert np.array_equal(np.nan_to_num(a["sm"]), np.nan_to_num(b["sm"]))          # the chains are identical
+    assert a["cols"] == b["cols"] and a["mm"].shape == b["mm"].shape
+    assert np.allclose(a["mm"], b["mm"], rtol=1e-10, equal_nan=True)
+    assert np.allclose(a["P"], b["P"], rtol=1e-12)
