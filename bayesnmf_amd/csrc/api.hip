@@ -1082,6 +1082,117 @@ int bnmf_run_until(bnmf_handle* h, const bnmf_convergence_control* cc, bnmf_conv
   return 0;
 }
 
+// rectangular assignment problem, n rows <= m columns, minimising sum of cost[i][col(i)] (Hungarian algorithm with
+// potentials, O(n^2 m)); returns the column of every row
+static std::vector<int> hungarian_min(const std::vector<double>& cost, int n, int m) {
+  const double INF = 1e300;
+  std::vector<double> u(n + 1, 0.0), v(m + 1, 0.0);
+  std::vector<int> p(m + 1, 0), way(m + 1, 0);
+  for (int i = 1; i <= n; ++i) {
+    p[0] = i;
+    int j0 = 0;
+    std::vector<double> minv(m + 1, INF);
+    std::vector<char> usedc(m + 1, 0);
+    do {
+      usedc[j0] = 1;
+      const int i0 = p[j0];
+      double delta = INF;
+      int j1 = 0;
+      for (int j = 1; j <= m; ++j) if (!usedc[j]) {
+        const double cur = cost[(size_t)(i0 - 1) * m + (j - 1)] - u[i0] - v[j];
+        if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
+        if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+      }
+      for (int j = 0; j <= m; ++j) { if (usedc[j]) { u[p[j]] += delta; v[j] -= delta; } else minv[j] -= delta; }
+      j0 = j1;
+    } while (p[j0] != 0);
+    do { const int j1 = way[j0]; p[j0] = p[j1]; j0 = j1; } while (j0);
+  }
+  std::vector<int> col(n, -1);
+  for (int j = 1; j <= m; ++j) if (p[j]) col[p[j] - 1] = j - 1;
+  return col;
+}
+static double quantile7(std::vector<double> x, double prob) {
+  std::sort(x.begin(), x.end());
+  const double hq = (x.size() - 1) * prob;
+  const size_t j = (size_t)std::floor(hq);
+  const double g = hq - (double)j;
+  return (1.0 - g) * x[j] + g * x[std::min(j + 1, x.size() - 1)];
+}
+
+int bnmf_assign(bnmf_handle* h, int last_n, const int32_t* used, const double* ref, int R, const int32_t* keep, const double* MAP_P,
+                double ci, double* votes, int32_t* assigned, double* MAP_cosine, double* lower, double* upper) {
+  if (!h || !ref || !votes || !assigned) return fail(BNMF_EINVAL, "bnmf_assign: null argument");
+  const int W = h->cfg.window;
+  if (W <= 0 || !h->arr[BNMF_P].ring) return fail(BNMF_ESTATE, "bnmf_assign: no recorded samples (window = 0)");
+  if (last_n < 1 || last_n > W || last_n > h->iter) return fail(BNMF_ESIZE, "bnmf_assign: last_n = %d but only min(window = %d, iter = %d) samples are kept", last_n, W, h->iter);
+  if (R < 1) return fail(BNMF_EINVAL, "bnmf_assign: empty reference");
+  const int K = h->cfg.K, N = h->cfg.N;
+  std::vector<int> slots, sig;
+  for (int s = 0; s < last_n; ++s) if (!used || used[s]) slots.push_back((int)((size_t)(h->iter - last_n + s) % (size_t)h->wcap));
+  for (int n = 0; n < N; ++n) if (!keep || keep[n]) sig.push_back(n);
+  const int nu = (int)slots.size(), nk = (int)sig.size();
+  for (int i = 0; i < N * R; ++i) votes[i] = 0.0;
+  for (int n = 0; n < N; ++n) { assigned[n] = -1; if (MAP_cosine) MAP_cosine[n] = std::nan(""); if (lower) lower[n] = std::nan(""); if (upper) upper[n] = std::nan(""); }
+  if (nu == 0 || nk == 0) return 0;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  std::vector<double> refT((size_t)K * R), rn2(R, 0.0);
+  for (int j = 0; j < R; ++j) for (int k = 0; k < K; ++k) { const double v = ref[k + (size_t)K * j]; refT[(size_t)k * R + j] = v; rn2[j] += v * v; }
+  const size_t nout = (size_t)nu * nk * R;
+  double *dRef = nullptr, *dN2 = nullptr, *dOut = nullptr; int *dSl = nullptr, *dSig = nullptr;
+  auto freeall = [&]() { hipFree(dRef); hipFree(dN2); hipFree(dOut); hipFree(dSl); hipFree(dSig); };
+#define ASG(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { freeall(); return fail(BNMF_EHIP, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+  ASG(hipMalloc(&dRef, refT.size() * 8)); ASG(hipMalloc(&dN2, R * 8)); ASG(hipMalloc(&dOut, nout * 8));
+  ASG(hipMalloc(&dSl, nu * sizeof(int))); ASG(hipMalloc(&dSig, nk * sizeof(int)));
+  ASG(hipMemcpy(dRef, refT.data(), refT.size() * 8, hipMemcpyHostToDevice)); ASG(hipMemcpy(dN2, rn2.data(), R * 8, hipMemcpyHostToDevice));
+  ASG(hipMemcpy(dSl, slots.data(), nu * sizeof(int), hipMemcpyHostToDevice)); ASG(hipMemcpy(dSig, sig.data(), nk * sizeof(int), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_ref_cosine, dim3(nu, nk), dim3(128), 0, h->stream, (const double*)h->arr[BNMF_P].ring, (size_t)K * N, K, (const int*)dSl,
+                     (const int*)dSig, nk, (const double*)dRef, (const double*)dN2, R, dOut);
+  ASG(hipGetLastError());
+  std::vector<double> cosv(nout);
+  ASG(hipMemcpyAsync(cosv.data(), dOut, nout * 8, hipMemcpyDeviceToHost, h->stream));
+  ASG(hipStreamSynchronize(h->stream));
+#undef ASG
+  freeall();
+  // one Hungarian assignment per sample (maximise the total cosine); the cosine of a chosen pair is its vote
+  const bool tr = nk > R;                                  // more signatures than references: assign references to signatures
+  std::vector<double> cost;
+  for (int s = 0; s < nu; ++s) {
+    const double* c = cosv.data() + (size_t)s * nk * R;
+    if (!tr) {
+      cost.assign((size_t)nk * R, 0.0);
+      for (size_t i = 0; i < (size_t)nk * R; ++i) cost[i] = -c[i];
+      const std::vector<int> col = hungarian_min(cost, nk, R);
+      for (int i = 0; i < nk; ++i) votes[sig[i] + (size_t)N * col[i]] += c[(size_t)i * R + col[i]];
+    } else {
+      cost.assign((size_t)R * nk, 0.0);
+      for (int i = 0; i < nk; ++i) for (int j = 0; j < R; ++j) cost[(size_t)j * nk + i] = -c[(size_t)i * R + j];
+      const std::vector<int> row = hungarian_min(cost, R, nk);
+      for (int j = 0; j < R; ++j) votes[sig[row[j]] + (size_t)N * j] += c[(size_t)row[j] * R + j];
+    }
+  }
+  for (int i = 0; i < nk; ++i) {                           // which.max(prop_votes): first maximum
+    const int n = sig[i];
+    int best = -1; double bv = 0.0;
+    for (int j = 0; j < R; ++j) if (votes[n + (size_t)N * j] > bv) { bv = votes[n + (size_t)N * j]; best = j; }
+    assigned[n] = best;
+    if (best < 0) continue;
+    if (MAP_P && MAP_cosine) {
+      double dot = 0.0, nn = 0.0;
+      for (int k = 0; k < K; ++k) { const double p = MAP_P[k + (size_t)K * n]; dot += p * ref[k + (size_t)K * best]; nn += p * p; }
+      MAP_cosine[n] = dot / std::sqrt(nn * rn2[best]);
+    }
+    if (ci > 0.0 && ci < 1.0 && (lower || upper)) {
+      std::vector<double> x(nu);
+      for (int s = 0; s < nu; ++s) x[s] = cosv[((size_t)s * nk + i) * R + best];
+      if (lower) lower[n] = quantile7(x, (1.0 - ci) / 2.0);
+      if (upper) upper[n] = quantile7(x, 1.0 - (1.0 - ci) / 2.0);
+    }
+  }
+  return 0;
+}
+
 // ---- device-side probes for the parity tests ----
 int bnmf_test_math(int device, int fn, const double* in, double* out, size_t n) {
   HIPCHK(hipSetDevice(device));

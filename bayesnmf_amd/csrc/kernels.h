@@ -662,6 +662,20 @@ __global__ __launch_bounds__(256) void k_map_fit(const int32_t* M, const double*
   if (lane == 0) { colsse[g] = sse; colkl[g] = kl; }
 }
 
+// ---- posterior reference assignment: pairwise_sim of every used sample's included signatures with the
+// reference catalogue (lsa::cosine, R/helpers.R:218-268).  One workgroup per (sample, signature); lane = reference
+// signature j (refT is the catalogue stored row-major [k][j], so the lanes read consecutive addresses).
+__global__ __launch_bounds__(128) void k_ref_cosine(const double* ringP, size_t lenP, int K, const int* slots, const int* sig, int nk,
+                                                     const double* refT, const double* refnorm2, int R, double* out /* [s][i][j] */) {
+  const int s = blockIdx.x, i = blockIdx.y;
+  const double* Pn = ringP + (size_t)slots[s] * lenP + (size_t)K * sig[i];
+  for (int j = threadIdx.x; j < R; j += blockDim.x) {
+    double dot = 0.0, nn = 0.0;
+    for (int k = 0; k < K; ++k) { const double p = Pn[k]; dot = dot + p * refT[(size_t)k * R + j]; nn = nn + p * p; }
+    out[((size_t)s * nk + i) * R + j] = dot / dsqrt(nn * refnorm2[j]);
+  }
+}
+
 // ---- constructor draws of the prior parameters from the hyper-priors ----
 // init_prior_params_ R/sample_priors.R:15-141 (all three families are rgamma(shape, rate) draws
 // for the Gamma / Exponential priors).  redraw[n] != 0: column n (P side) / row n (E side) missing.

@@ -66,7 +66,7 @@ CC_METRICS = ["loglikelihood", "logposterior", "RMSE", "KL", "BIC"]
 WHY = {0: None, 1: "no change", 2: "no best", 3: "max iters"}
 
 ABI_SYMBOLS = ["bnmf_create", "bnmf_destroy", "bnmf_set_array", "bnmf_get_array", "bnmf_get_array_i32",
-               "bnmf_init", "bnmf_run", "bnmf_window", "bnmf_map", "bnmf_run_until", "bnmf_get_iter", "bnmf_profile",
+               "bnmf_init", "bnmf_run", "bnmf_window", "bnmf_map", "bnmf_run_until", "bnmf_assign", "bnmf_get_iter", "bnmf_profile",
                "bnmf_kernel_name", "bnmf_test_math", "bnmf_test_sampler", "bnmf_test_philox",
                "bnmf_device_info", "bnmf_device_count", "bnmf_last_error", "bnmf_version"]
 
@@ -90,6 +90,7 @@ def lib():
         L.bnmf_map.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, dp, dp, dp, dp, dp, dp, dp, ip, C.POINTER(BnmfMapInfo)]
         L.bnmf_run_until.argtypes = [C.c_void_p, C.POINTER(BnmfConvergenceControl), C.POINTER(BnmfConvergenceState), dp, C.c_int,
                                      C.POINTER(C.c_int), dp, C.c_int, C.POINTER(C.c_int)]
+        L.bnmf_assign.argtypes = [C.c_void_p, C.c_int, ip, dp, C.c_int, ip, dp, C.c_double, dp, ip, dp, dp, dp]
         L.bnmf_get_iter.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.bnmf_profile.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
         L.bnmf_kernel_name.restype = C.c_char_p
@@ -252,6 +253,23 @@ class Engine:
         nr, nc = C.c_int(), C.c_int()
         _chk(lib().bnmf_run_until(self._h, C.byref(c), C.byref(st), _dp(rows), cap_rows, C.byref(nr), _dp(maps), cap_checks, C.byref(nc)))
         return rows[:nr.value].copy(), maps[:nc.value].copy(), st
+
+    def assign(self, last_n, reference_P, used=None, keep=None, MAP_P=None, credible_interval=0.95):
+        """assign_signatures_ensemble_ over recorded samples: votes (N x R), assigned reference per signature (-1 = not
+        kept), cosine of the MAP estimate and credible bounds of the per-sample cosines."""
+        N = self.N
+        ref = np.asfortranarray(reference_P, dtype=np.float64)
+        R = ref.shape[1]
+        ip = C.POINTER(C.c_int32)
+        u = None if used is None else np.ascontiguousarray(used, dtype=np.int32)
+        kp = None if keep is None else np.ascontiguousarray(keep, dtype=np.int32)
+        mp = None if MAP_P is None else np.asfortranarray(MAP_P, dtype=np.float64)
+        votes, asg = np.zeros(N * R), np.empty(N, dtype=np.int32)
+        mc, lo, hi = np.empty(N), np.empty(N), np.empty(N)
+        _chk(lib().bnmf_assign(self._h, last_n, None if u is None else u.ctypes.data_as(ip), _dp(ref.ravel(order="F")), R,
+                               None if kp is None else kp.ctypes.data_as(ip), None if mp is None else _dp(mp.ravel(order="F")),
+                               float(credible_interval), _dp(votes), asg.ctypes.data_as(ip), _dp(mc), _dp(lo), _dp(hi)))
+        return dict(votes=votes.reshape((N, R), order="F"), assigned=asg, MAP_cosine=mc, lower_cosine=lo, upper_cosine=hi)
 
     def map(self, last_n, credible_interval=0.95):
         """get_MAP_ over the last `last_n` recorded samples, on the device (one C-ABI call)."""

@@ -423,6 +423,45 @@ class bayesNMF_sampler:
             self.state["converged_iter"] = self.state["iter"]
             self.log(f"Converged at {self.state['iter']} due to {self.state['why']}", verbosity=1)
 
+    def assign_signatures_ensemble(self, reference_P, reference_names=None, idxs="MAP_idx", credible_interval=0.95):
+        """assign_signatures_ensemble_ (R/postprocessing.R:175-341): every posterior sample of the MAP window votes, with
+        its cosine similarity as weight, for the Hungarian assignment of its included signatures to the reference
+        catalogue `reference_P` (K x R matrix; the reference's default is its bundled COSMIC v3.3.1 SBS table).
+        Returns dict(assignments, votes) (data frames with the reference's columns) and stores them in
+        self.reference_comparison (fields reference_P, idxs, keep_sigs, assignments, votes)."""
+        ref = np.asarray(reference_P, dtype=float)
+        if ref.shape[0] != self.dims["K"]:
+            raise ValueError(f"Reference matrix has {ref.shape[0]} rows, but data has {self.dims['K']} rows.")
+        names = list(reference_names) if reference_names is not None else list(range(1, ref.shape[1] + 1))
+        cc = self.specs["convergence_control"]
+        n = min(cc["MAP_over"], self.state["iter"])
+        first_iter = self.state["iter"] - n + 1
+        idx = self.MAP["idx"] if isinstance(idxs, str) else list(idxs)
+        used = np.zeros(n, dtype=np.int32)
+        used[np.asarray(idx) - first_iter] = 1
+        N = self.dims["N"]
+        A = np.ravel(self.MAP["A"])
+        if len(self.MAP["keep_sigs"]) == N and (A == 0).any():      # get_MAP(final = FALSE): only included signatures
+            keep_sigs = np.where(A == 1)[0]
+            self.MAP["sig_idx"] = keep_sigs
+        else:
+            keep_sigs = np.asarray(self.MAP["keep_sigs"])
+            self.MAP["sig_idx"] = np.arange(len(keep_sigs))
+        keep = np.zeros(N, dtype=np.int32); keep[keep_sigs] = 1
+        MAP_full = np.zeros((self.dims["K"], N)); MAP_full[:, keep_sigs] = np.asarray(self.MAP["P"])[:, self.MAP["sig_idx"]]
+        r = self._chain.assign(n, ref, used=used, keep=keep, MAP_P=MAP_full, credible_interval=credible_interval)
+        rows = []
+        for i in keep_sigs:
+            tot = r["votes"][i].sum()
+            for j in np.argsort(-r["votes"][i], kind="stable"):
+                if r["votes"][i, j] > 0:
+                    rows.append(dict(sig_est=int(i) + 1, sig_ref=names[j], prop_votes=r["votes"][i, j] / tot))
+        votes = pd.DataFrame(rows, columns=["sig_est", "sig_ref", "prop_votes"])
+        assignments = pd.DataFrame([dict(sig_est=int(i) + 1, sig_ref=names[r["assigned"][i]], MAP_cosine=r["MAP_cosine"][i],
+                                         lower_cosine=r["lower_cosine"][i], upper_cosine=r["upper_cosine"][i]) for i in keep_sigs])
+        self.reference_comparison.update(reference_P=ref, idxs=idx, keep_sigs=keep_sigs, assignments=assignments, votes=votes)
+        return dict(assignments=assignments, votes=votes)
+
     def save_object(self):
         """save_object (R/bayesNMF_sampler.R:414-416): sampler.rds -> sampler.pkl (fields, not the device handle)."""
         keep = {k: v for k, v in self.__dict__.items() if k not in ("_chain", "log_con", "_block_hook")}

@@ -144,6 +144,17 @@ int bnmf_run_until(bnmf_handle* h, const bnmf_convergence_control* cc, bnmf_conv
                    double* metrics_rowmajor, int cap_rows, int* n_rows, double* map_rows, int cap_checks,
                    int* n_checks);
 
+/* Posterior reference assignment (assign_signatures_ensemble_, R/postprocessing.R:175-341; hungarian_assignment,
+ * pairwise_sim, R/helpers.R:218-398) over the recorded samples flagged in used[last_n] (MAP$idx; NULL = all):
+ * cosine similarities of every sample's included signatures (keep[N] flags; NULL = all) with the reference catalogue
+ * reference_P (K x R, column-major) on the device, one Hungarian assignment per sample maximising the total cosine,
+ * votes[n + N*j] = sum over samples of the cosine of the pairs (n, j) chosen; assigned_ref[n] = which.max of the votes
+ * (-1 for a signature that is not kept); MAP_P (K x N, may be NULL) -> MAP_cosine[n]; lower/upper_cosine[n] =
+ * quantile(type 7) of the per-sample cosine between signature n and its assigned reference. */
+int bnmf_assign(bnmf_handle* h, int last_n, const int32_t* used, const double* reference_P, int R,
+                const int32_t* keep, const double* MAP_P, double credible_interval, double* votes,
+                int32_t* assigned_ref, double* MAP_cosine, double* lower_cosine, double* upper_cosine);
+
 int bnmf_get_iter(bnmf_handle* h, int* iter);
 
 /* average device time (ms) of each kernel class over n_iter iterations, measured with HIP
