@@ -5,8 +5,10 @@
 # sample_params, record_sample, update_sample_metrics) by ONE `.Call` per block of iterations.
 # Everything else (get_MAP, check_convergence, logging, save_object, summary/plot) is the reference's
 # own code operating on fields that are refreshed from the device at block boundaries.
-# (Not runnable in this repository's container: no R.  The Python mirror bayesnmf_amd/sampler.py is the
-#  tested equivalent.)
+# EXPERIMENTAL: not runnable in this repository's container (no R).  The Python mirror bayesnmf_amd/sampler.py is
+# the tested equivalent and performs the same C-ABI call sequence; keep this file logic-free.  Faster paths that the
+# mirror uses and an R maintainer can bind the same way: bnmf_map (get_MAP on the device), bnmf_run_until (warm-up to
+# convergence in one call), bnmf_assign (assign_signatures_ensemble_): see INTEGRATION.md.
 
 .bnmf_ids <- c(P = 0L, E = 1L, A = 2L, R = 3L, Z = 4L, sigmasq = 7L,
                Alpha_p = 10L, Beta_p = 11L, Alpha_e = 12L, Beta_e = 13L, Mu_p = 14L, Sigmasq_p = 15L,
@@ -70,7 +72,13 @@ bayesNMF_sampler_hip <- R6::R6Class(
                            as.integer(private$hip$chain_id), as.integer(private$hip$device))
       for (nm in names(self$hyperprior_params)) if (nm %in% names(.bnmf_ids) && is.matrix(self$hyperprior_params[[nm]]))
         .Call("C_bnmf_set_array", self$handle, .bnmf_ids[[nm]], as.double(self$hyperprior_params[[nm]]))
-      for (nm in skip) .Call("C_bnmf_set_array", self$handle, .bnmf_ids[[nm]], as.double(self$params[[nm]]))
+      # prior parameters of iteration 1: the reference's constructor has already filled self$prior_params (user-supplied
+      # init_prior_params verbatim, the rest drawn from the hyper-priors in R, R/sample_priors.R:15-141).  All of them go
+      # to the device, which keeps supplied arrays verbatim (bnmf_set_array before bnmf_init), so samples$<name>[[1]]
+      # equals what the constructor produced (vignettes/advanced.qmd:181-185, :245-249, :315-319).
+      for (nm in names(self$prior_params)) if (nm %in% names(.bnmf_ids) && is.matrix(self$prior_params[[nm]]))
+        .Call("C_bnmf_set_array", self$handle, .bnmf_ids[[nm]], as.double(self$prior_params[[nm]]))
+      for (nm in skip) if (nm %in% names(.bnmf_ids)) .Call("C_bnmf_set_array", self$handle, .bnmf_ids[[nm]], as.double(self$params[[nm]]))
       row <- .Call("C_bnmf_init", self$handle)
       private$pull_state(); private$bind_metrics(matrix(row, ncol = 1))
     },
@@ -93,15 +101,24 @@ bayesNMF_sampler_hip <- R6::R6Class(
       for (nm in names(self$prior_params)) if (nm %in% names(.bnmf_ids))
         self$prior_params[[nm]] <- get(nm, if (grepl("_p$", nm)) c(K, N) else c(N, G))
     },
+    # samples[[name]][[i]] of the last n recorded iterations (record_sample, R/bayesNMF_sampler.R:651-672): every name the
+    # reference records (params, prior_params, acceptance rates, sigmasq).  With save_all_samples the lists are indexed
+    # by iteration (as in the reference) and MAP_idx is the last MAP_over iterations; otherwise positions 1..n.
     pull_window = function() {
       n <- min(self$specs$convergence_control$MAP_over, self$state$iter)
       K <- self$dims$K; N <- self$dims$N; G <- self$dims$G
-      for (nm in c("P", "E", "A")) {
-        d <- switch(nm, P = c(K, N), E = c(N, G), A = c(1, N))
+      nms <- c("P", "E", "A", "R", names(self$prior_params))
+      if (self$specs$MH) nms <- c(nms, "P_acceptance_rate", "E_acceptance_rate")
+      if (self$specs$likelihood == "normal") nms <- c(nms, "sigmasq")
+      first <- if (self$specs$save_all_samples) self$state$iter - n + 1 else 1
+      for (nm in intersect(nms, names(.bnmf_ids))) {
+        d <- if (nm == "A") c(1, N) else if (nm == "R") 1 else if (nm == "sigmasq") G else
+             if (nm == "P" || grepl("_p$", nm) || nm == "P_acceptance_rate") c(K, N) else c(N, G)
         w <- .Call("C_bnmf_window", self$handle, .bnmf_ids[[nm]], as.integer(n), as.double(prod(d)))
-        self$samples[[nm]] <- lapply(seq_len(n), function(i) array(w[, i], dim = d))
+        if (is.null(self$samples[[nm]])) self$samples[[nm]] <- list()
+        for (i in seq_len(n)) self$samples[[nm]][[first + i - 1]] <- array(w[, i], dim = d)
       }
-      self$state$MAP_idx <- seq_len(n)
+      self$state$MAP_idx <- seq(first, first + n - 1)
     }
   )
 )
