@@ -51,6 +51,7 @@ struct bnmf_handle {
   double *dLut = nullptr, *dTemp = nullptr, *dMetrics = nullptr, *dRaw = nullptr, *dRankCol = nullptr, *dRankMhat = nullptr;
   uint32_t* dRankSync = nullptr; int rank_grid = 0; bool rank_reg = false; void* dRankDbg = nullptr;
   int32_t* dMt = nullptr; double* dEt = nullptr;
+  int32_t* zring = nullptr;            // save_Z with a window: samples$Z, [wcap][K*N*G] int32 (only if it fits BNMF_ZRING_GB, default 32)
   double *dMhat = nullptr, *dAccPn = nullptr, *dAccEpart = nullptr; int* dNzE = nullptr; int mh_S = 1; size_t mhe_lds = 0;
   size_t metrics_rows = 0;
   int maxM = 0, nblkE = 0;
@@ -360,7 +361,7 @@ int bnmf_destroy(bnmf_handle* h) {
   hipFree(h->dR); hipFree(h->dRedraw); hipFree(h->dEsum); hipFree(h->dPsum); hipFree(h->dlpPn);
   hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol); if (h->dRankMhat) hipFree(h->dRankMhat); if (h->dRankSync) hipFree(h->dRankSync);
   if (h->dMhat) hipFree(h->dMhat); if (h->dAccPn) hipFree(h->dAccPn); if (h->dAccEpart) hipFree(h->dAccEpart); if (h->dNzE) hipFree(h->dNzE);
-  if (h->dEt) hipFree(h->dEt); if (h->dMt) hipFree(h->dMt);
+  if (h->dEt) hipFree(h->dEt); if (h->dMt) hipFree(h->dMt); if (h->zring) hipFree(h->zring);
   if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); if (h->side) hipStreamDestroy(h->side); if (h->side2) hipStreamDestroy(h->side2);
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
   if (h->dMap) hipFree(h->dMap);
@@ -632,7 +633,17 @@ static int ensure_rings(bnmf_handle* h) {
     Arr& a = h->arr[id];
     if (!a.ring) HIPCHK(hipMalloc(&a.ring, (size_t)h->wcap * id_len(h, id) * sizeof(double)));
   }
+  if (h->dZ && !h->zring) {                                // samples$Z (R/bayesNMF_sampler.R:245-252): K*N*G ints per kept sample
+    const double gb = (double)h->wcap * (double)id_len(h, BNMF_Z) * 4.0 / 1e9;
+    const char* e = getenv("BNMF_ZRING_GB");
+    if (gb <= (e ? atof(e) : 32.0)) HIPCHK(hipMalloc(&h->zring, (size_t)h->wcap * id_len(h, BNMF_Z) * sizeof(int32_t)));
+  }
   return 0;
+}
+static void record_Z(bnmf_handle* h, uint32_t t) {
+  if (!h->zring) return;
+  const size_t len = id_len(h, BNMF_Z);
+  hipMemcpyAsync(h->zring + (size_t)((t - 1) % (uint32_t)h->wcap) * len, h->dZ, len * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream);
 }
 // the Gibbs sweep (Poisson, no MH) records inside its producers: k_pdraw (P, and A, R when the rank is fixed), k_edraw (E),
 // k_side (prior parameters), k_sumA (A, R when the rank is learned).  The MH / Normal sweeps copy with k_record.
@@ -748,6 +759,7 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   }
   if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
   tm.begin(KN_ZALLOC, h->stream); if (int rc = launch_zalloc(h, t)) return rc; tm.end(KN_ZALLOC, h->stream);
+  record_Z(h, t);
   launch_reduce(h, t, row, tm);
   return 0;
 }
@@ -829,7 +841,7 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
     hipLaunchKernelGGL(k_rank_Aprior, dim3((N + 63) / 64), dim3(64), 0, h->stream, h->dev, 1u);
   }
   if (c.MH || c.likelihood == BNMF_NORMAL) launch_mh_metrics(h, 1u, true);
-  else if (int rc = launch_zalloc(h, 1u)) return rc;
+  else { if (int rc = launch_zalloc(h, 1u)) return rc; record_Z(h, 1u); }
   if (int rc = launch_record(h, 1u)) return rc;
   launch_reduce(h, 1u, 0, tm);
   flush_reduce(h, tm);
@@ -903,6 +915,19 @@ int bnmf_window(bnmf_handle* h, int id, int last_n, double* out) {
   if (W <= 0) return fail(BNMF_ESTATE, "bnmf_window: the handle was created with window = 0");
   if (last_n < 1 || last_n > W || last_n > h->iter) return fail(BNMF_ESIZE, "bnmf_window: last_n = %d but only min(window = %d, iter = %d) samples are kept", last_n, W, h->iter);
   if (id < 0 || id >= BNMF_ID_MAX) return fail(BNMF_EINVAL, "bnmf_window: unknown id %d", id);
+  if (id == BNMF_Z) {
+    if (!h->zring) return fail(BNMF_EUNSET, "bnmf_window: Z is not kept per sample (needs save_Z, a window, and window * K*N*G * 4 B within BNMF_ZRING_GB)");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t lenz = id_len(h, BNMF_Z);
+    std::vector<int32_t> tmp(lenz);
+    for (int i = 0; i < last_n; ++i) {
+      const size_t slot = (size_t)(h->iter - last_n + i) % (size_t)h->wcap;
+      HIPCHK(hipMemcpy(tmp.data(), h->zring + slot * lenz, lenz * sizeof(int32_t), hipMemcpyDeviceToHost));
+      for (size_t j = 0; j < lenz; ++j) out[(size_t)i * lenz + j] = tmp[j];
+    }
+    return 0;
+  }
   const Arr& a = h->arr[id];
   const size_t len = id_len(h, id);
   if (!a.ring || len == 0) return fail(BNMF_EUNSET, "bnmf_window: id %d is not recorded for this model", id);

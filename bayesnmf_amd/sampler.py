@@ -99,7 +99,7 @@ class bayesNMF_sampler:
         self.dims = dict(K=data.shape[0], N=int(rank.max()), G=data.shape[1])
         self.specs = dict(rank=rank, likelihood=likelihood, prior=prior, MH=bool(MH), learning_rank=learning_rank,
                           convergence_control=cc, output_dir=final_dir, overwrite=overwrite, verbosity=verbosity,
-                          periodic_save=periodic_save, save_all_samples=save_all_samples,
+                          periodic_save=periodic_save, save_all_samples=save_all_samples, save_Z=bool(save_Z),
                           intermediate_credible_intervals=intermediate_credible_intervals,
                           engine_side_convergence=engine_side_convergence)
         if learning_rank:
@@ -204,9 +204,11 @@ class bayesNMF_sampler:
 
     def _sync_state(self):
         """Materialise the device state into the R6-style fields (params, prior_params)."""
-        names = ["P", "E", "A", "R"]
+        names = ["P", "E", "A", "R"] + (["sigmasq"] if self.specs["likelihood"] == "normal" else [])
         self.params = {n: self._chain.get(n) for n in names}
         self.prior_params = {n: self._chain.get(n) for n in _PRIOR_PARAM_NAMES[self.specs["prior"]]}
+        if self.specs["MH"]:
+            self.acceptance_rates = {n: self._chain.get(n) for n in ("P_acceptance_rate", "E_acceptance_rate")}
 
     @property
     def samples(self):
@@ -214,7 +216,17 @@ class bayesNMF_sampler:
         cc = self.specs["convergence_control"]
         n = min(self.state["iter"], len(self.temperature_schedule) if self.specs["save_all_samples"] else cc["MAP_over"])
         names = ["P", "E", "A", "R"] + _PRIOR_PARAM_NAMES[self.specs["prior"]]
-        return {nm: self._chain.window(nm, n) for nm in names}
+        if self.specs["MH"]:
+            names += ["P_acceptance_rate", "E_acceptance_rate"]
+        if self.specs["likelihood"] == "normal":
+            names += ["sigmasq"]
+        out = {nm: self._chain.window(nm, n) for nm in names}
+        if self.specs.get("save_Z"):
+            try:
+                out["Z"] = self._chain.window("Z", n)
+            except Exception:  # noqa: BLE001  (Z history not kept: too large for the device ring)
+                pass
+        return out
 
     # ---------------------------------------------------------------- public utilities (R/utils.R)
     def get_Mhat(self, P=None, A=None, E=None):

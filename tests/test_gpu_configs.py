@@ -211,6 +211,24 @@ def test_record_sample_against_oracle(model):
     e.close()
 
 
+def test_Z_history_window():
+    """samples$Z (R/bayesNMF_sampler.R:245-252): with save_Z and a window the last Z arrays are kept per sample."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts
+    M, _, _ = synth_counts(96, 30, 3, 5)
+    o = _mk(O.Oracle, M, 4, "gamma", seed=3, save_Z=True, nthreads=4)
+    e = _mk(Engine, M, 4, "gamma", seed=3, save_Z=True, window=3)
+    o.init(); e.init()
+    hist = {1: o.get("Z").copy()}
+    for it in range(2, 7):
+        o.run(1); e.run(1); hist[it] = o.get("Z").copy()
+    win = e.window("Z", 3)
+    for j, it in enumerate((4, 5, 6)):
+        assert np.array_equal(win[j], hist[it]), it
+    e.close()
+
+
 @pytest.mark.parametrize("prior", ["truncnormal", "exponential", "gamma"])
 def test_vignette_initial_value_checks(prior, tmp_path):
     """The reference's own executable checks (vignettes/advanced.qmd:181-185, :245-249, :315-319):
