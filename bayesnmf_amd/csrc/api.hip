@@ -706,8 +706,10 @@ static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged) {
   hipLaunchKernelGGL(k_mh_nz, dim3(N), dim3(256), 0, h->stream, h->dev, h->dNzE);
   double* accP = h->arr[BNMF_ACC_P].d; double* accE = h->arr[BNMF_ACC_E].d;
   const size_t ldsP = (4 * (size_t)S + N + 2) * sizeof(double);
-  if (normal) hipLaunchKernelGGL(k_mh_prow<true>, dim3(K), dim3(MHP_T), ldsP, h->stream, h->dev, t, mhstep, S, (const int*)h->dNzE, accP, h->dMhat);
-  else hipLaunchKernelGGL(k_mh_prow<false>, dim3(K), dim3(MHP_T), ldsP, h->stream, h->dev, t, mhstep, S, (const int*)h->dNzE, accP, h->dMhat);
+  auto goP = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(K), dim3(MHP_T), ldsP, h->stream, h->dev, t, mhstep, S, (const int*)h->dNzE, accP, h->dMhat); };
+  const bool regP = S <= MHP_W;                              // one 320-column segment per wave: the row's cells stay in registers
+  if (normal) { if (regP) goP(k_mh_prow<true, true>); else goP(k_mh_prow<true, false>); }
+  else { if (regP) goP(k_mh_prow<false, true>); else goP(k_mh_prow<false, false>); }
   hipLaunchKernelGGL(k_mh_nzp, dim3(N), dim3(64), 0, h->stream, h->dev, h->dNzE + N);
   int grid = (G + 3) / 4; if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(k_mh_ecol<false>, dim3(grid), dim3(MHE_T), h->mhe_lds, h->stream, h->dev, t, mhstep, (const int*)(h->dNzE + N), accE, 0);

@@ -74,7 +74,10 @@ __global__ void k_mh_nzp(Dev d, int* nzP) {
 constexpr int MHP_T = 1024;
 constexpr int MHP_W = MHP_T / 64;
 constexpr int MH_CPL = MH_SEG / 64;                       // cells per lane and segment
-template <bool NORMAL>
+// REG (G <= 16 segments, i.e. one segment per wave): the lane's 5 cells of Mhat, the counts and the current factor's
+// exposures stay in registers for the whole sweep, the next factor's exposures are requested one factor ahead; otherwise
+// Mhat lives in `mhrow`.
+template <bool NORMAL, bool REG>
 __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int mhstep, int S, const int* nzE, double* accP, double* mhrow) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -86,36 +89,80 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int mhstep
   const int32_t* Mk = d.Mt + (size_t)G * k;             // M[k, g] at Mt[g + G k]
   for (int j = tid; j < N; j += MHP_T) pa[j] = d.P[k + (size_t)K * j] * d.A[j];
   __syncthreads();
+  double mh[REG ? MH_CPL : 1], enr[REG ? MH_CPL : 1], enx[REG ? MH_CPL : 1], sgr[(REG && NORMAL) ? MH_CPL : 1];
+  int mr[REG ? MH_CPL : 1];
+  const int g0r = wave * MH_SEG + lane;                 // REG: this lane's cells are g0r + 64 i
   // fresh Mhat of the row (factor order), by the lane that owns the cell
-  for (int s = wave; s < S; s += MHP_W) {
-    const int g0 = s * MH_SEG, gend = min(G, g0 + MH_SEG);
-    for (int g = g0 + lane; g < gend; g += 64) {
-      double c = 0.0;
-      for (int j = 0; j < N; ++j) c = c + pa[j] * d.Et[g + (size_t)G * j];
-      row[g] = c;
+  if (REG) {
+#pragma unroll
+    for (int i = 0; i < MH_CPL; ++i) {
+      const int g = g0r + 64 * i;
+      mh[i] = 0.0; mr[i] = 0; enx[i] = 0.0; enr[i] = 0.0; if (NORMAL) sgr[i] = 1.0;
+      if (wave < S && g < min(G, (wave + 1) * MH_SEG)) {
+        double c = 0.0;
+        for (int j = 0; j < N; ++j) c = c + pa[j] * d.Et[g + (size_t)G * j];
+        mh[i] = c; mr[i] = Mk[g]; enx[i] = d.Et[g];      // exposures of factor 0
+        if (NORMAL) sgr[i] = d.sigmasq[g];
+      }
+    }
+  } else {
+    for (int s = wave; s < S; s += MHP_W) {
+      const int g0 = s * MH_SEG, gend = min(G, g0 + MH_SEG);
+      for (int g = g0 + lane; g < gend; g += 64) {
+        double c = 0.0;
+        for (int j = 0; j < N; ++j) c = c + pa[j] * d.Et[g + (size_t)G * j];
+        row[g] = c;
+      }
     }
   }
   for (int n = 0; n < N; ++n) {
     const int e = k + K * n;
     const double a_n = d.A[n];
+    if (REG) {
+#pragma unroll
+      for (int i = 0; i < MH_CPL; ++i) enr[i] = enx[i];
+      if (n + 1 < N) {
+#pragma unroll
+        for (int i = 0; i < MH_CPL; ++i) { const int g = g0r + 64 * i; if (wave < S && g < min(G, (wave + 1) * MH_SEG)) enx[i] = d.Et[g + (size_t)G * (n + 1)]; }
+      }
+    }
     if (a_n == 0.0) { if (tid == 0) d.P[e] = prior_draw<0>(d, e, t); continue; }          // sample_Pn :12
     const bool allzero = nzE[n] == 0;
     const double pold = pa[n];                                                             // P[k,n] * A[n]
     const double* En = d.Et + (size_t)G * n;
     if (!allzero) {
-      for (int s = wave; s < S; s += MHP_W) {
-        const int g0 = s * MH_SEG, gend = min(G, g0 + MH_SEG);
+      if (REG) {
         double a0 = 0.0, a1 = 0.0;
-        for (int g = g0 + lane; g < gend; g += 64) {
-          const double en = En[g];
-          const double mh = row[g];
-          const double mno = mh - pold * en;                                               // Mhat_no_n
-          const double V = NORMAL ? d.sigmasq[g] : mh;                                     // sigmasq_kg :137-147
-          a0 = a0 + en * (((double)Mk[g] - mno) / V);                                      // :155-161
-          a1 = a1 + (a_n * (en * en)) * (1.0 / V);                                         // :163-169
+#pragma unroll
+        for (int i = 0; i < MH_CPL; ++i) {
+          const int g = g0r + 64 * i;
+          if (wave < S && g < min(G, (wave + 1) * MH_SEG)) {
+            const double en = enr[i], mhv = mh[i];
+            const double mno = mhv - pold * en;
+            const double V = NORMAL ? sgr[i] : mhv;
+            a0 = a0 + en * (((double)mr[i] - mno) / V);
+            a1 = a1 + (a_n * (en * en)) * (1.0 / V);
+          }
         }
-        a0 = wave_tree64(a0); a1 = wave_tree64(a1);
-        if (lane == 0) { part[s] = a0; part[S + s] = a1; }
+        if (wave < S) {
+          a0 = wave_tree64(a0); a1 = wave_tree64(a1);
+          if (lane == 0) { part[wave] = a0; part[S + wave] = a1; }
+        }
+      } else {
+        for (int s = wave; s < S; s += MHP_W) {
+          const int g0 = s * MH_SEG, gend = min(G, g0 + MH_SEG);
+          double a0 = 0.0, a1 = 0.0;
+          for (int g = g0 + lane; g < gend; g += 64) {
+            const double en = En[g];
+            const double mhv = row[g];
+            const double mno = mhv - pold * en;                                            // Mhat_no_n
+            const double V = NORMAL ? d.sigmasq[g] : mhv;                                  // sigmasq_kg :137-147
+            a0 = a0 + en * (((double)Mk[g] - mno) / V);                                    // :155-161
+            a1 = a1 + (a_n * (en * en)) * (1.0 / V);                                       // :163-169
+          }
+          a0 = wave_tree64(a0); a1 = wave_tree64(a1);
+          if (lane == 0) { part[s] = a0; part[S + s] = a1; }
+        }
       }
     }
     __syncthreads();
@@ -129,22 +176,44 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int mhstep
     const double pnew = pr * a_n;
     bool take = true;
     if (mhstep) {                                                                          // MH_Pn_poisson :206-247
-      for (int s = wave; s < S; s += MHP_W) {
-        const int g0 = s * MH_SEG, gend = min(G, g0 + MH_SEG);
+      if (REG) {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        for (int g = g0 + lane; g < gend; g += 64) {
-          const double en = En[g];
-          const double m0 = row[g], m1 = (m0 - pold * en) + pnew * en;
-          const int m = Mk[g];
-          const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
-          const double lgf = d.lgfact[mi];
-          a0 = a0 + dpois_log(m, m1, lgf);                                                 // loglik_poisson_new :216-218
-          a1 = a1 + dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);                        // loglik_normal_old  :219-224
-          a2 = a2 + dpois_log(m, m0, lgf);                                                 // loglik_poisson_old :213-215
-          a3 = a3 + dnorm_log((double)m, m1, m0 < 1.0 ? 1.0 : m0);                        // loglik_normal_new  :225-231
+#pragma unroll
+        for (int i = 0; i < MH_CPL; ++i) {
+          const int g = g0r + 64 * i;
+          if (wave < S && g < min(G, (wave + 1) * MH_SEG)) {
+            const double en = enr[i];
+            const double m0 = mh[i], m1 = (m0 - pold * en) + pnew * en;
+            const int m = mr[i];
+            const double lgf = d.lgfact[m];
+            a0 = a0 + dpois_log(m, m1, lgf);
+            a1 = a1 + dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);
+            a2 = a2 + dpois_log(m, m0, lgf);
+            a3 = a3 + dnorm_log((double)m, m1, m0 < 1.0 ? 1.0 : m0);
+          }
         }
-        a0 = wave_tree64(a0); a1 = wave_tree64(a1); a2 = wave_tree64(a2); a3 = wave_tree64(a3);
-        if (lane == 0) { part[s] = a0; part[S + s] = a1; part[2 * S + s] = a2; part[3 * S + s] = a3; }
+        if (wave < S) {
+          a0 = wave_tree64(a0); a1 = wave_tree64(a1); a2 = wave_tree64(a2); a3 = wave_tree64(a3);
+          if (lane == 0) { part[wave] = a0; part[S + wave] = a1; part[2 * S + wave] = a2; part[3 * S + wave] = a3; }
+        }
+      } else {
+        for (int s = wave; s < S; s += MHP_W) {
+          const int g0 = s * MH_SEG, gend = min(G, g0 + MH_SEG);
+          double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+          for (int g = g0 + lane; g < gend; g += 64) {
+            const double en = En[g];
+            const double m0 = row[g], m1 = (m0 - pold * en) + pnew * en;
+            const int m = Mk[g];
+            const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
+            const double lgf = d.lgfact[mi];
+            a0 = a0 + dpois_log(m, m1, lgf);                                               // loglik_poisson_new :216-218
+            a1 = a1 + dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);                      // loglik_normal_old  :219-224
+            a2 = a2 + dpois_log(m, m0, lgf);                                               // loglik_poisson_old :213-215
+            a3 = a3 + dnorm_log((double)m, m1, m0 < 1.0 ? 1.0 : m0);                      // loglik_normal_new  :225-231
+          }
+          a0 = wave_tree64(a0); a1 = wave_tree64(a1); a2 = wave_tree64(a2); a3 = wave_tree64(a3);
+          if (lane == 0) { part[s] = a0; part[S + s] = a1; part[2 * S + s] = a2; part[3 * S + s] = a3; }
+        }
       }
       __syncthreads();
       if (tid == 0) {
@@ -160,9 +229,14 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int mhstep
       take = bc[1] != 0.0;
     } else if (tid == 0 && accP) accP[e] = 1.0;                                            // :201-204
     if (take) {
-      for (int s = wave; s < S; s += MHP_W) {
-        const int g0 = s * MH_SEG, gend = min(G, g0 + MH_SEG);
-        for (int g = g0 + lane; g < gend; g += 64) { const double en = En[g]; row[g] = (row[g] - pold * en) + pnew * en; }
+      if (REG) {
+#pragma unroll
+        for (int i = 0; i < MH_CPL; ++i) mh[i] = (mh[i] - pold * enr[i]) + pnew * enr[i];   // cells beyond G hold zeros: unchanged
+      } else {
+        for (int s = wave; s < S; s += MHP_W) {
+          const int g0 = s * MH_SEG, gend = min(G, g0 + MH_SEG);
+          for (int g = g0 + lane; g < gend; g += 64) { const double en = En[g]; row[g] = (row[g] - pold * en) + pnew * en; }
+        }
       }
       if (tid == 0) { d.P[e] = pr; pa[n] = pnew; }
     }
