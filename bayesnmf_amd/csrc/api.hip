@@ -61,6 +61,8 @@ struct bnmf_handle {
   hipEvent_t ev[2 * BNMF_NKERNEL]{};
   bool have_ev = false;
   double* dMap = nullptr; size_t map_words = 0;   // scratch of bnmf_map (grown on demand)
+  unsigned* dFlags = nullptr;                     // [0] counter, [1] flag of the E-side hyper sweep; [2], [3] of P part + Esum; [4] time-out
+  bool flags_valid = false;                       // the side work of the next iteration publishes its flags
   std::vector<double> hist;                       // [wcap][4]: loglikelihood, logposterior, P / E mean acceptance of the last iterations
   std::vector<double> temp_host;                  // temperature schedule (host copy, for the convergence rule)
 };
@@ -201,6 +203,8 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   HIPCHK(hipMemset(h->dZsumK, 0, N * G * sizeof(int32_t)));
   HIPCHK(hipMemset(h->dZsumG, 0, K * N * sizeof(int32_t)));
   if (cfg->save_Z) HIPCHK(hipMalloc(&h->dZ, K * N * G * sizeof(int32_t)));
+  HIPCHK(hipMalloc(&h->dFlags, 64));
+  HIPCHK(hipMemset(h->dFlags, 0, 64));
   HIPCHK(hipMalloc(&h->dR, sizeof(int)));
   int Rinit = (int)N;
   HIPCHK(hipMemcpy(h->dR, &Rinit, sizeof(int), hipMemcpyHostToDevice));
@@ -365,6 +369,7 @@ int bnmf_destroy(bnmf_handle* h) {
   if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); if (h->side) hipStreamDestroy(h->side); if (h->side2) hipStreamDestroy(h->side2);
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
   if (h->dMap) hipFree(h->dMap);
+  if (h->dFlags) hipFree(h->dFlags);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -504,7 +509,7 @@ static RecDst rec_pdraw(const bnmf_handle* h, uint32_t t, bool on) {   // what k
 }
 static void launch_pdraw(bnmf_handle* h, uint32_t t, int from_prior, bool rec) {
   const size_t lds = 2 * (size_t)h->cfg.K * sizeof(double);
-  hipLaunchKernelGGL(k_pdraw, dim3(h->cfg.N), dim3(PD_T), lds, h->stream, h->dev, t, from_prior, 1, rec_pdraw(h, t, rec));
+  hipLaunchKernelGGL(k_pdraw, dim3(h->cfg.N), dim3(PD_T), lds, h->stream, h->dev, t, from_prior, 1, rec_pdraw(h, t, rec), SideWait{});
 }
 static void launch_edraw(bnmf_handle* h, uint32_t t, int from_prior, bool rec) {
   hipLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, from_prior, 1, rec_at(h, t, rec).E);
@@ -525,7 +530,8 @@ static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm) {
   hipEventRecord(h->ev_draw, h->stream);
   hipStreamWaitEvent(h->side, h->ev_draw, 0);
   tm.begin(KN_SIDE, h->side);
-  hipLaunchKernelGGL(k_side, dim3(h->cfg.N + nbP + nbE), dim3(RT), 0, h->side, h->dev, t, nbP, 0, rec_at(h, t, fused_rec(h)));
+  hipLaunchKernelGGL(k_side, dim3(h->cfg.N + nbP + nbE), dim3(RT), 0, h->side, h->dev, t, nbP, 0, rec_at(h, t, fused_rec(h)), SideDone{});
+  h->flags_valid = false;
   tm.end(KN_SIDE, h->side);
   hipEventRecord(h->ev_side, h->side);
   hipEventRecord(h->ev_sideP, h->side);
@@ -544,19 +550,21 @@ static void launch_side_P(bnmf_handle* h, uint32_t t) {       // ev_p = completi
   hipStreamWaitEvent(h->side2, h->ev_p, 0);
   // k_lpp below rewrites lpPn slot (t-1) % 3, last read by k_reduce of iteration t-4 (side stream): order behind it
   if (h->red_issued) hipStreamWaitEvent(h->side2, h->ev_red, 0);
-  hipLaunchKernelGGL(k_side, dim3(nbP), dim3(RT), 0, h->side2, h->dev, t, nbP, h->cfg.N, rec_at(h, t, fused_rec(h)));
+  hipLaunchKernelGGL(k_side, dim3(nbP), dim3(RT), 0, h->side2, h->dev, t, nbP, h->cfg.N, rec_at(h, t, fused_rec(h)), SideDone{});
   hipLaunchKernelGGL(k_lpp, dim3(h->cfg.N), dim3(64), 0, h->side2, h->dev, t - 1);   // log-prior of the P just drawn
 }
 static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm) {   // ev_draw = completion of k_edraw(t-1)
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
   const int nbE = (int)(((size_t)h->cfg.N * h->cfg.G + RT - 1) / RT);
   hipStreamWaitEvent(h->side2, h->ev_draw, 0);
-  hipLaunchKernelGGL(k_side, dim3(h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{});
+  // Esum closes the side2 work the next k_pdraw needs (the P part ran before it on the same stream): it publishes flag [3]
+  hipLaunchKernelGGL(k_side, dim3(h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)h->cfg.N, t});
   // log-prior of the E just drawn (iteration t-1, whose slot pointers h->dev still holds): off the critical path
   hipLaunchKernelGGL(k_lpe, dim3(h->nblkE), dim3(ES_T), 0, h->side2, h->dev, t - 1);
   hipEventRecord(h->ev_sideP, h->side2);
   hipStreamWaitEvent(h->side, h->ev_draw, 0);
-  hipLaunchKernelGGL(k_side, dim3(nbE), dim3(RT), 0, h->side, h->dev, t, nbP, h->cfg.N + nbP, rec_at(h, t, fused_rec(h)));
+  hipLaunchKernelGGL(k_side, dim3(nbE), dim3(RT), 0, h->side, h->dev, t, nbP, h->cfg.N + nbP, rec_at(h, t, fused_rec(h)), SideDone{h->dFlags, h->dFlags + 1, (unsigned)nbE, t});
+  h->flags_valid = true;
   // ONE event for the main stream: ev_side fires when the E part (side) AND the P part / Esum / k_lpe (side2) are done.
   // (A wait costs a barrier packet on the main stream, ~8 us even when the event has long fired.)
   hipStreamWaitEvent(h->side, h->ev_sideP, 0);
@@ -746,7 +754,10 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   use_slot(h, t);
   const bool rec = fused_rec(h);
   if (!h->side_valid) launch_side(h, t, tm);               // first sweep after init / set_array
-  hipStreamWaitEvent(h->stream, h->ev_side, 0);            // prior parameters + Esum of iteration t ready (the only wait)
+  // prior parameters + Esum of iteration t: in the steady state k_pdraw polls the flags their kernels publish (no barrier
+  // packet on the main stream); after init / set_array / in profile mode a stream wait
+  const bool poll = h->flags_valid && !tm.on;
+  if (!poll) hipStreamWaitEvent(h->stream, h->ev_side, 0);
   if (tm.on) {                                             // profile mode: one kernel at a time
     tm.begin(KN_PDRAW, h->stream); launch_pdraw(h, t, 0, rec); tm.end(KN_PDRAW, h->stream);
     tm.begin(KN_EDRAW, h->stream); launch_edraw(h, t, 0, rec); tm.end(KN_EDRAW, h->stream);
@@ -754,7 +765,8 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   } else {
     // completion events ride on the dispatches themselves (stop events): no marker packets on the main stream
     hipExtLaunchKernelGGL(k_pdraw, dim3(h->cfg.N), dim3(PD_T), (uint32_t)(2 * (size_t)h->cfg.K * sizeof(double)), h->stream,
-                          nullptr, h->ev_p, 0, h->dev, t, 0, 0, rec_pdraw(h, t, rec));
+                          nullptr, h->ev_p, 0, h->dev, t, 0, 0, rec_pdraw(h, t, rec),
+                          poll ? SideWait{h->dFlags + 1, h->dFlags + 3, t, (int*)(h->dFlags + 4)} : SideWait{});
     launch_side_P(h, t + 1);
     hipExtLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, 0, 0, rec_at(h, t, rec).E);
     launch_side_E(h, t + 1, tm);                           // overlaps the rank update / k_zalloc below
@@ -890,6 +902,11 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
       double* d = h->hist.data() + (size_t)((t0 + i - 1) % (uint32_t)h->wcap) * 4;
       d[0] = r[3]; d[1] = r[4]; d[2] = r[9]; d[3] = r[10];
     }
+  }
+  {
+    int ferr = 0;
+    HIPCHK(hipMemcpy(&ferr, h->dFlags + 4, sizeof(int), hipMemcpyDeviceToHost));
+    if (ferr) return fail(BNMF_EHIP, "bnmf_run: k_pdraw timed out waiting for the hyper-parameter sweep of its iteration");
   }
   if (h->dRankSync) {
     int err = 0;

@@ -49,6 +49,41 @@ template <int SIDE> BNMF_DEV double* slot(const Dev& d, double* base, uint32_t t
 
 BNMF_DEV double clamp_tiny(double v) { return (v < 1e-300) ? 1e-300 : v; }
 
+// ---- hand-off of the side kernels' results to k_pdraw WITHOUT a cross-stream event on the main stream ----
+// (a stream-wait is a barrier packet that costs ~16 us after k_zalloc even when its event has long fired).  The side
+// kernels store what the next draws read with write-through agent-scope stores; every workgroup then drains its stores
+// and bumps a counter, and the LAST one publishes the iteration number in a flag.  k_pdraw (next kernel on the main
+// stream) polls the flags from one lane per workgroup, bounded, then takes ONE agent-scope acquire.
+struct SideDone { unsigned* counter; unsigned* flag; unsigned nblk; unsigned epoch; };
+struct SideWait { const unsigned* f0; const unsigned* f1; unsigned epoch; int* err; };
+BNMF_DEV void st_wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+BNMF_DEV void side_done(const SideDone& sd, int tid) {
+  if (!sd.flag) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's write-through stores have left
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(sd.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == sd.nblk - 1) {
+      __hip_atomic_store(sd.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sd.flag, sd.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+BNMF_DEV void side_wait(const SideWait& sw, int tid) {
+  if (!sw.f0) return;
+  if (tid == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(sw.f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sw.epoch ||
+           __hip_atomic_load(sw.f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sw.epoch) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 24)) { __hip_atomic_store(sw.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+
 // ---- hyper sweep of one element: R/sample_priors.R:150-200 (element-wise conditionals) ----
 template <int SIDE>
 BNMF_DEV void hyper_elem(const Dev& d, int e, uint32_t t, double v, double* rec0 = nullptr, double* rec1 = nullptr) {
@@ -60,19 +95,19 @@ BNMF_DEV void hyper_elem(const Dev& d, int e, uint32_t t, double v, double* rec0
     Stream s(d.k0, d.k1, SIDE ? BNMF_V_BETA_E : BNMF_V_BETA_P, (uint32_t)e, t);
     const double al_old = slot<SIDE>(d, Al, t - 1)[e];
     const double b = rgamma(s, hy(hA, e) + al_old, hy(hB, e) + v);        // sample_Beta_*  :323-345
-    slot<SIDE>(d, Be, t)[e] = b;
+    st_wt(&slot<SIDE>(d, Be, t)[e], b);
     if (rec1) rec1[e] = b;
     const double tau = (hy(hD, e) - dlog(clamp_tiny(b))) - dlog(clamp_tiny(v));
     Stream s2(d.k0, d.k1, SIDE ? BNMF_V_ALPHA_E : BNMF_V_ALPHA_P, (uint32_t)e, t);
     const double al = ralpha(s2, hy(hC, e), tau, al_old);                   // sample_Alpha_* :356-397
-    slot<SIDE>(d, Al, t)[e] = al;
+    st_wt(&slot<SIDE>(d, Al, t)[e], al);
     if (rec0) rec0[e] = al;
   } else if (d.prior == BNMF_EXPONENTIAL) {
     const HRef &hA = SIDE ? d.hA_e : d.hA_p, &hB = SIDE ? d.hB_e : d.hB_p;
     double* La = SIDE ? d.Lam_e : d.Lam_p;
     Stream s(d.k0, d.k1, SIDE ? BNMF_V_LAMBDA_E : BNMF_V_LAMBDA_P, (uint32_t)e, t);
     const double la = rgamma(s, hy(hA, e) + 1.0, hy(hB, e) + v);            // sample_Lambda_* :284-308
-    slot<SIDE>(d, La, t)[e] = la;
+    st_wt(&slot<SIDE>(d, La, t)[e], la);
     if (rec0) rec0[e] = la;
   } else {
     const HRef &hM = SIDE ? d.hM_e : d.hM_p, &hS = SIDE ? d.hS_e : d.hS_p;
@@ -84,13 +119,13 @@ BNMF_DEV void hyper_elem(const Dev& d, int e, uint32_t t, double v, double* rec0
     const double den = 1.0 / hy(hS, e) + 1.0 / sg;
     Stream s(d.k0, d.k1, SIDE ? BNMF_V_MU_E : BNMF_V_MU_P, (uint32_t)e, t);
     const double mu = num / den + (1.0 / den) * rnorm_std(s);               // sd = 1/denom (quirk) :214-236
-    slot<SIDE>(d, Mu, t)[e] = mu;
+    st_wt(&slot<SIDE>(d, Mu, t)[e], mu);
     if (rec0) rec0[e] = mu;
     const double dl = v - mu;
     const double rate = (SIDE ? hy(hA, e) : hy(hB, e)) + (dl * dl) / 2.0;   // A_e for B_e (quirk) :263-270
     Stream s2(d.k0, d.k1, SIDE ? BNMF_V_SIGSQ_E : BNMF_V_SIGSQ_P, (uint32_t)e, t);
     const double sgn = rinvgamma(s2, hy(hA, e) + 0.5, rate);
-    slot<SIDE>(d, Sg, t)[e] = sgn;
+    st_wt(&slot<SIDE>(d, Sg, t)[e], sgn);
     if (rec1) rec1[e] = sgn;
   }
 }
@@ -139,7 +174,7 @@ BNMF_DEV double canon1024_by256(const double* x, long L, long stride, double* bu
 //   blocks [0, N)            : Esum[n] = canonical sum_g E[n,g]   (rate of P's Gamma, R/sample_Pn.R:103-106)
 //   blocks [N, N+nbP)        : hyper sweep of the P-side prior parameters (R/sample_priors.R:150-200)
 //   blocks [N+nbP, ...)      : hyper sweep of the E-side prior parameters
-__global__ __launch_bounds__(RT, 4) void k_side(Dev d, uint32_t t, int nbP, int blk0, RecDst rec) {
+__global__ __launch_bounds__(RT, 4) void k_side(Dev d, uint32_t t, int nbP, int blk0, RecDst rec, SideDone sd) {
   __shared__ double buf[RT];
   const int tid = threadIdx.x, blk = blockIdx.x + blk0;   // one launch (blk0 = 0) or one launch per part
   // The small launches (P part, Esum: a few dozen workgroups) share the CUs with k_zalloc, whose older waves win the
@@ -148,7 +183,7 @@ __global__ __launch_bounds__(RT, 4) void k_side(Dev d, uint32_t t, int nbP, int 
   if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);
   if (blk < d.N) {
     const double r = canon1024_by256(d.E + blk, d.G, d.N, buf, tid);
-    if (tid == 0) d.Esum[blk] = r;
+    if (tid == 0) st_wt(&d.Esum[blk], r);
   } else if (blk < d.N + nbP) {
     const long e = (long)(blk - d.N) * RT + tid;
     if (e < (long)d.lenP) hyper_elem<0>(d, (int)e, t, d.P[e], rec.pp[0], rec.pp[1]);
@@ -156,20 +191,23 @@ __global__ __launch_bounds__(RT, 4) void k_side(Dev d, uint32_t t, int nbP, int 
     const long e = (long)(blk - d.N - nbP) * RT + tid;
     if (e < (long)d.lenE) hyper_elem<1>(d, (int)e, t, d.E[e], rec.pp[2], rec.pp[3]);
   }
+  side_done(sd, tid);
 }
 
 // ---- k_pdraw: one workgroup of 128 lanes per factor n ----
 // sample_Pn_poisson R/sample_Pn.R:98-120 (dispatch :11-42); Psum[n] and the log-prior of column n
 // are reduced canonically (W = 64) over k.
 constexpr int PD_T = 128;
-__global__ __launch_bounds__(PD_T) void k_pdraw(Dev d, uint32_t t, int from_prior, int with_lp, RecDst rec) {
+__global__ __launch_bounds__(PD_T) void k_pdraw(Dev d, uint32_t t, int from_prior, int with_lp, RecDst rec, SideWait sw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  side_wait(sw, threadIdx.x);
   double* Pn = (double*)dyn;          // [K]
   double* lp = Pn + d.K;              // [K]
   const int n = blockIdx.x, tid = threadIdx.x;
   const int K = d.K;
   const double a_n = d.A[n];
-  const double Esum = from_prior ? 0.0 : d.Esum[n];
+  // Esum may have been published while this kernel was already polling: an agent-scope load (never the scalar cache)
+  const double Esum = from_prior ? 0.0 : __hip_atomic_load(&d.Esum[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (int k = tid; k < K; k += PD_T) {
     const int e = k + K * n;
     double x;
