@@ -397,8 +397,6 @@ def test_user_supplied_initial_values():
     E0 = rng.gamma(2.0, 500.0, size=(N, 40))
     Ap = rng.gamma(5.0, 1.0, size=(96, N))
     Ap[:, 2] = np.nan                       # column 3 missing -> re-drawn from the hyper-prior
-    for fac in (lambda **kw: O.Oracle(M, N, nthreads=4, **kw), lambda **kw: Engine(M, N, window=2, **kw)):
-        pass
     o = O.Oracle(M, N, prior="gamma", seed=8, save_Z=True, nthreads=4)
     e = Engine(M, N, prior="gamma", seed=8, save_Z=True, window=2)
     for c in (o, e):
