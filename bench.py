@@ -211,12 +211,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # REHEARSAL ONLY (a one-GPU box): BNMF_BENCH_REHEARSE=1 puts every rank on GPU 0 and gathers over gloo, to exercise
+    # the multi-rank code path; its numbers are meaningless and the line says so.
+    rehearse = os.environ.get("BNMF_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
+    tdev = "cpu" if rehearse else "cuda"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
 
@@ -245,14 +254,14 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         barrier()
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
         if dist is not None:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         rep_dt.append(float(tmax.item()))
     gathered = None
     if dist is not None:
         from bayesnmf_amd.multichain import gather_rows
-        gathered = gather_rows(met[-1:], dist, device="cuda")   # RCCL: gather the chains' last metrics rows
+        gathered = gather_rows(met[-1:], dist, device=tdev)     # RCCL: gather the chains' last metrics rows
     tmed = float(np.median(rep_dt))
 
     out = None
@@ -264,6 +273,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * tmed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            **({"REHEARSAL": "all ranks on one GPU over gloo: not a measurement"} if rehearse else {}),
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"Poisson-Gamma fixed rank N={N_}, K={K_} x G={args.G} synthetic counts, "
                                    f"one chain per GPU, {'full (save_Z)' if args.save_z else 'stats'} mode, "
