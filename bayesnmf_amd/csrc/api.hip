@@ -309,7 +309,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
         zg.KC = chunked ? 64 : (int)((K + 63) & ~(size_t)63);
         zg.KP = chunked ? 65 : ((K % 32 == 0) ? (int)K + 1 : (int)(K | 1));
         const bool loc = chunked || cfg->save_Z;
-        slab = (size_t)zg.HW * ZH + 2 * N + (N <= (size_t)ZALIAS_NMAX ? N : N - 1) * (size_t)zg.KP + (zg.KC + 1) + zg.KC + N + (loc ? N * (size_t)zg.KP : 0);
+        slab = (size_t)zg.HW * ZH + 2 * N + (N - 1) * (size_t)zg.KP + (zg.KC + 1) + zg.KC + N + (loc ? N * (size_t)zg.KP : 0);
         zg.zacc_words = chunked ? 0 : (int)((N * (size_t)zg.KP + 3) & ~(size_t)3);
         zg.p_words = 0;
       }

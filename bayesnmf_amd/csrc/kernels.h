@@ -310,11 +310,6 @@ __global__ __launch_bounds__(ES_T) void k_lpe(Dev d, uint32_t t) {
 // LDS hand-off between lanes of ONE wave: DS operations of a wave are executed in issue order,
 // so only the compiler has to be stopped from moving LDS accesses across this point.  (A
 // workgroup-scope fence would also wait for every outstanding global store: ~microseconds.)
-BNMF_DEV uint32_t cvt_u32_sat_k(double x) {   // v_cvt_u32_f64: truncates, saturates (x >= 2^32 -> 0xFFFFFFFF)
-  uint32_t r;
-  asm("v_cvt_u32_f64 %0, %1" : "=v"(r) : "v"(x));
-  return r;
-}
 BNMF_DEV void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -327,8 +322,6 @@ BNMF_DEV uint32_t wave_sum_u32(uint32_t v) {
 struct __attribute__((aligned(16))) u4 { uint32_t x, y, z, w; };
 struct ZGeom { int KP, HW, TR, KC, slab_words, zacc_words, p_words; };
 constexpr int ZH = 68;             // pitch of the per-lane histogram rows (16-byte aligned rows)
-constexpr int ZALIAS_NMAX = 128;   // alias-table allocation up to this N (8-bit alias index, 24-bit mass)
-constexpr uint32_t ZALIAS_FULL = 1u << 24;
 // General kernel (any N, any K): the rows of a column are processed in chunks of zg.KC rows (a multiple of
 // 64; KC >= K, i.e. one chunk, whenever the whole column's thresholds fit the wave's LDS slab).  With more
 // than one chunk the workgroup-level zacc[n][k] does not fit LDS either (zg.zacc_words == 0): the chunk's counts
@@ -348,9 +341,8 @@ __global__ __launch_bounds__(ZT) void k_zalloc(Dev d, uint32_t t, ZGeom zg, int 
   uint32_t* slab = zacc + zg.zacc_words + (size_t)wave * zg.slab_words;
   uint32_t* hist = slab;                                 // [HW][ZH] per-lane packed 8-bit bucket counts (16-B aligned)
   double* ae = (double*)(hist + HW * ZH);                // [N]  A[n] * E[n,g]
-  const bool alias = N <= ZALIAS_NMAX;                   // stream spec: alias table for N <= 128, thresholds above
-  uint32_t* thr = (uint32_t*)(ae + N);                   // alias: [N][KP] table entries (mass << 8 | alias); else [N-1][KP] thresholds
-  uint32_t* qoff = thr + (size_t)(alias ? N : N - 1) * KP;   // [KC+1]  quad offset (22 bits) | nlast << 22
+  uint32_t* thr = (uint32_t*)(ae + N);                   // [N-1][KP] thresholds of the current chunk
+  uint32_t* qoff = thr + (size_t)(N - 1) * KP;           // [KC+1]  quad offset (22 bits) | nlast << 22
   int* mcnt = (int*)(qoff + KC + 1);                     // [KC]
   uint32_t* zkt = (uint32_t*)(mcnt + KC);                // [N] column totals
   uint32_t* zloc = zkt + N;                              // [N][KP]  (SAVE_Z or chunked)
@@ -391,40 +383,7 @@ __global__ __launch_bounds__(ZT) void k_zalloc(Dev d, uint32_t t, ZGeom zg, int 
               }
             }
           }
-          if (alias && c > 0.0 && m > 0 && nl >= 0) {
-            // ---- alias table of the cell (Vose, integer masses: see the stream spec in oracle/bnmf_oracle.c: alias_build)
-            const double scale = ((double)N * 16777216.0) / c;
-            uint32_t* tabc = thr + cl;                       // entry n at tabc[n * KP]
-            uint32_t sum = 0, mmax = 0; int amax = 0;
-            for (int n0 = 0; n0 < N; n0 += 8) {
-              double pv[8];
-#pragma unroll
-              for (int j = 0; j < 8; ++j) pv[j] = Pk[(size_t)K * min(n0 + j, N - 1)];
-#pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                if (n0 + j < N) {
-                  const uint32_t mv = cvt_u32_sat_k((pv[j] * ae[n0 + j]) * scale);
-                  tabc[(size_t)(n0 + j) * KP] = mv; sum += mv;
-                  if (mv > mmax) { mmax = mv; amax = n0 + j; }
-                }
-              }
-            }
-            tabc[(size_t)amax * KP] += (uint32_t)N * ZALIAS_FULL - sum;      // rounding deficit (modular arithmetic: exact)
-            uint8_t* stk = (uint8_t*)hist + lane;            // this lane's stack bytes at stk[i * 64]: small from 0 up, large from N-1 down
-            int ns = 0, nlg = 0;
-            for (int n = 0; n < N; ++n) { if (tabc[(size_t)n * KP] < ZALIAS_FULL) stk[(ns++) * 64] = (uint8_t)n; else stk[(N - 1 - nlg++) * 64] = (uint8_t)n; }
-            while (ns > 0 && nlg > 0) {
-              const int sidx = stk[(--ns) * 64], lidx = stk[(N - nlg) * 64];
-              const uint32_t ms = tabc[(size_t)sidx * KP];
-              tabc[(size_t)sidx * KP] = (ms << 8) | (uint32_t)lidx;
-              const uint32_t ml = tabc[(size_t)lidx * KP] - (ZALIAS_FULL - ms);
-              tabc[(size_t)lidx * KP] = ml;
-              if (ml < ZALIAS_FULL) { --nlg; stk[(ns++) * 64] = (uint8_t)lidx; }
-            }
-            while (nlg > 0) { const int lidx = stk[(N - nlg) * 64]; --nlg; tabc[(size_t)lidx * KP] = ((ZALIAS_FULL - 1) << 8) | (uint32_t)lidx; }
-            while (ns > 0) { const int sidx = stk[(--ns) * 64]; tabc[(size_t)sidx * KP] = ((ZALIAS_FULL - 1) << 8) | (uint32_t)sidx; }
-            q = (m + 3) >> 2;
-          } else if (c > 0.0 && m > 0 && nl >= 0) {
+          if (c > 0.0 && m > 0 && nl >= 0) {
             const double scale = 4294967296.0 / c;
             double cc = 0.0;
             for (int n0 = 0; n0 < nthr; n0 += 8) {
@@ -460,7 +419,6 @@ __global__ __launch_bounds__(ZT) void k_zalloc(Dev d, uint32_t t, ZGeom zg, int 
       }
       const int Q = carry;
       if (lane == 0) qoff[kc] = (uint32_t)Q;
-      if (alias) { wave_lds_fence(); for (int i = lane; i < HW * ZH; i += 64) hist[i] = 0; }   // the build used it as stack space
       wave_lds_fence();
       // ---------------- phase 2: lane takes quads [q0, q1) of the chunk, in sub-chunks of <= 63 quads so that
       // the packed 8-bit per-lane histogram cannot overflow (<= 252 counts per flush)
@@ -490,15 +448,7 @@ __global__ __launch_bounds__(ZT) void k_zalloc(Dev d, uint32_t t, ZGeom zg, int 
             const uint32_t* col = thr + cell;
             const uint32_t u0 = min(w.x, 0xFFFFFFFEu), u1 = min(w.y, 0xFFFFFFFEu), u2 = min(w.z, 0xFFFFFFFEu), u3 = min(w.w, 0xFFFFFFFEu);
             int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-            if (alias) {                                   // i = floor(w N / 2^32), f = bits 8..31 of the low word, ONE look-up
-              const uint64_t p0 = (uint64_t)w.x * (uint32_t)N, p1 = (uint64_t)w.y * (uint32_t)N, p2 = (uint64_t)w.z * (uint32_t)N, p3 = (uint64_t)w.w * (uint32_t)N;
-              const uint32_t i0 = (uint32_t)(p0 >> 32), i1 = (uint32_t)(p1 >> 32), i2 = (uint32_t)(p2 >> 32), i3 = (uint32_t)(p3 >> 32);
-              const uint32_t e0 = col[i0 * KP], e1 = col[i1 * KP], e2 = col[i2 * KP], e3 = col[i3 * KP];
-              b0 = (((uint32_t)p0 >> 8) < (e0 >> 8)) ? (int)i0 : (int)(e0 & 0xFFu);
-              b1 = (((uint32_t)p1 >> 8) < (e1 >> 8)) ? (int)i1 : (int)(e1 & 0xFFu);
-              b2 = (((uint32_t)p2 >> 8) < (e2 >> 8)) ? (int)i2 : (int)(e2 & 0xFFu);
-              b3 = (((uint32_t)p3 >> 8) < (e3 >> 8)) ? (int)i3 : (int)(e3 & 0xFFu);
-            } else if (nthr > 0) {
+            if (nthr > 0) {
               int len = nthr;
               while (len > 1) {                           // 4 interleaved branch-free searches
                 const int half = len >> 1, off = half - 1;

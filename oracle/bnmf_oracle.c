@@ -286,80 +286,36 @@ static void sample_E_poisson(orc_handle* o, uint32_t t, int from_prior) {
 
 /* ---- Z allocation + fused per-cell metric terms ----
  * sample_Zkg R/sample_params.R:253-265: probs[n] = P[k,n]*A[n]*E[n,g]; sum==0 -> zeros;
- * else Multinomial(M[k,g], probs/sum).  Stream spec: the M[k,g] counts of a cell are allocated one by one; count j
- * uses 32-bit word (j&3) of block (j>>2) of stream (V_Z, cell=k+K*g, iter).  The sum of M independent categorical
- * draws is exactly the multinomial R's rmultinom samples by conditional binomials.
- *
- * N <= 128: the categorical draw uses an ALIAS TABLE (Walker / Vose) built per cell in exact integer arithmetic:
- *   mass_n = floor(p_n * (N 2^24 / sum)) (saturating), the rounding deficit N 2^24 - sum(mass) goes to the first factor
- *   of maximal mass; factors are pushed in order n = 0..N-1 on a "small" (mass < 2^24) or a "large" stack; while both
- *   are non-empty: s = pop small, l = top large: entry[s] = (mass_s, alias l), mass_l -= 2^24 - mass_s, and l moves to
- *   the small stack when its mass drops below 2^24; what remains on the large stack has mass exactly 2^24 (entry:
- *   itself).  Integers only, so the table is identical on every machine, a factor of probability zero has mass 0 and
- *   can never be drawn, and the probabilities are resolved to 2^-24 / N.
- *   A count with word w: i = floor(w N / 2^32), f = bits 8..31 of (w N mod 2^32); bucket = f < mass-part of entry[i] ?
- *   i : alias of entry[i].  One table look-up per count instead of a search.
- * N > 128: cumulative thresholds thr[n] = floor(cum[n] * 2^32 / sum), bucket = #{thr <= word} (word clamped to 2^32-2,
- *   "never" thresholds at / after the last factor of positive probability).
+ * else Multinomial(M[k,g], probs/sum).  Stream spec: the M[k,g] counts of a cell are
+ * allocated one by one; count j uses 32-bit word (j&3) of block (j>>2) of stream
+ * (V_Z, cell=k+K*g, iter); it lands in the first n whose cumulative threshold
+ * thr[n] = floor(cum[n] * 2^32 / sum) exceeds the word; the word is clamped to 2^32-2 and
+ * thresholds at or beyond the last n with a positive probability (or that saturate) are
+ * 2^32-1 = "never", so no count can land on a factor of zero probability.  The sum of M independent categorical draws is
+ * exactly the multinomial R's rmultinom samples by conditional binomials.
  * The same pass yields Mhat[k,g] = sum (get_Mhat_, R/utils.R:29-49) and the per-cell
  * terms of RMSE / KL / Poisson log-lik (R/utils.R:62-112, :412-471). */
-#define ALIAS_FULL 16777216u
-static void alias_build(const double* p, long N, double c, uint32_t* entry) {
-  uint32_t mass[128];
-  uint8_t stack[128];                       /* small grows from 0 upwards, large from N-1 downwards */
-  const double scale = ((double)N * 16777216.0) / c;
-  int64_t sum = 0; long amax = 0;
-  for (long n = 0; n < N; ++n) {
-    double x = p[n] * scale;
-    uint32_t mval = x >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)x;       /* v_cvt_u32_f64: truncates, saturates */
-    mass[n] = mval; sum += mval;
-    if (mval > mass[amax]) amax = n;
-  }
-  mass[amax] = (uint32_t)((int64_t)mass[amax] + ((int64_t)N * ALIAS_FULL - sum));
-  long ns = 0, nl = 0;                      /* small stack: stack[0..ns), large stack: stack[N-nl..N) (top = stack[N-nl]) */
-  for (long n = 0; n < N; ++n) { if (mass[n] < ALIAS_FULL) stack[ns++] = (uint8_t)n; else stack[N - 1 - nl++] = (uint8_t)n; }
-  while (ns > 0 && nl > 0) {
-    long s = stack[--ns], l = stack[N - nl];
-    entry[s] = (mass[s] << 8) | (uint32_t)l;
-    mass[l] -= ALIAS_FULL - mass[s];
-    if (mass[l] < ALIAS_FULL) { --nl; stack[ns++] = (uint8_t)l; }           /* l leaves the large stack (its slot is free: ns <= N - nl) */
-  }
-  while (nl > 0) { long l = stack[N - nl]; --nl; entry[l] = ((ALIAS_FULL - 1) << 8) | (uint32_t)l; }   /* mass exactly 2^24: always itself */
-  while (ns > 0) { long s2 = stack[--ns]; entry[s2] = ((ALIAS_FULL - 1) << 8) | (uint32_t)s2; }        /* cannot happen (sum is exact) */
-}
 static void z_cell(const orc_handle* o, long k, long g, uint32_t t, int32_t* zrow, double* mhat) {
   const long K = o->cfg.K, N = o->cfg.N;
   const double *P = o->a[ID_P].p, *E = o->a[ID_E].p, *A = o->a[ID_A].p;
-  double cum[4096], pr[4096]; uint32_t thr[4096];
+  double cum[4096]; uint32_t thr[4096];
   double c = 0.0; long nlast = -1;
   for (long n = 0; n < N; ++n) {
     double p = (P[k + K * n] * A[n]) * E[n + N * g];
-    c = c + p; cum[n] = c; pr[n] = p;
+    c = c + p; cum[n] = c;
     if (p > 0.0) nlast = n;
     zrow[n] = 0;
   }
   *mhat = c;
   int32_t m = o->M[k + K * g];
   if (!(c > 0.0) || m <= 0 || nlast < 0) return;
-  orc_stream s = ST(o, V_Z, (uint32_t)(k + K * g), t);
-  uint32_t w[4];
-  if (N <= 128) {
-    uint32_t entry[128];
-    alias_build(pr, N, c, entry);
-    for (int32_t j = 0; j < m; ++j) {
-      if ((j & 3) == 0) orc_stream_next(&s, w);
-      uint64_t prod = (uint64_t)w[j & 3] * (uint64_t)N;
-      uint32_t i = (uint32_t)(prod >> 32), f = ((uint32_t)prod) >> 8;
-      uint32_t e = entry[i];
-      zrow[(f < (e >> 8)) ? i : (e & 0xFFu)]++;
-    }
-    return;
-  }
   double scale = 4294967296.0 / c;
   for (long n = 0; n < N; ++n) {
     double tt = cum[n] * scale;
     thr[n] = (n >= nlast || tt >= 4294967295.0) ? 0xFFFFFFFFu : (uint32_t)tt;   /* 2^32-1 = "never" */
   }
+  orc_stream s = ST(o, V_Z, (uint32_t)(k + K * g), t);
+  uint32_t w[4];
   for (int32_t j = 0; j < m; ++j) {
     if ((j & 3) == 0) orc_stream_next(&s, w);
     uint32_t u = w[j & 3];
