@@ -14,6 +14,7 @@
 #include <vector>
 #include "kernels.h"
 #include "zalloc_reg.h"
+#include "zalloc_tile.h"
 #include "rank.h"
 #include "mh.h"
 
@@ -58,6 +59,7 @@ struct bnmf_handle {
   int wcap = 0;                        // ring capacity = window + 1: the hyper sweep of iteration t+1 is issued (and, in the
                                        // Gibbs sweep, recorded) during iteration t, one slot ahead of the oldest kept sample
   int z_grid = 0, z_zw = 8, z_ablate = 0; bool z_reg = false; size_t z_lds = 0; ZGeom zg{};
+  bool z_tile = false; ZTGeom ztg{}; double* dMhatZ = nullptr;   // k_zalloc_tile (zalloc_tile.h): N > 25 / large K
   hipEvent_t ev[2 * BNMF_NKERNEL]{};
   bool have_ev = false;
   double* dMap = nullptr; size_t map_words = 0;   // scratch of bnmf_map (grown on demand)
@@ -347,6 +349,38 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
     const long want = ((long)G + best_w - 1) / best_w;
     h->z_grid = (int)(want < resident ? want : resident);
     if (const char* e = getenv("BNMF_ZGRID")) h->z_grid = atoi(e);          // diagnostics only
+    // N > 25 (or K too large for the register kernel): the tile kernel, when at least two waves per CU fit
+    if (!h->z_reg) {
+      bool want_tile = true;
+      if (const char* e = getenv("BNMF_ZTILE")) want_tile = atoi(e) != 0;   // diagnostics / tests: 0 = k_zalloc
+      ZTGeom& tg = h->ztg;
+      tg.HW = zg.HW;
+      tg.nch = (int)((K + ZTR - 1) / ZTR);
+      tg.p_words = (int)((2 * N * (size_t)ZTR + 3) & ~(size_t)3);
+      tg.zacc_words = (int)((N * (size_t)ZTP + 3) & ~(size_t)3);
+      tg.slab_words = (int)ztile_slab_words((int)N, tg.HW, cfg->save_Z != 0);
+      const size_t shw = (size_t)tg.p_words + tg.zacc_words;
+      int tw = 0, tper = 0, ttot = 0;
+      for (int per_cu = 1; per_cu <= 2; ++per_cu)
+        for (int w : {16, 8, 6, 4, 2}) {
+          const size_t lds = (shw + (size_t)w * tg.slab_words) * 4;
+          if (lds * per_cu <= 160 * 1024 && w * per_cu <= 16 && w * per_cu > ttot) { ttot = w * per_cu; tw = w; tper = per_cu; }
+        }
+      if (want_tile && ttot >= 2 && (N - 1) * (size_t)ZTP < (1u << 22)) {
+        h->z_tile = true;
+        h->z_zw = tw;
+        h->z_lds = ((shw + (size_t)tw * tg.slab_words) * 4 + 15) & ~(size_t)15;
+        // column slices: about four rounds of resident workgroups, every wave with at least two columns
+        const long res = (long)prop.multiProcessorCount * tper;
+        long ns = (4 * res) / tg.nch;
+        const long nsmax = ((long)G + 2 * tw - 1) / (2 * tw);
+        if (ns > nsmax) ns = nsmax;
+        if (ns < 1) ns = 1;
+        tg.nslice = (int)ns;
+        h->z_grid = tg.nch * tg.nslice;
+        HIPCHK(hipMalloc(&h->dMhatZ, K * G * sizeof(double)));
+      }
+    }
     if (const char* e = getenv("BNMF_ABLATE")) h->z_ablate = atoi(e);       // diagnostics only
   }
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -364,6 +398,7 @@ int bnmf_destroy(bnmf_handle* h) {
   hipFree(h->dM); hipFree(h->dZsumK); hipFree(h->dZsumG); if (h->dZ) hipFree(h->dZ);
   hipFree(h->dR); hipFree(h->dRedraw); hipFree(h->dEsum); hipFree(h->dPsum); hipFree(h->dlpPn);
   hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol); if (h->dRankMhat) hipFree(h->dRankMhat); if (h->dRankSync) hipFree(h->dRankSync);
+  if (h->dMhatZ) hipFree(h->dMhatZ);
   if (h->dMhat) hipFree(h->dMhat); if (h->dAccPn) hipFree(h->dAccPn); if (h->dAccEpart) hipFree(h->dAccEpart); if (h->dNzE) hipFree(h->dNzE);
   if (h->dEt) hipFree(h->dEt); if (h->dMt) hipFree(h->dMt); if (h->zring) hipFree(h->zring);
   if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); if (h->side) hipStreamDestroy(h->side); if (h->side2) hipStreamDestroy(h->side2);
@@ -596,7 +631,21 @@ static int launch_zreg_t(bnmf_handle* h, uint32_t t) {
   }
 }
 template <bool SZ, int ZT_>
+static int launch_ztile(bnmf_handle* h, uint32_t t) {
+  auto kern = k_zalloc_tile<SZ, ZT_>;
+  if (h->z_attr_kernel != (const void*)kern) {
+    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    h->z_attr_kernel = (const void*)kern;
+  }
+  const ZArgs za = zargs(h);
+  hipMemsetAsync(h->dZsumK, 0, (size_t)h->cfg.N * h->cfg.G * sizeof(int32_t), h->stream);   // accumulated across the row chunks
+  hipLaunchKernelGGL(kern, dim3(h->z_grid), dim3(ZT_), h->z_lds, h->stream, za, h->dMhatZ, t, h->ztg);
+  hipLaunchKernelGGL(k_colmetrics<256>, dim3((h->cfg.G + 3) / 4), dim3(256), 0, h->stream, za, (const double*)h->dMhatZ);
+  return 0;
+}
+template <bool SZ, int ZT_>
 static int launch_zalloc_t(bnmf_handle* h, uint32_t t) {
+  if (h->z_tile) return launch_ztile<SZ, ZT_>(h, t);
   if (!h->z_reg) return launch_z(h, t, k_zalloc<SZ, ZT_>, h->dev, ZT_);
   return h->z_ablate ? launch_zreg_t<SZ, ZT_, true>(h, t) : launch_zreg_t<SZ, ZT_, false>(h, t);   // DIAG build honours BNMF_ABLATE
 }

@@ -260,18 +260,24 @@ def test_ragged_and_edge_shapes():
         assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), (K, G, N)
 
 
+@pytest.mark.parametrize("kernel", ["tile", "wave"])
 @pytest.mark.parametrize("shape,force", [((200, 9, 30), True), ((33, 17, 26), True), ((130, 12, 40), True),
-                                         ((1536, 12, 100), False)])
-def test_row_chunked_allocation_kernel(shape, force, monkeypatch):
-    """Large K x N (BASELINE config 5: K = 1,536, N = 100): the column's thresholds do not fit one wave's LDS
-    slab, so k_zalloc walks the rows in chunks of 64 and keeps ZsumG in global memory.  Forced on small shapes
-    (BNMF_ZCHUNK=1) and taken automatically at the config-5 row/factor counts; bit-exact against the oracle."""
+                                         ((1536, 12, 100), False), ((96, 300, 50), False), ((70, 40, 128), False),
+                                         ((45, 23, 140), False)])
+def test_general_allocation_kernels(shape, force, kernel, monkeypatch):
+    """N > 25 (BASELINE configs 4 and 5: N = 50, K = 96; N = 100, K = 1,536).  "tile": k_zalloc_tile, the default
+    (workgroup per 32-row chunk, P chunk in LDS, ZsumK accumulated across the chunks, metrics from the Mhat it writes).
+    "wave": k_zalloc (BNMF_ZTILE=0), one wave per column; where the column's thresholds do not fit one wave's LDS slab
+    it walks the rows in chunks of 64 and keeps ZsumG in global memory (forced on small shapes with BNMF_ZCHUNK=1, taken
+    automatically at the config-5 row/factor counts).  Both bit-exact against the oracle."""
     import oracle as O
     from bayesnmf_amd import Engine
     from bayesnmf_amd.setup import apply_hyperprior_params
     K, G, N = shape
-    if force:
-        monkeypatch.setenv("BNMF_ZCHUNK", "1")
+    if kernel == "wave":
+        monkeypatch.setenv("BNMF_ZTILE", "0")
+        if force:
+            monkeypatch.setenv("BNMF_ZCHUNK", "1")
     rng = np.random.default_rng(K + N)
     M = rng.poisson(rng.gamma(0.5, 12.0, size=(K, G))).astype(np.int32)
     M[:, G // 2] = 0
