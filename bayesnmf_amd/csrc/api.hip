@@ -356,29 +356,33 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
       ZTGeom& tg = h->ztg;
       tg.HW = zg.HW;
       tg.nch = (int)((K + ZTR - 1) / ZTR);
-      tg.p_words = (int)((2 * N * (size_t)ZTR + 3) & ~(size_t)3);
-      tg.zacc_words = (int)((N * (size_t)ZTP + 3) & ~(size_t)3);
+      tg.p_words = 2 * ztile_np8((int)N) * ZTR;
+      tg.zacc_words = (int)((N * (size_t)ZTR + 3) & ~(size_t)3);
       tg.slab_words = (int)ztile_slab_words((int)N, tg.HW, cfg->save_Z != 0);
       const size_t shw = (size_t)tg.p_words + tg.zacc_words;
       int tw = 0, tper = 0, ttot = 0;
       for (int per_cu = 1; per_cu <= 2; ++per_cu)
-        for (int w : {16, 8, 6, 4, 2}) {
+        for (int w : {8, 6, 4, 2}) {
           const size_t lds = (shw + (size_t)w * tg.slab_words) * 4;
-          if (lds * per_cu <= 160 * 1024 && w * per_cu <= 16 && w * per_cu > ttot) { ttot = w * per_cu; tw = w; tper = per_cu; }
+          // at most 8 waves per CU: the kernel holds ~190 VGPRs (double-buffered LDS reads), i.e. two waves per SIMD
+          if (lds * per_cu <= 160 * 1024 && w * per_cu <= 8 && w * per_cu > ttot) { ttot = w * per_cu; tw = w; tper = per_cu; }
         }
-      if (want_tile && ttot >= 2 && (N - 1) * (size_t)ZTP < (1u << 22)) {
+      if (want_tile && ttot >= 2) {
         h->z_tile = true;
         h->z_zw = tw;
         h->z_lds = ((shw + (size_t)tw * tg.slab_words) * 4 + 15) & ~(size_t)15;
-        // column slices: about four rounds of resident workgroups, every wave with at least two columns
+        // column slices: one round of resident workgroups when the row chunks are few (the chunk's P rows are staged and
+        // its ZsumG counts flushed once per workgroup), about four rounds otherwise; every wave with at least two columns
         const long res = (long)prop.multiProcessorCount * tper;
-        long ns = (4 * res) / tg.nch;
+        long ns = tg.nch * 4 <= res ? res / tg.nch : (4 * res) / tg.nch;
         const long nsmax = ((long)G + 2 * tw - 1) / (2 * tw);
         if (ns > nsmax) ns = nsmax;
         if (ns < 1) ns = 1;
         tg.nslice = (int)ns;
         h->z_grid = tg.nch * tg.nslice;
         HIPCHK(hipMalloc(&h->dMhatZ, K * G * sizeof(double)));
+        tg.dbg = nullptr;
+        if (getenv("BNMF_ZTDBG")) { HIPCHK(hipMalloc(&tg.dbg, 8 * sizeof(unsigned long long))); HIPCHK(hipMemset(tg.dbg, 0, 8 * sizeof(unsigned long long))); }   // diagnostics only
       }
     }
     if (const char* e = getenv("BNMF_ABLATE")) h->z_ablate = atoi(e);       // diagnostics only
@@ -641,6 +645,14 @@ static int launch_ztile(bnmf_handle* h, uint32_t t) {
   hipMemsetAsync(h->dZsumK, 0, (size_t)h->cfg.N * h->cfg.G * sizeof(int32_t), h->stream);   // accumulated across the row chunks
   hipLaunchKernelGGL(kern, dim3(h->z_grid), dim3(ZT_), h->z_lds, h->stream, za, h->dMhatZ, t, h->ztg);
   hipLaunchKernelGGL(k_colmetrics<256>, dim3((h->cfg.G + 3) / 4), dim3(256), 0, h->stream, za, (const double*)h->dMhatZ);
+  if (h->ztg.dbg) {                                        // BNMF_ZTDBG: section cycles (100 MHz s_memtime ticks) per launch
+    unsigned long long v[8];
+    hipStreamSynchronize(h->stream);
+    hipMemcpy(v, h->ztg.dbg, sizeof v, hipMemcpyDeviceToHost);
+    hipMemset(h->ztg.dbg, 0, sizeof v);
+    if (v[0]) fprintf(stderr, "[ztile t=%u] waves %llu grid %d w %d lds %zu  per wave: phase1 %.1f  phase2 %.1f  flush %.1f  columns %.1f  kernel %.1f (s_memtime ticks)\n",
+                      t, v[0], h->z_grid, h->z_zw, h->z_lds, (double)v[1] / v[0], (double)v[2] / v[0], (double)v[3] / v[0], (double)v[4] / v[0], (double)v[5] / v[0]);
+  }
   return 0;
 }
 template <bool SZ, int ZT_>
