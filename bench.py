@@ -166,10 +166,10 @@ def secondary_configs(device, quick=False):
 
     run("2: Poisson-Gamma fixed rank N=20, K=96 x G=2,000", 96, 2000, 20, "gamma", 1000, 8, 2, "k_zalloc_reg")
     run("3: Poisson-TruncNormal+MH fixed rank N=20, K=96 x G=5,000", 96, 5000, 20, "truncnormal", 60, 8, 3, "k_mh", MH=True)
-    run("4: Poisson-Gamma SBFI learned rank 1:50, K=96 x G=10,000", 96, 10000, 50, "gamma", 60, 12, 4, "k_zalloc",
+    run("4: Poisson-Gamma SBFI learned rank 1:50, K=96 x G=10,000", 96, 10000, 50, "gamma", 60, 12, 4, "k_zalloc_tile (+ memset, k_colmetrics)",
         learning_rank=True, rank_method="SBFI", temperature=np.ones(8000))
     if not quick:
-        run("5: Poisson-Gamma fixed rank N=100, K=1,536 x G=50,000", 1536, 50000, 100, "gamma", 6, 30, 5, "k_zalloc (row-chunked)",
+        run("5: Poisson-Gamma fixed rank N=100, K=1,536 x G=50,000", 1536, 50000, 100, "gamma", 12, 30, 5, "k_zalloc_tile (+ memset, k_colmetrics)",
             window=2)
     return out
 
