@@ -371,10 +371,17 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
         h->z_tile = true;
         h->z_zw = tw;
         h->z_lds = ((shw + (size_t)tw * tg.slab_words) * 4 + 15) & ~(size_t)15;
-        // column slices: one round of resident workgroups when the row chunks are few (the chunk's P rows are staged and
-        // its ZsumG counts flushed once per workgroup), about four rounds otherwise; every wave with at least two columns
+        // column slices: the fewest rounds (1..4) of resident workgroups that fill >= 97 % of the CUs (the chunk's P rows
+        // are staged and its ZsumG counts flushed once per workgroup); every wave with at least two columns
         const long res = (long)prop.multiProcessorCount * tper;
-        long ns = tg.nch * 4 <= res ? res / tg.nch : (4 * res) / tg.nch;
+        long ns = 1; double best_util = 0.0;
+        for (long r = 1; r <= 4; ++r) {
+          const long c = (r * res) / tg.nch;
+          if (c < 1) continue;
+          const double util = (double)(c * tg.nch) / (double)(r * res);
+          if (util > best_util + 1e-9) { best_util = util; ns = c; }
+          if (util >= 0.97) break;
+        }
         const long nsmax = ((long)G + 2 * tw - 1) / (2 * tw);
         if (ns > nsmax) ns = nsmax;
         if (ns < 1) ns = 1;
