@@ -254,8 +254,8 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   }
   if (cfg->MH || cfg->likelihood == BNMF_NORMAL) {
     h->mh_S = (int)((G + MH_SEG - 1) / MH_SEG);
-    HIPCHK(hipMalloc(&h->dMhat, K * G * sizeof(double)));          // rows of Mhat maintained by the P sweep
-    h->mhe_lds = 4 * (2 * N + K) * sizeof(double);                 // k_mh_ecol: per wave E column, A, Mhat column
+    HIPCHK(hipMalloc(&h->dMhat, 3 * K * G * sizeof(double)));      // rows of Mhat maintained by the P sweep; log(Mhat) and its candidates (MH step)
+    h->mhe_lds = 4 * (2 * N + 3 * K) * sizeof(double);             // k_mh_ecol: per wave E column, A, Mhat column, log(Mhat) and candidates
     if (h->mhe_lds > 64 * 1024) {
       if (h->mhe_lds > 160 * 1024) return fail(BNMF_EINVAL, "bnmf_create: K = %zu too large for the column kernel of the MH / Normal models (LDS)", K);
       HIPCHK(hipFuncSetAttribute((const void*)k_mh_ecol<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -781,11 +781,12 @@ static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged) {
   hipMemsetAsync(h->dNzE, 0, 2 * N * sizeof(int), h->stream);           // nzE[N], nzP[N]
   hipLaunchKernelGGL(k_mh_nz, dim3(N), dim3(256), 0, h->stream, h->dev, h->dNzE);
   double* accP = h->arr[BNMF_ACC_P].d; double* accE = h->arr[BNMF_ACC_E].d;
-  const size_t ldsP = (4 * (size_t)S + N + 2) * sizeof(double);
-  auto goP = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(K), dim3(MHP_T), ldsP, h->stream, h->dev, t, mhstep, S, (const int*)h->dNzE, accP, h->dMhat); };
   const bool regP = S <= MHP_W;                              // one 320-column segment per wave: the row's cells stay in registers
-  if (normal) { if (regP) goP(k_mh_prow<true, true>); else goP(k_mh_prow<true, false>); }
-  else { if (regP) goP(k_mh_prow<false, true>); else goP(k_mh_prow<false, false>); }
+  const size_t ldsP = (4 * (size_t)S + N + 2 + ((regP && mhstep) ? (size_t)MH_CPL * MHP_T : 0)) * sizeof(double);
+  auto goP = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(K), dim3(MHP_T), ldsP, h->stream, h->dev, t, S, (const int*)h->dNzE, accP, h->dMhat, h->dMhat + (size_t)K * h->cfg.G); };
+  if (normal) { if (regP) goP(k_mh_prow<true, true, false>); else goP(k_mh_prow<true, false, false>); }
+  else if (mhstep) { if (regP) goP(k_mh_prow<false, true, true>); else goP(k_mh_prow<false, false, true>); }
+  else { if (regP) goP(k_mh_prow<false, true, false>); else goP(k_mh_prow<false, false, false>); }
   hipLaunchKernelGGL(k_mh_nzp, dim3(N), dim3(64), 0, h->stream, h->dev, h->dNzE + N);
   int grid = (G + 3) / 4; if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(k_mh_ecol<false>, dim3(grid), dim3(MHE_T), h->mhe_lds, h->stream, h->dev, t, mhstep, (const int*)(h->dNzE + N), accE, 0);

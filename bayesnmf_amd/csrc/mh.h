@@ -20,11 +20,32 @@ BNMF_DEV double dpois_log(int m, double lam, double lgf) {      // get_loglik_ p
   const double mh = lam < 1e-6 ? 1e-6 : lam;
   return ((double)m * dlog(mh) - mh) - lgf;
 }
-BNMF_DEV double dnorm_log(double x, double mean, double var) { // dnorm(x, mean, sqrt(var), log = TRUE)
+BNMF_DEV double dnorm_log_sd(double x, double mean, double var) { // dnorm(x, mean, sqrt(var), log = TRUE): metric rows
   const double sd = dsqrt(var);
   const double z = (x - mean) / sd;
   return (-0.91893853320467274178 - dlog(sd)) - 0.5 * (z * z);
 }
+// The four log-likelihood terms of one cell of the MH ratio (MH_Pn_poisson R/sample_Pn.R:213-231): Poisson at the
+// proposed / current Mhat (m1 / m0) and the Normal approximations dnorm(m; mean, var = max(Mhat, 1)) in variance form,
+// -(log(2 pi) + log var)/2 - (m - mean)^2 / (2 var).  For Mhat >= 1 the variance IS the clamped Poisson mean, so
+// log var is the Poisson term's logarithm; L0 = log(max(m0, 1e-6)) of the current state is carried from step to step
+// (after an accepted proposal it is this step's L1): one logarithm per cell and step instead of four.
+struct MhTerms { double pn, nold, po, nnew, L1; };
+BNMF_DEV MhTerms mh_cell_terms(int m, double m0, double m1, double L0, double lgf, double LOG1) {
+  const double mh0 = m0 < 1e-6 ? 1e-6 : m0, mh1 = m1 < 1e-6 ? 1e-6 : m1;
+  const double L1 = dlog(mh1);
+  const double v0 = m0 < 1.0 ? 1.0 : m0, v1 = m1 < 1.0 ? 1.0 : m1;
+  const double lv0 = m0 < 1.0 ? LOG1 : L0, lv1 = m1 < 1.0 ? LOG1 : L1;
+  const double d0 = (double)m - m0, d1 = (double)m - m1;
+  MhTerms r;
+  r.pn = ((double)m * L1 - mh1) - lgf;                                                     // loglik_poisson_new :216-218
+  r.nold = (-0.91893853320467274178 - 0.5 * lv1) - 0.5 * ((d0 * d0) / v1);                 // loglik_normal_old  :219-224
+  r.po = ((double)m * L0 - mh0) - lgf;                                                     // loglik_poisson_old :213-215
+  r.nnew = (-0.91893853320467274178 - 0.5 * lv0) - 0.5 * ((d1 * d1) / v0);                 // loglik_normal_new  :225-231
+  r.L1 = L1;
+  return r;
+}
+BNMF_DEV double mh_log_clamped(double mhat) { return dlog(mhat < 1e-6 ? 1e-6 : mhat); }
 // proposal from the Normal full conditional (or the prior): get_mu_sigmasq_*_normal :132-187
 template <int SIDE>
 BNMF_DEV double mh_prior_or_cond(const Dev& d, int e, uint32_t t, bool use_prior, double num1, double den) {
@@ -77,19 +98,25 @@ constexpr int MH_CPL = MH_SEG / 64;                       // cells per lane and 
 // REG (G <= 16 segments, i.e. one segment per wave): the lane's 5 cells of Mhat, the counts and the current factor's
 // exposures stay in registers for the whole sweep, the next factor's exposures are requested one factor ahead; otherwise
 // Mhat lives in `mhrow`.
-template <bool NORMAL, bool REG>
-__global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int mhstep, int S, const int* nzE, double* accP, double* mhrow) {
+template <bool NORMAL, bool REG, bool MHSTEP /* the Metropolis-Hastings step runs (after convergence) */>
+__global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, const int* nzE, double* accP, double* mhrow, double* mhlog) {
+  constexpr int mhstep = MHSTEP ? 1 : 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = d.K, G = d.G, N = d.N, k = blockIdx.x;
   double* part = (double*)smem;                         // [4][S] segment partial sums
   double* pa = part + 4 * (size_t)S;                    // [N] P[k,j] * A[j]
   double* bc = pa + N;                                  // [2] broadcast: proposal, accept flag
+  double* lgc = bc + 2 + tid;                           // REG && MHSTEP: [MH_CPL][MHP_T] this step's candidate logarithms
   double* row = mhrow + (size_t)k * G;
+  double* lrow = mhlog + (size_t)k * G;                 // !REG: log(max(Mhat, 1e-6)) of the row; candidates at lrow + K G
+  double* lcand = lrow + (size_t)K * G;
+  const double LOG1 = dlog(1.0);
   const int32_t* Mk = d.Mt + (size_t)G * k;             // M[k, g] at Mt[g + G k]
   for (int j = tid; j < N; j += MHP_T) pa[j] = d.P[k + (size_t)K * j] * d.A[j];
   __syncthreads();
   double mh[REG ? MH_CPL : 1], enr[REG ? MH_CPL : 1], enx[REG ? MH_CPL : 1], sgr[(REG && NORMAL) ? MH_CPL : 1];
+  double lg[(REG && MHSTEP) ? MH_CPL : 1];              // log(max(Mhat, 1e-6)) of the lane's cells
   int mr[REG ? MH_CPL : 1];
   const int g0r = wave * MH_SEG + lane;                 // REG: this lane's cells are g0r + 64 i
   // fresh Mhat of the row (factor order), by the lane that owns the cell
@@ -97,11 +124,12 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int mhstep
 #pragma unroll
     for (int i = 0; i < MH_CPL; ++i) {
       const int g = g0r + 64 * i;
-      mh[i] = 0.0; mr[i] = 0; enx[i] = 0.0; enr[i] = 0.0; if (NORMAL) sgr[i] = 1.0;
+      mh[i] = 0.0; mr[i] = 0; enx[i] = 0.0; enr[i] = 0.0; if (MHSTEP) lg[i] = 0.0; if (NORMAL) sgr[i] = 1.0;
       if (wave < S && g < min(G, (wave + 1) * MH_SEG)) {
         double c = 0.0;
         for (int j = 0; j < N; ++j) c = c + pa[j] * d.Et[g + (size_t)G * j];
         mh[i] = c; mr[i] = Mk[g]; enx[i] = d.Et[g];      // exposures of factor 0
+        if (MHSTEP) lg[i] = mh_log_clamped(c);
         if (NORMAL) sgr[i] = d.sigmasq[g];
       }
     }
@@ -112,6 +140,7 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int mhstep
         double c = 0.0;
         for (int j = 0; j < N; ++j) c = c + pa[j] * d.Et[g + (size_t)G * j];
         row[g] = c;
+        if (mhstep) lrow[g] = mh_log_clamped(c);
       }
     }
   }
@@ -185,11 +214,9 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int mhstep
             const double en = enr[i];
             const double m0 = mh[i], m1 = (m0 - pold * en) + pnew * en;
             const int m = mr[i];
-            const double lgf = d.lgfact[m];
-            a0 = a0 + dpois_log(m, m1, lgf);
-            a1 = a1 + dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);
-            a2 = a2 + dpois_log(m, m0, lgf);
-            a3 = a3 + dnorm_log((double)m, m1, m0 < 1.0 ? 1.0 : m0);
+            const MhTerms tm = mh_cell_terms(m, m0, m1, lg[MHSTEP ? i : 0], d.lgfact[m], LOG1);
+            lgc[i * MHP_T] = tm.L1;
+            a0 = a0 + tm.pn; a1 = a1 + tm.nold; a2 = a2 + tm.po; a3 = a3 + tm.nnew;
           }
         }
         if (wave < S) {
@@ -205,11 +232,9 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int mhstep
             const double m0 = row[g], m1 = (m0 - pold * en) + pnew * en;
             const int m = Mk[g];
             const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
-            const double lgf = d.lgfact[mi];
-            a0 = a0 + dpois_log(m, m1, lgf);                                               // loglik_poisson_new :216-218
-            a1 = a1 + dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);                      // loglik_normal_old  :219-224
-            a2 = a2 + dpois_log(m, m0, lgf);                                               // loglik_poisson_old :213-215
-            a3 = a3 + dnorm_log((double)m, m1, m0 < 1.0 ? 1.0 : m0);                      // loglik_normal_new  :225-231
+            const MhTerms tm = mh_cell_terms(m, m0, m1, lrow[g], d.lgfact[mi], LOG1);
+            lcand[g] = tm.L1;
+            a0 = a0 + tm.pn; a1 = a1 + tm.nold; a2 = a2 + tm.po; a3 = a3 + tm.nnew;
           }
           a0 = wave_tree64(a0); a1 = wave_tree64(a1); a2 = wave_tree64(a2); a3 = wave_tree64(a3);
           if (lane == 0) { part[s] = a0; part[S + s] = a1; part[2 * S + s] = a2; part[3 * S + s] = a3; }
@@ -231,11 +256,11 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int mhstep
     if (take) {
       if (REG) {
 #pragma unroll
-        for (int i = 0; i < MH_CPL; ++i) mh[i] = (mh[i] - pold * enr[i]) + pnew * enr[i];   // cells beyond G hold zeros: unchanged
+        for (int i = 0; i < MH_CPL; ++i) { mh[i] = (mh[i] - pold * enr[i]) + pnew * enr[i]; if (MHSTEP) lg[i] = lgc[i * MHP_T]; }   // cells beyond G hold zeros: unchanged
       } else {
         for (int s = wave; s < S; s += MHP_W) {
           const int g0 = s * MH_SEG, gend = min(G, g0 + MH_SEG);
-          for (int g = g0 + lane; g < gend; g += 64) { const double en = En[g]; row[g] = (row[g] - pold * en) + pnew * en; }
+          for (int g = g0 + lane; g < gend; g += 64) { const double en = En[g]; row[g] = (row[g] - pold * en) + pnew * en; if (mhstep) lrow[g] = lcand[g]; }
         }
       }
       if (tid == 0) { d.P[e] = pr; pa[n] = pnew; }
@@ -254,9 +279,12 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int mhstep
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = d.K, G = d.G, N = d.N;
   const int KR = (K + 63) >> 6;
-  double* ec = (double*)smem + (size_t)wave * (2 * N + K);   // [N] current column of E
+  double* ec = (double*)smem + (size_t)wave * (2 * N + 3 * K);   // [N] current column of E
   double* av = ec + N;                                        // [N] A
   double* mhc = av + N;                                       // [K] Mhat[., g]
+  double* l0c = mhc + K;                                      // [K] log(max(Mhat, 1e-6)), carried from step to step (MH)
+  double* l1c = l0c + K;                                      // [K] this step's candidates
+  const double LOG1 = dlog(1.0);
   const int gw = blockIdx.x * (MHE_T / 64) + wave, nw = gridDim.x * (MHE_T / 64);
   for (int g = gw; g < G; g += nw) {
     for (int j = lane; j < N; j += 64) { ec[j] = d.E[j + (size_t)N * g]; av[j] = d.A[j]; }
@@ -271,6 +299,7 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int mhstep
           double c = 0.0;
           for (int j = 0; j < N; ++j) c = c + (d.P[kk + (size_t)K * j] * av[j]) * ec[j];
           mhc[kk] = c;
+          if (mhstep) l0c[kk] = mh_log_clamped(c);
         }
       }
       for (int n = 0; n < N; ++n) {
@@ -310,11 +339,9 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int mhstep
               const double m0 = mhc[kk], m1 = (m0 - pna * eold) + pna * pr;
               const int m = d.M[kk + (size_t)K * g];
               const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
-              const double lgf = d.lgfact[mi];
-              A_ = A_ + dpois_log(m, m1, lgf);
-              B_ = B_ + dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);
-              C_ = C_ + dpois_log(m, m0, lgf);
-              D_ = D_ + dnorm_log((double)m, m1, m0 < 1.0 ? 1.0 : m0);
+              const MhTerms tm = mh_cell_terms(m, m0, m1, l0c[kk], d.lgfact[mi], LOG1);
+              l1c[kk] = tm.L1;
+              A_ = A_ + tm.pn; B_ = B_ + tm.nold; C_ = C_ + tm.po; D_ = D_ + tm.nnew;
             }
           }
           A_ = __shfl(wave_tree64(A_), 0, 64); B_ = __shfl(wave_tree64(B_), 0, 64);
@@ -328,7 +355,7 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int mhstep
         if (take) {
           for (int r = 0; r < KR; ++r) {
             const int kk = (r << 6) + lane;
-            if (kk < K) { const double pna = Pn[kk] * a_n; mhc[kk] = (mhc[kk] - pna * eold) + pna * pr; }
+            if (kk < K) { const double pna = Pn[kk] * a_n; mhc[kk] = (mhc[kk] - pna * eold) + pna * pr; if (mhstep) l0c[kk] = l1c[kk]; }
           }
           if (lane == 0) { ec[n] = pr; d.E[e] = pr; }
         }
@@ -367,7 +394,7 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int mhstep
         const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
         const double mt = m < 1 ? 1e-6 : (double)m;
         a_sse = a_sse + dd * dd;
-        if (normal) a_ll = a_ll + dnorm_log((double)m, c, sg_col);           // get_loglik_ normal branch R/utils.R:72-97
+        if (normal) a_ll = a_ll + dnorm_log_sd((double)m, c, sg_col);           // get_loglik_ normal branch R/utils.R:72-97
         else a_ll = a_ll + (((double)m * lmh - mh) - d.lgfact[mi]);
         a_kl = a_kl + mt * (d.logm[mi] - lmh);
       }

@@ -543,10 +543,11 @@ static inline double dpois_log(int32_t m, double lam) {   /* get_loglik_ poisson
   double mh = lam < 1e-6 ? 1e-6 : lam;
   return ((double)m * orc_log(mh) - mh) - orc_lgamma((double)m + 1.0);
 }
-static inline double dnorm_log(double x, double mean, double var) {   /* dnorm(x, mean, sqrt(var), log = TRUE) */
-  double sd = sqrt(var);
-  double z = (x - mean) / sd;
-  return (-0.91893853320467274178 - orc_log(sd)) - 0.5 * (z * z);
+/* dnorm(x, mean, sqrt(var), log = TRUE) in variance form, -(log(2 pi) + log(var)) / 2 - (x - mean)^2 / (2 var): with
+ * var = max(Mhat, 1) the logarithm is the one the Poisson term of the same cell already needs (stream spec) */
+static inline double dnorm_log(double x, double mean, double var) {
+  double dlt = x - mean;
+  return (-0.91893853320467274178 - 0.5 * orc_log(var)) - 0.5 * ((dlt * dlt) / var);
 }
 static void mh_prior_or_cond(orc_handle* o, int side, long e, uint32_t t, int use_prior, double num1, double den, double* out) {
   if (use_prior) { *out = prior_draw(o, side, e, t); return; }
@@ -731,7 +732,7 @@ static void metrics_cells_normal(orc_handle* o) {
     for (long k = 0; k < K; ++k) {
       double mh = mhat_cell(o, k, g, -1, NULL, 0), dummy;
       cell_terms(o, o->M[k + K * g], mh, &a[k], &dummy, &c[k]);
-      b[k] = dnorm_log((double)o->M[k + K * g], mh, sg);
+      b[k] = dnorm_log_fwd((double)o->M[k + K * g], mh, sg);
     }
     o->colsse[g] = orc_canon_sum(a, K, 1, 64);
     o->colll[g] = orc_canon_sum(b, K, 1, 64);
