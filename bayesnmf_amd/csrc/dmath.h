@@ -20,8 +20,8 @@ BNMF_DEV u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;   // v_mad_u64_u32
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);   // a ^ b ^ c in one v_bitop3_b32 (gfx950)
+    const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
     c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
