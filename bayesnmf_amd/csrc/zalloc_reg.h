@@ -48,6 +48,17 @@ BNMF_DEV uint32_t mul24(uint32_t a, int b) {
   return r;
 }
 
+// LDS atomics by byte offset: address = base + index * pitch as ONE v_mad_u32_u24 (index and pitch are far below 2^24; the
+// pointer form costs a multiply and a shift-add)
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+BNMF_DEV uint32_t lds_off(const void* p) { return (uint32_t)(uintptr_t)(lds_u32*)p; }
+BNMF_DEV uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+BNMF_DEV void lds_add(uint32_t off, uint32_t v) { __hip_atomic_fetch_add((lds_u32*)(uintptr_t)off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 // v_cvt_u32_f64 saturates (x >= 2^32 -> 0xFFFFFFFF, x < 0 / NaN -> 0): C's (uint32_t)x is undefined there
 BNMF_DEV uint32_t cvt_u32_sat(double x) {
   uint32_t r;
@@ -246,18 +257,18 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(ZArgs d, uint32_t t, ZGeom
         const u4 h0 = *(const u4*)rowp;                    // {cend, k | pad << 30, next cend, next k | pad}
         int cend = (int)h0.x;
         uint32_t kkpad = h0.y, lnkz = h0.z, lnkw = h0.w;   // link = (end offset, row id) of the next cell of the list
-        uint32_t* hl = hist + lane;
+        const uint32_t hlb = lds_off(hist + lane), ztb = lds_off(ztarget), KP4 = (uint32_t)KP * 4u;
         const uint32_t gK = (uint32_t)K * (uint32_t)g;
         // two LDS atomics per count: zacc[n][k] and the lane's packed histogram.  Branch-free: counts beyond the
         // cell's last one (ND < 4, only in a cell's last quad) add 0
 #define ZATOM(B0, B1, B2, B3, CELL, ND)                                                                            \
         if (!(DIAG && (ablate & 4))) {                                                                             \
-          uint32_t* zc_ = ztarget + (CELL);                                                                        \
+          const uint32_t zb_ = ztb + ((CELL) << 2);                                                                \
           const uint32_t a0_ = (ND) > 0 ? 1u : 0u, a1_ = (ND) > 1 ? 1u : 0u, a2_ = (ND) > 2 ? 1u : 0u, a3_ = (ND) > 3 ? 1u : 0u; \
-          atomicAdd(&zc_[mul24(B0, KP)], a0_); atomicAdd(&hl[mul24((B0) >> 2, ZH)], a0_ << (((B0) & 3) << 3));    \
-          atomicAdd(&zc_[mul24(B1, KP)], a1_); atomicAdd(&hl[mul24((B1) >> 2, ZH)], a1_ << (((B1) & 3) << 3));    \
-          atomicAdd(&zc_[mul24(B2, KP)], a2_); atomicAdd(&hl[mul24((B2) >> 2, ZH)], a2_ << (((B2) & 3) << 3));    \
-          atomicAdd(&zc_[mul24(B3, KP)], a3_); atomicAdd(&hl[mul24((B3) >> 2, ZH)], a3_ << (((B3) & 3) << 3));    \
+          lds_add(mad24(B0, KP4, zb_), a0_); lds_add(mad24((B0) >> 2, ZH * 4, hlb), a0_ << (((B0) & 3) << 3));      \
+          lds_add(mad24(B1, KP4, zb_), a1_); lds_add(mad24((B1) >> 2, ZH * 4, hlb), a1_ << (((B1) & 3) << 3));      \
+          lds_add(mad24(B2, KP4, zb_), a2_); lds_add(mad24((B2) >> 2, ZH * 4, hlb), a2_ << (((B2) & 3) << 3));      \
+          lds_add(mad24(B3, KP4, zb_), a3_); lds_add(mad24((B3) >> 2, ZH * 4, hlb), a3_ << (((B3) & 3) << 3));      \
         }
         u4 pa = *(const u4*)(rowp + 4);                    // pivots 0..3
         uint32_t pb = HB == 3 ? rowp[8] : 0u;              // pivot 4
