@@ -248,7 +248,10 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
     const long cap_reg = (long)fit(nrm0 ? (const void*)k_rank_sweep<true, true> : (const void*)k_rank_sweep<true, false>) * prop0.multiProcessorCount;
     const long cap_gen = (long)fit(nrm0 ? (const void*)k_rank_sweep<false, true> : (const void*)k_rank_sweep<false, false>) * prop0.multiProcessorCount;
     h->rank_reg = K <= 128 && wg_needed <= cap_reg;
+    // (a wider grid with the blocks dealt wave-major over all CUs was measured: no gain, the sweep is bound by the
+    // per-factor exchange, not by VALU contention)
     h->rank_grid = (int)std::min<long>(wg_needed, h->rank_reg ? cap_reg : cap_gen);
+    if (const char* e = getenv("BNMF_RANKGRID")) { const long v = atol(e); if (v >= wg_needed && v <= (h->rank_reg ? cap_reg : cap_gen)) h->rank_grid = (int)v; }   // diagnostics only
     if (!h->rank_reg) HIPCHK(hipMalloc(&h->dRankMhat, K * G * sizeof(double)));
     if (getenv("BNMF_RANKDBG")) { HIPCHK(hipMalloc(&h->dRankDbg, (size_t)h->rank_grid * 16 * 8 * 8)); HIPCHK(hipMemset(h->dRankDbg, 0, (size_t)h->rank_grid * 16 * 8 * 8)); }   // diagnostics only
   }
@@ -591,9 +594,9 @@ static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm) {
 // Esum follows it once k_edraw is done; both are over long before k_zalloc, so that the event the next k_pdraw
 // waits for is already satisfied when the main stream reaches it (a late cross-stream event costs ~12 us).
 // The E-side sweep (needed only by the next k_edraw) shares the CUs with k_zalloc and ends with it.
-static void launch_side_P(bnmf_handle* h, uint32_t t) {       // ev_p = completion of k_pdraw(t-1)
+static void launch_side_P(bnmf_handle* h, uint32_t t, hipEvent_t after = nullptr) {   // ev_p = completion of k_pdraw(t-1)
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
-  hipStreamWaitEvent(h->side2, h->ev_p, 0);
+  hipStreamWaitEvent(h->side2, after ? after : h->ev_p, 0);
   // k_lpp below rewrites lpPn slot (t-1) % 3, last read by k_reduce of iteration t-4 (side stream): order behind it
   if (h->red_issued) hipStreamWaitEvent(h->side2, h->ev_red, 0);
   hipLaunchKernelGGL(k_side, dim3(nbP), dim3(RT), 0, h->side2, h->dev, t, nbP, h->cfg.N, rec_at(h, t, fused_rec(h)), SideDone{});
@@ -680,13 +683,13 @@ static int launch_zalloc(bnmf_handle* h, uint32_t t) {
   }
 }
 // sample_R then sample_An for n = 1..N (R/sample_params.R:67-74): one persistent launch for the N sequential updates
-static void launch_rank(bnmf_handle* h, uint32_t t) {
+static void launch_rank(bnmf_handle* h, uint32_t t, hipEvent_t stop = nullptr) {
   const int N = h->cfg.N;
   hipLaunchKernelGGL(k_rank_R, dim3(1), dim3(64), (size_t)(N + 1) * sizeof(double), h->stream, h->dev, t, 0);
   const int NB = (h->cfg.G + RK_MAXC - 1) / RK_MAXC;
   const size_t lds = ((size_t)N + NB) * sizeof(double);
   auto go = [&](auto kern) {
-    hipLaunchKernelGGL(kern, dim3(h->rank_grid), dim3(RK_T), lds, h->stream, h->dev, t, (unsigned long long*)h->dRankCol, NB, (int*)(h->dRankSync + 4), h->dRankMhat, (unsigned long long*)h->dRankDbg);
+    hipExtLaunchKernelGGL(kern, dim3(h->rank_grid), dim3(RK_T), (uint32_t)lds, h->stream, nullptr, stop, 0, h->dev, t, (unsigned long long*)h->dRankCol, NB, (int*)(h->dRankSync + 4), h->dRankMhat, (unsigned long long*)h->dRankDbg);
   };
   const bool nrm = h->cfg.likelihood == BNMF_NORMAL;
   if (h->rank_reg) { if (nrm) go(k_rank_sweep<true, true>); else go(k_rank_sweep<true, false>); }
@@ -836,11 +839,21 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
     hipExtLaunchKernelGGL(k_pdraw, dim3(h->cfg.N), dim3(PD_T), (uint32_t)(2 * (size_t)h->cfg.K * sizeof(double)), h->stream,
                           nullptr, h->ev_p, 0, h->dev, t, 0, 0, rec_pdraw(h, t, rec),
                           poll ? SideWait{h->dFlags + 1, h->dFlags + 3, t, (int*)(h->dFlags + 4)} : SideWait{});
-    launch_side_P(h, t + 1);
-    hipExtLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, 0, 0, rec_at(h, t, rec).E);
-    launch_side_E(h, t + 1, tm);                           // overlaps the rank update / k_zalloc below
+    if (!h->cfg.learning_rank) {
+      launch_side_P(h, t + 1);
+      hipExtLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, 0, 0, rec_at(h, t, rec).E);
+      launch_side_E(h, t + 1, tm);                         // overlaps k_zalloc below
+    } else {
+      // rank learning: every workgroup of the rank sweep waits for all others at every factor, so a hyper-sweep
+      // workgroup sharing a CU with one of them delays the whole grid.  The hyper sweep of t+1 starts when the rank sweep
+      // is done (ev_draw rides on its dispatch) and overlaps k_zalloc only.
+      hipLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, 0, 0, rec_at(h, t, rec).E);
+      launch_rank(h, t, h->ev_draw);
+      launch_side_P(h, t + 1, h->ev_draw);
+      launch_side_E(h, t + 1, tm);
+    }
   }
-  if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
+  if (h->cfg.learning_rank && tm.on) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
   tm.begin(KN_ZALLOC, h->stream); if (int rc = launch_zalloc(h, t)) return rc; tm.end(KN_ZALLOC, h->stream);
   record_Z(h, t);
   launch_reduce(h, t, row, tm);

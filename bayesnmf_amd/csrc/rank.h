@@ -160,7 +160,9 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = d.K, G = d.G, N = d.N;
   const int KR = (K + 63) >> 6;
-  const int wg = blockIdx.x * RK_W + wave, Wt = gridDim.x * RK_W;
+  // block (REG) / first block (otherwise) of this wave: wave-major, so that a grid wider than NB / RK_W spreads the
+  // blocks over all CUs (about one busy wave per SIMD instead of two on 60 % of the CUs)
+  const int wg = wave * gridDim.x + blockIdx.x, Wt = gridDim.x * RK_W;
   constexpr bool normal = NORMAL;
   const unsigned tag0 = t * (unsigned)(N + 2);           // tags of this launch: tag0 + phase, unique over the chain
   // the workgroup's own copy of A: every workgroup takes every decision itself, so A is never read across
