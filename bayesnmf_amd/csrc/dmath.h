@@ -251,9 +251,30 @@ BNMF_DEV double dlog_pnorm(double z) {
 // ----------------------------------------------------------- canonical reductions
 // canon_sum(x, L, W): accumulator i adds x[i], x[i+W], ... in order from +0.0, then the
 // halving tree acc[i] += acc[i+h], h = W/2..1.  W = 64: one wavefront; larger W: a workgroup.
+// The same halving tree (lane i adds lane i + h for h = 32, 16, 8, 4, 2, 1: same operands, same bits as the __shfl_down
+// form) without the LDS crossbar: gfx950's v_permlane32_swap / v_permlane16_swap bring lanes i + 32 / i + 16 down, DPP
+// row shifts do the rest.  A tree is ~20 VALU instructions instead of 12 dependent ds_bpermute round trips.
 BNMF_DEV double wave_tree64(double v) {   // lane 0 gets the W=64 halving tree of v over the wave
-#pragma unroll
-  for (int h = 32; h >= 1; h >>= 1) v = v + __shfl_down(v, h, 64);
+  {
+    const unsigned lo = (unsigned)__double_as_longlong(v), hi = (unsigned)(__double_as_longlong(v) >> 32);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = v + __longlong_as_double(((long long)b[1] << 32) | (unsigned)a[1]);
+  }
+  {
+    const unsigned lo = (unsigned)__double_as_longlong(v), hi = (unsigned)(__double_as_longlong(v) >> 32);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = v + __longlong_as_double(((long long)b[1] << 32) | (unsigned)a[1]);
+  }
+#define BNMF_TREE_STEP(CTRL)                                                                                       \
+  {                                                                                                                \
+    int lo = (int)__double_as_longlong(v), hi = (int)(__double_as_longlong(v) >> 32);                              \
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true); \
+    v = v + __longlong_as_double(((long long)hi << 32) | (unsigned)lo);                                            \
+  }
+  BNMF_TREE_STEP(0x108) BNMF_TREE_STEP(0x104) BNMF_TREE_STEP(0x102) BNMF_TREE_STEP(0x101)   // row_shl:8, 4, 2, 1
+#undef BNMF_TREE_STEP
   return v;
 }
 // block tree over NT (<=1024, power of two) values through LDS `buf` (NT doubles); result in buf[0]

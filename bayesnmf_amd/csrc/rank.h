@@ -234,7 +234,16 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
     rc.l1mp = dlog(1.0 - pi1); rc.lpi = dlog(pi1); rc.lgG = dlog((double)G); rc.T = temp_at(d, t);
     for (int j = 0; j < N; ++j) sumA = sumA + Ash[j];
   }
-  // ---- factors in order
+  // ---- factors in order.  REG: column n of P and row n of E (this wave's 8 columns) are requested one factor ahead,
+  // so that their L2 latency is not at the head of every factor's critical path
+  double np0 = 0.0, np1 = 0.0, nen[REG ? RK_MAXC : 1];
+  auto prefetch = [&](int n) {
+    const double* Pq = d.P + (size_t)K * n;
+    np0 = lane < K ? Pq[lane] : 0.0; np1 = 64 + lane < K ? Pq[64 + lane] : 0.0;
+#pragma unroll
+    for (int c = 0; c < (REG ? RK_MAXC : 1); ++c) { const int g = wg * RK_MAXC + c; nen[c] = g < G ? d.E[n + (size_t)N * g] : 0.0; }
+  };
+  if (REG) prefetch(0);
   for (int n = 0; n < N; ++n) {
     const double a_old = Ash[n];
     gran = granbuf + (size_t)((n + 1) & 1) * 2 * NB;
@@ -242,9 +251,10 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
     const double* Pn = d.P + (size_t)K * n;
     double p0 = 0.0, p1 = 0.0, en_[REG ? RK_MAXC : 1];
     if (REG) {
-      p0 = lane < K ? Pn[lane] : 0.0; p1 = 64 + lane < K ? Pn[64 + lane] : 0.0;
+      p0 = np0; p1 = np1;
 #pragma unroll
-      for (int c = 0; c < RK_MAXC; ++c) { const int g = wg * RK_MAXC + c; en_[c] = g < G ? d.E[n + (size_t)N * g] : 0.0; }
+      for (int c = 0; c < RK_MAXC; ++c) en_[c] = nen[c];
+      if (n + 1 < N) prefetch(n + 1);
       double bs = 0.0;
       {
 #pragma unroll

@@ -144,8 +144,10 @@ def secondary_configs(device, quick=False):
         rec = {"config": name, "K": K, "G": G, "N": N, "window": kw.get("window", MAP_OVER)}
         phases = [("it_per_s", False)] + ([("it_per_s_after_convergence", True)] if kw.get("MH") else [])
         for key, conv in phases:
-            t1 = time.perf_counter(); c.run(iters, converged=conv, metrics=True); dt = time.perf_counter() - t1
-            rec[key] = iters / dt
+            vals = []
+            for _ in range(3):                                # median of three timed blocks (a block is 10-300 ms)
+                t1 = time.perf_counter(); c.run(iters, converged=conv, metrics=True); vals.append(iters / (time.perf_counter() - t1))
+            rec[key] = sorted(vals)[1]
         if not kw.get("MH"):
             zb = z_bytes(K, G, N, False)
             prof = c.profile(max(3, iters // 10))
