@@ -277,6 +277,11 @@ BNMF_DEV double wave_tree64(double v) {   // lane 0 gets the W=64 halving tree o
 #undef BNMF_TREE_STEP
   return v;
 }
+// lane 0's value to every lane through the scalar unit (v_readlane: no LDS crossbar); all lanes of the wave must be active
+BNMF_DEV double wave_bcast0(double v) {
+  const int lo = __builtin_amdgcn_readlane((int)__double_as_longlong(v), 0), hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(v) >> 32), 0);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
 // block tree over NT (<=1024, power of two) values through LDS `buf` (NT doubles); result in buf[0]
 template <int NT>
 BNMF_DEV double block_tree(double v, double* buf, int tid) {

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int mhstep
               s2 = s2 + (a_n * (pn * pn)) * (1.0 / V);
             }
           }
-          s1 = __shfl(wave_tree64(s1), 0, 64); s2 = __shfl(wave_tree64(s2), 0, 64);
+          s1 = wave_bcast0(wave_tree64(s1)); s2 = wave_bcast0(wave_tree64(s2));
         }
         const double pr = mh_prior_or_cond<1>(d, e, t, allzero, s1, s2);
         bool take = true;
@@ -344,8 +344,8 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int mhstep
               A_ = A_ + tm.pn; B_ = B_ + tm.nold; C_ = C_ + tm.po; D_ = D_ + tm.nnew;
             }
           }
-          A_ = __shfl(wave_tree64(A_), 0, 64); B_ = __shfl(wave_tree64(B_), 0, 64);
-          C_ = __shfl(wave_tree64(C_), 0, 64); D_ = __shfl(wave_tree64(D_), 0, 64);
+          A_ = wave_bcast0(wave_tree64(A_)); B_ = wave_bcast0(wave_tree64(B_));
+          C_ = wave_bcast0(wave_tree64(C_)); D_ = wave_bcast0(wave_tree64(D_));
           double ratio = dexp((A_ + B_) - (C_ + D_));
           if (ratio > 1.0) ratio = 1.0;
           if (lane == 0) accE[e] = ratio;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int mhstep
           ss = ss + rr * rr;
         }
       }
-      ss = __shfl(wave_tree64(ss), 0, 64);
+      ss = wave_bcast0(wave_tree64(ss));
       Stream s(d.k0, d.k1, BNMF_V_SIGMASQ, (uint32_t)g, t);
       sg_col = rinvgamma(s, hy(d.hAlphaS, g) + (double)K / 2.0, hy(d.hBetaS, g) + 0.5 * ss);
       if (lane == 0) d.sigmasq[g] = sg_col;
