@@ -53,7 +53,7 @@ struct bnmf_handle {
   uint32_t* dRankSync = nullptr; int rank_grid = 0; bool rank_reg = false; void* dRankDbg = nullptr;
   int32_t* dMt = nullptr; double* dEt = nullptr;
   int32_t* zring = nullptr;            // save_Z with a window: samples$Z, [wcap][K*N*G] int32 (only if it fits BNMF_ZRING_GB, default 32)
-  double *dMhat = nullptr, *dAccPn = nullptr, *dAccEpart = nullptr; int* dNzE = nullptr; int mh_S = 1; size_t mhe_lds = 0;
+  double *dMhat = nullptr, *dAccPn = nullptr, *dAccEpart = nullptr; int* dNzE = nullptr; int mh_S = 1; size_t mhe_lds = 0; int mhe_gw = 0;
   size_t metrics_rows = 0;
   int maxM = 0, nblkE = 0;
   int wcap = 0;                        // ring capacity = window + 1: the hyper sweep of iteration t+1 is issued (and, in the
@@ -258,6 +258,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   if (cfg->MH || cfg->likelihood == BNMF_NORMAL) {
     h->mh_S = (int)((G + MH_SEG - 1) / MH_SEG);
     HIPCHK(hipMalloc(&h->dMhat, 3 * K * G * sizeof(double)));      // rows of Mhat maintained by the P sweep; log(Mhat) and its candidates (MH step)
+    if (const char* e = getenv("BNMF_MHE_GW")) h->mhe_gw = atoi(e) == 32 ? 32 : atoi(e) == 16 ? 16 : 0;   // diagnostics / tests: lanes per column of k_mh_ecol16 (0 = by mode)
     h->mhe_lds = 4 * (2 * N + 3 * K) * sizeof(double);             // k_mh_ecol: per wave E column, A, Mhat column, log(Mhat) and candidates
     if (h->mhe_lds > 64 * 1024) {
       if (h->mhe_lds > 160 * 1024) return fail(BNMF_EINVAL, "bnmf_create: K = %zu too large for the column kernel of the MH / Normal models (LDS)", K);
@@ -792,6 +793,15 @@ static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged) {
   else { if (regP) goP(k_mh_prow<false, true, false>); else goP(k_mh_prow<false, false, false>); }
   hipLaunchKernelGGL(k_mh_nzp, dim3(N), dim3(64), 0, h->stream, h->dev, h->dNzE + N);
   int grid = (G + 3) / 4; if (grid > 2048) grid = 2048;
+  if (K <= MHE16_KMAX) {                                   // several columns per wave
+    // lanes per column: 16 for the Gibbs-only sweep, 32 with the MH step (measured at config 3: 117 / 126 us and 276 / 205 us)
+    const int gw = h->mhe_gw ? h->mhe_gw : (mhstep ? 32 : 16), cpw = 64 / gw;
+    int g16 = ((G + cpw - 1) / cpw + 3) / 4; if (g16 > 2048) g16 = 2048;
+    const size_t lds16 = 4 * (size_t)cpw * N * sizeof(double);
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)(h->dNzE + N), accE, 0); };
+    if (gw == 16) { if (mhstep) go(k_mh_ecol16<false, true, 16>); else go(k_mh_ecol16<false, false, 16>); }
+    else { if (mhstep) go(k_mh_ecol16<false, true, 32>); else go(k_mh_ecol16<false, false, 32>); }
+  } else
   hipLaunchKernelGGL(k_mh_ecol<false>, dim3(grid), dim3(MHE_T), h->mhe_lds, h->stream, h->dev, t, mhstep, (const int*)(h->dNzE + N), accE, 0);
 }
 static void launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells) {
@@ -799,8 +809,16 @@ static void launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells) {
   if (draw_sig) cells = true;                 // sigmasq is drawn after R, A (R/sample_params.R:86-88) in the metrics pass
   const int N = h->cfg.N, G = h->cfg.G;
   if (cells) {
-    int grid = (G + 3) / 4; if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(k_mh_ecol<true>, dim3(grid), dim3(MHE_T), h->mhe_lds, h->stream, h->dev, t, 0, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
+    if (h->cfg.K <= MHE16_KMAX) {
+      const int gw = h->mhe_gw ? h->mhe_gw : 16, cpw = 64 / gw;
+      int g16 = ((G + cpw - 1) / cpw + 3) / 4; if (g16 > 2048) g16 = 2048;
+      const size_t lds16 = 4 * (size_t)cpw * N * sizeof(double);
+      if (gw == 16) hipLaunchKernelGGL((k_mh_ecol16<true, false, 16>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
+      else hipLaunchKernelGGL((k_mh_ecol16<true, false, 32>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
+    } else {
+      int grid = (G + 3) / 4; if (grid > 2048) grid = 2048;
+      hipLaunchKernelGGL(k_mh_ecol<true>, dim3(grid), dim3(MHE_T), h->mhe_lds, h->stream, h->dev, t, 0, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
+    }
   }
   hipLaunchKernelGGL(k_lp_p, dim3(N), dim3(64), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_P].d, accPn_slot(h, t));
   hipLaunchKernelGGL(k_lp_e, dim3(h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_E].d, accEp_slot(h, t));

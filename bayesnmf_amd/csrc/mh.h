@@ -405,6 +405,188 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int mhstep
   }
 }
 
+// ---- E side, K <= 128: SEVERAL columns per wave, GW = 16 or 32 lanes per column ----
+// k_mh_ecol spends a whole wave on one column: with K = 96 the second row pass runs half empty and the per-factor
+// scalar work (conditional parameters, truncated-normal draw, MH decision) is done by 64 lanes for one column.
+// Here a group of GW lanes owns a column: lane j holds rows j, j+GW, ... in registers.  The canonical W = 64 sum over
+// rows is kept: accumulator i = row mod 64 belongs to lane i mod GW, slot i / GW; the tree steps that stay inside the
+// lane are plain adds, h = 16 of a 32-lane group is a v_permlane16_swap, h = 8..1 DPP row shifts.
+constexpr int MHE16_KMAX = 128;
+template <int GW>
+BNMF_DEV double grp_tree(const double (&acc)[64 / GW]) {  // lane 0 of every GW-lane group: the W = 64 halving tree
+  double v;
+  if (GW == 16) v = (acc[0] + acc[2 % (64 / GW)]) + (acc[1] + acc[3 % (64 / GW)]);   // h = 32: i + (i + 32); h = 16: i + (i + 16)
+  else {
+    v = acc[0] + acc[1];                                  // h = 32
+    const unsigned lo = (unsigned)__double_as_longlong(v), hi = (unsigned)(__double_as_longlong(v) >> 32);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = v + __longlong_as_double(((long long)b[1] << 32) | (unsigned)a[1]);            // h = 16: lane i + lane i + 16
+  }
+#define BNMF_ROW_STEP(CTRL)                                                                                        \
+  {                                                                                                                \
+    int lo = (int)__double_as_longlong(v), hi = (int)(__double_as_longlong(v) >> 32);                              \
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true); \
+    v = v + __longlong_as_double(((long long)hi << 32) | (unsigned)lo);                                            \
+  }
+  BNMF_ROW_STEP(0x108) BNMF_ROW_STEP(0x104) BNMF_ROW_STEP(0x102) BNMF_ROW_STEP(0x101)
+#undef BNMF_ROW_STEP
+  return v;
+}
+template <int GW>
+BNMF_DEV double grp_bcast0(double v, int lane) {          // lane 0 of the group to all its lanes
+  int lo = (int)__double_as_longlong(v), hi = (int)(__double_as_longlong(v) >> 32);
+  if (GW == 16) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x150, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150, 0xf, 0xf, false); }   // row_newbcast:0
+  else {
+    const int l0 = __builtin_amdgcn_readlane(lo, 0), h0 = __builtin_amdgcn_readlane(hi, 0), l1 = __builtin_amdgcn_readlane(lo, 32), h1 = __builtin_amdgcn_readlane(hi, 32);
+    lo = lane < 32 ? l0 : l1; hi = lane < 32 ? h0 : h1;
+  }
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <bool METRICS_ONLY, bool MHSTEP, int GW>
+__global__ __launch_bounds__(MHE_T) void k_mh_ecol16(Dev d, uint32_t t, const int* nzP, double* accE, int draw_sig) {
+  constexpr int MHE16_RPL = MHE16_KMAX / GW;              // rows per lane
+  constexpr int NS = 64 / GW;                             // accumulator slots per lane
+  constexpr int CPW = 64 / GW;                            // columns per wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane % GW, grp = lane / GW;
+  const int K = d.K, G = d.G, N = d.N;
+  double* ec = (double*)smem + (size_t)(wave * CPW + grp) * N;   // [N] current column of E, one per group
+  const double LOG1 = dlog(1.0);
+  const bool normal = d.likelihood == BNMF_NORMAL;
+  const int ngrp = (G + CPW - 1) / CPW;                       // sets of CPW columns
+  for (int gq = blockIdx.x * (MHE_T / 64) + wave; gq < ngrp; gq += gridDim.x * (MHE_T / 64)) {
+    const int g = gq * CPW + grp;
+    const bool live = g < G;                                  // a row beyond G works on column G - 1 and writes nothing
+    const int gc = live ? g : G - 1;
+    for (int i = j; i < N; i += GW) ec[i] = d.E[i + (size_t)N * gc];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double sg_col = normal ? d.sigmasq[gc] : 1.0;
+    double mh[MHE16_RPL], l0[MHSTEP ? MHE16_RPL : 1], l1[MHSTEP ? MHE16_RPL : 1];
+    int mr[MHE16_RPL];
+#pragma unroll
+    for (int r = 0; r < MHE16_RPL; ++r) { const int kk = j + GW * r; mr[r] = kk < K ? d.M[kk + (size_t)K * gc] : 0; mh[r] = 0.0; }
+    if (!METRICS_ONLY) {
+#pragma unroll
+      for (int r = 0; r < MHE16_RPL; ++r) {                   // fresh Mhat of the column
+        const int kk = j + GW * r;
+        if (kk < K) {
+          double c = 0.0;
+          for (int q = 0; q < N; ++q) c = c + (d.P[kk + (size_t)K * q] * d.A[q]) * ec[q];
+          mh[r] = c;
+          if (MHSTEP) l0[MHSTEP ? r : 0] = mh_log_clamped(c);
+        }
+      }
+      for (int n = 0; n < N; ++n) {
+        const int e = n + N * gc;
+        const double a_n = d.A[n];
+        if (a_n == 0.0) {                                                                  // sample_En :12
+          const double x = prior_draw<1>(d, e, t);
+          if (j == 0) { ec[n] = x; if (live) d.E[e] = x; }
+          continue;
+        }
+        const bool allzero = nzP[n] == 0;
+        const double eold = ec[n];
+        const double* Pn = d.P + (size_t)K * n;
+        double pn[MHE16_RPL];
+#pragma unroll
+        for (int r = 0; r < MHE16_RPL; ++r) { const int kk = j + GW * r; pn[r] = kk < K ? Pn[kk] : 0.0; }
+        double s1 = 0.0, s2 = 0.0;
+        if (!allzero) {
+          double a1[NS] = {}, a2[NS] = {};
+#pragma unroll
+          for (int r = 0; r < MHE16_RPL; ++r) {
+            if (j + GW * r < K) {
+              const double mno = mh[r] - (pn[r] * a_n) * eold;
+              const double V = normal ? sg_col : mh[r];
+              a1[r % NS] = a1[r % NS] + pn[r] * (((double)mr[r] - mno) / V);
+              a2[r % NS] = a2[r % NS] + (a_n * (pn[r] * pn[r])) * (1.0 / V);
+            }
+          }
+          s1 = grp_bcast0<GW>(grp_tree<GW>(a1), lane); s2 = grp_bcast0<GW>(grp_tree<GW>(a2), lane);
+        }
+        const double pr = mh_prior_or_cond<1>(d, e, t, allzero, s1, s2);
+        bool take = true;
+        if (MHSTEP) {
+          double tA[NS] = {}, tB[NS] = {}, tC[NS] = {}, tD[NS] = {};
+#pragma unroll
+          for (int r = 0; r < MHE16_RPL; ++r) {
+            if (j + GW * r < K) {
+              const double pna = pn[r] * a_n;
+              const double m0 = mh[r], m1 = (m0 - pna * eold) + pna * pr;
+              const int m = mr[r];
+              const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
+              const MhTerms tm = mh_cell_terms(m, m0, m1, l0[MHSTEP ? r : 0], d.lgfact[mi], LOG1);
+              l1[MHSTEP ? r : 0] = tm.L1;
+              tA[r % NS] = tA[r % NS] + tm.pn; tB[r % NS] = tB[r % NS] + tm.nold; tC[r % NS] = tC[r % NS] + tm.po; tD[r % NS] = tD[r % NS] + tm.nnew;
+            }
+          }
+          const double A_ = grp_bcast0<GW>(grp_tree<GW>(tA), lane), B_ = grp_bcast0<GW>(grp_tree<GW>(tB), lane);
+          const double C_ = grp_bcast0<GW>(grp_tree<GW>(tC), lane), D_ = grp_bcast0<GW>(grp_tree<GW>(tD), lane);
+          double ratio = dexp((A_ + B_) - (C_ + D_));
+          if (ratio > 1.0) ratio = 1.0;
+          if (j == 0 && live) accE[e] = ratio;
+          Stream su(d.k0, d.k1, BNMF_V_MHU_E, (uint32_t)e, t);
+          take = runif(su) < ratio;
+        } else if (j == 0 && live && accE) accE[e] = 1.0;
+        if (take) {
+#pragma unroll
+          for (int r = 0; r < MHE16_RPL; ++r) {
+            if (j + GW * r < K) { const double pna = pn[r] * a_n; mh[r] = (mh[r] - pna * eold) + pna * pr; if (MHSTEP) l0[MHSTEP ? r : 0] = l1[MHSTEP ? r : 0]; }
+          }
+          if (j == 0) { ec[n] = pr; if (live) d.E[e] = pr; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    // fresh Mhat of the (updated) column: residuals for sigmasq, then the metric terms (R/utils.R:412-471)
+    double cfresh[MHE16_RPL];
+#pragma unroll
+    for (int r = 0; r < MHE16_RPL; ++r) {
+      const int kk = j + GW * r;
+      cfresh[r] = 0.0;
+      if (kk < K) {
+        double c = 0.0;
+        for (int q = 0; q < N; ++q) c = c + (d.P[kk + (size_t)K * q] * d.A[q]) * ec[q];
+        cfresh[r] = c;
+      }
+    }
+    if (normal && draw_sig) {
+      // sample_sigmasq R/sample_params.R:275-286: sigmasq_g ~ InvGamma(Alpha_g + K/2, Beta_g + sum_k resid^2 / 2)
+      double sa[NS] = {};
+#pragma unroll
+      for (int r = 0; r < MHE16_RPL; ++r) if (j + GW * r < K) { const double rr = (double)mr[r] - cfresh[r]; sa[r % NS] = sa[r % NS] + rr * rr; }
+      const double ss = grp_bcast0<GW>(grp_tree<GW>(sa), lane);
+      Stream s(d.k0, d.k1, BNMF_V_SIGMASQ, (uint32_t)gc, t);
+      sg_col = rinvgamma(s, hy(d.hAlphaS, gc) + (double)K / 2.0, hy(d.hBetaS, gc) + 0.5 * ss);
+      if (j == 0 && live) d.sigmasq[g] = sg_col;
+    }
+    double qs[NS] = {}, ql[NS] = {}, qk[NS] = {};
+#pragma unroll
+    for (int r = 0; r < MHE16_RPL; ++r) {
+      if (j + GW * r < K) {
+        const double c = cfresh[r];
+        const int m = mr[r];
+        const double dd = c - (double)m;
+        const double mhv = c < 1e-6 ? 1e-6 : c;
+        const double lmh = dlog(mhv);
+        const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
+        const double mt = m < 1 ? 1e-6 : (double)m;
+        qs[r % NS] = qs[r % NS] + dd * dd;
+        if (normal) ql[r % NS] = ql[r % NS] + dnorm_log_sd((double)m, c, sg_col);           // get_loglik_ normal branch R/utils.R:72-97
+        else ql[r % NS] = ql[r % NS] + (((double)m * lmh - mhv) - d.lgfact[mi]);
+        qk[r % NS] = qk[r % NS] + mt * (d.logm[mi] - lmh);
+      }
+    }
+    const double a_sse = grp_tree<GW>(qs), a_ll = grp_tree<GW>(ql), a_kl = grp_tree<GW>(qk);
+    if (j == 0 && live) { d.colsse[g] = a_sse; d.colll[g] = a_ll; d.colkl[g] = a_kl; }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // log-prior and mean-acceptance partial sums for the models whose P/E are not drawn by k_pdraw/k_edraw
 __global__ void k_lp_p(Dev d, uint32_t t, const double* accP, double* accPn) {
   const int n = blockIdx.x, lane = threadIdx.x;      // 64 lanes

@@ -315,12 +315,16 @@ def test_bayesNMF_end_to_end_gpu(tmp_path):
     s.close()
 
 
+@pytest.mark.parametrize("gw", [None, "16", "32"])
 @pytest.mark.parametrize("prior,G", [("truncnormal", 70), ("exponential", 70), ("truncnormal", 600)])
-def test_mh_chain_bitexact(prior, G):
+def test_mh_chain_bitexact(prior, G, gw, monkeypatch):
     """Poisson + MH (config-3 model): proposals from the Normal full conditional, accept-all before
     convergence, true accept/reject after (R/sample_Pn.R:199-248, R/sample_En.R:196-241).  P, E, prior
     parameters, acceptance matrices and metrics bit-exact against the oracle; G = 600 spans two
-    512-column segments of the canonical row sums."""
+    320-column segments of the canonical row sums.  gw: lanes per column of the E-side kernel (k_mh_ecol16: 16 before
+    / 32 after convergence by default; both forced here in both phases)."""
+    if gw:
+        monkeypatch.setenv("BNMF_MHE_GW", gw)
     import oracle as O
     from bayesnmf_amd import Engine
     from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
