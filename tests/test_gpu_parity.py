@@ -315,6 +315,32 @@ def test_bayesNMF_end_to_end_gpu(tmp_path):
     s.close()
 
 
+@pytest.mark.parametrize("K,G,N", [(5, 7, 3), (17, 3, 2), (128, 9, 4), (40, 1, 1)])
+@pytest.mark.parametrize("model", ["mh", "normal"])
+def test_column_kernel_edge_shapes(K, G, N, model):
+    """k_mh_ecol16 (several columns per wave): fewer rows than lanes of a group, fewer columns than groups of a wave
+    (idle groups work on a copy of the last column and write nothing), K = 128 (all 8 cells per lane), a single
+    column / factor.  MH model before and after convergence and the Normal-likelihood model, bit-exact against the oracle."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import apply_hyperprior_params
+    rng = np.random.default_rng(K * 100 + G)
+    M = rng.poisson(rng.gamma(0.8, 9.0, size=(K, G))).astype(np.int32)
+    kw = dict(prior="truncnormal", MH=True, seed=11) if model == "mh" else dict(prior="exponential", likelihood="normal", seed=11)
+    o = O.Oracle(M, N, nthreads=2, **kw)
+    e = Engine(M, N, **kw)
+    apply_hyperprior_params(o, kw["prior"], M, N)
+    apply_hyperprior_params(e, kw["prior"], M, N)
+    r0, r1 = o.init(), e.init()
+    assert np.array_equal(r0[:9].view(np.uint64), r1[:9].view(np.uint64))
+    for conv in (False, True):
+        mo, me = o.run(5, converged=conv), e.run(5, converged=conv)
+        for nm in ["P", "E"] + (["sigmasq"] if model == "normal" else ["E_acceptance_rate"]):
+            assert np.array_equal(o.get(nm).view(np.uint64), e.get(nm).view(np.uint64)), (nm, conv)
+        assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), conv
+    e.close()
+
+
 @pytest.mark.parametrize("gw", [None, "16", "32"])
 @pytest.mark.parametrize("prior,G", [("truncnormal", 70), ("exponential", 70), ("truncnormal", 600)])
 def test_mh_chain_bitexact(prior, G, gw, monkeypatch):
