@@ -8,10 +8,11 @@
 //   * the chunk's rows of P are staged in LDS once per workgroup (fp64, [n][row]) and the chunk's ZsumG counts
 //     accumulate in one LDS table shared by the workgroup (flushed once with global integer atomics);
 //   * a wave takes one column at a time: a tile of 32 cells, threshold table (N-1) x 32 words;
-//     phase 1 builds it from LDS (pass A, Mhat: lane and lane + 32 mirror a row; pass B, thresholds: the two
+//     a wave works on PAIRS of columns: pass A of phase 1 (Mhat, lane = row: a sequential sum per cell) runs for both
+//     at once, one per half-wave; pass B (thresholds) and phase 2 then take the two columns in turn.  In pass B the two
 //     half-waves take the two halves of the factors, the upper one continuing from the partial sum pass A recorded, so
-//     the sequential sum of the spec is kept), phase 2 (lane = contiguous quad range) is k_zalloc's search;
-//   * the per-factor totals of a tile come from a packed 8-bit histogram with 16 replicas (1.7 KB instead of the
+//     the sequential sum of the spec is kept; phase 2 (lane = contiguous quad range) is k_zalloc's search;
+//   * the per-factor totals of a tile come from a packed 8-bit histogram with 8 replicas (0.9 KB instead of the
 //     6.8 KB of one row per lane): N = 100 fits 8 waves per CU;
 //   * ZsumK[:, g] is accumulated across the row chunks with coalesced global integer atomics (zeroed by the host before
 //     the launch), Mhat[k, g] is written out and the per-column metric terms are formed by k_colmetrics afterwards in
@@ -22,14 +23,14 @@
 namespace bnmf {
 
 constexpr int ZTR = 32;            // rows per tile = pitch of the [n][row] LDS arrays of a tile
-constexpr int ZTHR = 16;           // replicas of the packed bucket histogram (lane l uses replica l & 15)
-constexpr int ZTHP = 17;           // pitch of a histogram row
-constexpr int ZTSUB = 15;          // quads per lane between histogram flushes: 4 lanes x 15 x 4 counts <= 255 per 8-bit field
+constexpr int ZTHR = 8;            // replicas of the packed bucket histogram (lane l uses replica l & 7)
+constexpr int ZTHP = 9;            // pitch of a histogram row
+constexpr int ZTSUB = 7;           // quads per lane between histogram flushes: 8 lanes x 7 x 4 counts <= 255 per 8-bit field
 struct ZTGeom { int HW, nch, nslice, slab_words, zacc_words, p_words; unsigned long long* dbg; };   // dbg: BNMF_ZTDBG diagnostics (null otherwise)
 
 // host and device agree on the slab layout through these
 constexpr int ztile_np8(int N) { return (N + 7) & ~7; }              // factors padded to whole groups of 8 (zero rows of P, zero ae)
-constexpr int ztile_ae_words(int N) { return 2 * ztile_np8(N); }
+constexpr int ztile_ae_words(int N) { return 4 * ztile_np8(N); }      // two columns (a wave works on a pair)
 constexpr int ztile_hist_words(int HW) { return (HW * ZTHP + 1) & ~1; }
 inline size_t ztile_slab_words(int N, int HW, bool save_Z) {
   size_t w = (size_t)ztile_ae_words(N) + (size_t)ztile_hist_words(HW) + (size_t)(N - 1) * ZTR + (ZTR + 1) + ZTR + (save_Z ? (size_t)N * ZTR : 0);
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(ZT) void k_zalloc_tile(ZArgs d, double* __restrict_
   double* Pc = (double*)smem;                             // [NP8][ZTR] rows k0.. of P (zero beyond N), shared by the workgroup
   uint32_t* zacc = (uint32_t*)(Pc + (size_t)zg.p_words / 2);   // [N][ZTR] ZsumG counts of the chunk
   uint32_t* slab = zacc + zg.zacc_words + (size_t)wave * zg.slab_words;
-  double* ae = (double*)slab;                             // [NP8]  A[n] * E[n,g] (zero beyond N)
+  double* ae = (double*)slab;                             // [2][NP8]  A[n] * E[n,g] of the wave's two columns (zero beyond N)
   uint32_t* hist = slab + ztile_ae_words(N);              // [HW][ZTHP] packed 8-bit bucket counts, 16 replicas
   uint32_t* thr = hist + ztile_hist_words(HW);            // [N-1][ZTR] thresholds of the tile
   uint32_t* qoff = thr + (size_t)(N - 1) * ZTR;           // [ZTR+1]  quad offsets
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(ZT) void k_zalloc_tile(ZArgs d, double* __restrict_
   const int gs0 = (int)((long)G * slice / zg.nslice), gs1 = (int)((long)G * (slice + 1) / zg.nslice);
   for (int i = tid; i < zg.zacc_words; i += ZT) zacc[i] = 0;
   for (int i = tid; i < NP8 * ZTR; i += ZT) { const int cl = i & (ZTR - 1), n = i / ZTR; Pc[i] = (cl < kc && n < N) ? d.P[k0 + cl + (size_t)K * n] : 0.0; }
-  for (int n = N + lane; n < NP8; n += 64) ae[n] = 0.0;
+  for (int n = N + lane; n < NP8; n += 64) { ae[n] = 0.0; ae[NP8 + n] = 0.0; }
   for (int i = lane; i < HW * ZTHP; i += 64) hist[i] = 0;
   if (SAVE_Z) for (int i = lane; i < N * ZTR; i += 64) zloc[i] = 0;
   __syncthreads();
@@ -75,44 +76,51 @@ __global__ __launch_bounds__(ZT) void k_zalloc_tile(ZArgs d, double* __restrict_
   const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
 #define ZT_TIC(i) const unsigned long long tic_##i = zg.dbg ? __builtin_amdgcn_s_memtime() : 0ull
 #define ZT_TOC(i) if (zg.dbg) tp[i] += __builtin_amdgcn_s_memtime() - tic_##i
-  // counts and exposures of the NEXT column are requested while this one is processed
+  // A wave works on PAIRS of columns: pass A of phase 1 (lane = row, a sequential sum per cell) runs for both at once,
+  // lanes 0..31 on column g, lanes 32..63 on column g + 1; pass B and phase 2 then take the two columns in turn.
+  // Counts and exposures of the NEXT pair are requested while this one is processed.
+  const double* aeh = ae + (size_t)half * NP8;            // this half-wave's column in pass A
   int mpre = 0;
-  double epre0 = 0.0, epre1 = 0.0;                         // N <= 128 rides in registers; larger N reloads below
-  if (gs0 + wave < gs1) {
-    const int g = gs0 + wave;
-    if (cellok) mpre = d.M[k0 + cellL + (size_t)K * g];
-    if (lane < N) epre0 = d.E[lane + (size_t)N * g];
-    if (64 + lane < N) epre1 = d.E[64 + lane + (size_t)N * g];
-  }
-  for (int g = gs0 + wave; g < gs1; g += ZW) {
-    const int m = mpre;
-    if (lane < N) ae[lane] = d.A[lane] * epre0;
-    if (64 + lane < N) ae[64 + lane] = d.A[64 + lane] * epre1;
-    for (int n = 128 + lane; n < N; n += 64) ae[n] = d.A[n] * d.E[n + (size_t)N * g];
-    {
-      const int gn = g + ZW;
-      if (gn < gs1) {
-        if (cellok) mpre = d.M[k0 + cellL + (size_t)K * gn];
-        if (lane < N) epre0 = d.E[lane + (size_t)N * gn];
-        if (64 + lane < N) epre1 = d.E[64 + lane + (size_t)N * gn];
-      }
+  double epre[2][2] = {{0.0, 0.0}, {0.0, 0.0}};           // [column of the pair][n < 64, n >= 64]; larger N reloads below
+  auto request = [&](int g) {
+    const int gm = min(g + half, gs1 - 1);
+    if (cellok) mpre = d.M[k0 + cellL + (size_t)K * gm];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int gs = min(g + s, gs1 - 1);
+      if (lane < N) epre[s][0] = d.E[lane + (size_t)N * gs];
+      if (64 + lane < N) epre[s][1] = d.E[64 + lane + (size_t)N * gs];
     }
+  };
+  if (gs0 + 2 * wave < gs1) request(gs0 + 2 * wave);
+  for (int g = gs0 + 2 * wave; g < gs1; g += 2 * ZW) {
+    const bool liveB = g + 1 < gs1;                       // an odd tail: the upper half-wave repeats column g and stores nothing
+    const int gmine = (half && liveB) ? g + 1 : g;
+    const int m_own = mpre;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int gs = min(g + s, gs1 - 1);
+      if (lane < N) ae[s * NP8 + lane] = d.A[lane] * epre[s][0];
+      if (64 + lane < N) ae[s * NP8 + 64 + lane] = d.A[64 + lane] * epre[s][1];
+      for (int n = 128 + lane; n < N; n += 64) ae[s * NP8 + n] = d.A[n] * d.E[n + (size_t)N * gs];
+    }
+    if (g + 2 * ZW < gs1) request(g + 2 * ZW);
     wave_lds_fence();
     ZT_TIC(1);
-    // ---------------- phase 1, pass A: lane (and its mirror lane + 32) = row of the tile.  Mhat = sum_n P[k,n] ae[n] in
-    // factor order; the LDS reads of the next 8 factors are in flight while the current 8 are added
-    double c = 0.0, ch = 0.0;
-    int nl = -1;
+    // ---------------- phase 1, pass A: Mhat = sum_n P[k,n] ae[n] in factor order; the LDS reads of the next 8 factors are
+    // in flight while the current 8 are added
+    double c_own = 0.0, ch_own = 0.0;
+    int nl_own = -1;
     {
       double pa[8], aa[8], pb[8], ab[8];
       auto ld = [&](int n0, double* pv, double* av) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { pv[j] = Pl[(n0 + j) * ZTR]; av[j] = ae[n0 + j]; }
+        for (int j = 0; j < 8; ++j) { pv[j] = Pl[(n0 + j) * ZTR]; av[j] = aeh[n0 + j]; }
       };
       auto acc = [&](int n0, const double* pv, const double* av) {
-        if (n0 == H) ch = c;
+        if (n0 == H) ch_own = c_own;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const double p = pv[j] * av[j]; c = c + p; nl = p > 0.0 ? n0 + j : nl; }
+        for (int j = 0; j < 8; ++j) { const double p = pv[j] * av[j]; c_own = c_own + p; nl_own = p > 0.0 ? n0 + j : nl_own; }
       };
       ld(0, pa, aa);
       for (int n0 = 0; n0 < N; n0 += 16) {
@@ -122,8 +130,16 @@ __global__ __launch_bounds__(ZT) void k_zalloc_tile(ZArgs d, double* __restrict_
         if (n0 + 8 < N) acc(n0 + 8, pb, ab);
       }
     }
+    if (cellok && (half == 0 || liveB)) Mhat[k0 + cellL + (size_t)K * gmine] = c_own;
+    ZT_TOC(1);
+   for (int s = 0; s < (liveB ? 2 : 1); ++s) {             // the two columns of the pair in turn
+    const int gcol = g + s;
+    const double* aes = ae + (size_t)s * NP8;
+    ZT_TIC(4);
+    // the column's pass-A results, mirrored to both half-waves
+    const double c = __shfl(c_own, cellL + 32 * s, 64), ch = __shfl(ch_own, cellL + 32 * s, 64);
+    const int nl = __shfl(nl_own, cellL + 32 * s, 64), m = __shfl(m_own, cellL + 32 * s, 64);
     const bool act = cellok && c > 0.0 && m > 0 && nl >= 0;
-    if (half == 0 && cellok) Mhat[k0 + cellL + (size_t)K * g] = c;
     // ---------------- pass B: thresholds; lanes 0..31 take factors [0, H), lanes 32..63 continue from the sum at H
     if (act) {
       const double scale = 4294967296.0 / c;
@@ -133,7 +149,7 @@ __global__ __launch_bounds__(ZT) void k_zalloc_tile(ZArgs d, double* __restrict_
       double pa[8], aa[8], pb[8], ab[8];
       auto ld = [&](int i0, double* pv, double* av) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { pv[j] = Pl[(nb + i0 + j) * ZTR]; av[j] = ae[nb + i0 + j]; }
+        for (int j = 0; j < 8; ++j) { pv[j] = Pl[(nb + i0 + j) * ZTR]; av[j] = aes[nb + i0 + j]; }
       };
       auto put = [&](int i0, const double* pv, const double* av) {
 #pragma unroll
@@ -159,7 +175,7 @@ __global__ __launch_bounds__(ZT) void k_zalloc_tile(ZArgs d, double* __restrict_
     const int Q = __builtin_amdgcn_readlane(incl, 63);
     if (lane == 0) qoff[kc] = (uint32_t)Q;
     wave_lds_fence();
-    ZT_TOC(1);
+    ZT_TOC(4);
     // ---------------- phase 2: lane takes quads [q0, q1) of the tile, in sub-chunks of <= ZTSUB quads so that the packed
     // 8-bit histogram fields (shared by 4 lanes) cannot overflow
     const int per = (Q + 63) >> 6;
@@ -185,7 +201,7 @@ __global__ __launch_bounds__(ZT) void k_zalloc_tile(ZArgs d, double* __restrict_
           }
           const int j0 = (qi - cstart) << 2;
           const int nd = mc - j0;                          // >= 1; draws of this quad = min(4, nd)
-          const u32x4 w = philox4x32_10((uint32_t)(j0 >> 2), (uint32_t)(k0 + cell) + (uint32_t)K * (uint32_t)g, t, BNMF_V_Z, d.k0, d.k1);
+          const u32x4 w = philox4x32_10((uint32_t)(j0 >> 2), (uint32_t)(k0 + cell) + (uint32_t)K * (uint32_t)gcol, t, BNMF_V_Z, d.k0, d.k1);
           const uint32_t* col = thr + cell;
           const uint32_t u0 = min(w.x, 0xFFFFFFFEu), u1 = min(w.y, 0xFFFFFFFEu), u2 = min(w.z, 0xFFFFFFFEu), u3 = min(w.w, 0xFFFFFFFEu);
           int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
@@ -222,7 +238,7 @@ __global__ __launch_bounds__(ZT) void k_zalloc_tile(ZArgs d, double* __restrict_
         uint32_t tot = 0;
 #pragma unroll
         for (int r = 0; r < ZTHR; ++r) tot += (hr[r] >> sh) & 0xFFu;
-        if (tot) atomicAdd(&d.ZsumK[n + (size_t)N * g], (int32_t)tot);
+        if (tot) atomicAdd(&d.ZsumK[n + (size_t)N * gcol], (int32_t)tot);
       }
       wave_lds_fence();
       for (int i = lane; i < HW * ZTHP; i += 64) hist[i] = 0;
@@ -235,11 +251,12 @@ __global__ __launch_bounds__(ZT) void k_zalloc_tile(ZArgs d, double* __restrict_
         const int cl = i % kc, n = i / kc;
         const size_t a = (size_t)n * ZTR + cl;
         const uint32_t z = zloc[a];
-        d.Z[k0 + cl + (size_t)K * (n + (size_t)N * g)] = (int32_t)z;
+        d.Z[k0 + cl + (size_t)K * (n + (size_t)N * gcol)] = (int32_t)z;
         if (z) { atomicAdd(&zacc[a], z); zloc[a] = 0; }
       }
       wave_lds_fence();
     }
+   }
   }
   const unsigned long long tk1 = __builtin_amdgcn_s_memtime();
   __syncthreads();
@@ -249,7 +266,7 @@ __global__ __launch_bounds__(ZT) void k_zalloc_tile(ZArgs d, double* __restrict_
     if (v) atomicAdd(&d.ZsumG[k0 + cl + (size_t)K * n], (int32_t)v);
   }
   if (zg.dbg && lane == 0) {                               // [0] waves, [1..3] sections, [4] column loop, [5] whole kernel
-    atomicAdd(&zg.dbg[0], 1ull); atomicAdd(&zg.dbg[1], tp[1]); atomicAdd(&zg.dbg[2], tp[2]); atomicAdd(&zg.dbg[3], tp[3]);
+    atomicAdd(&zg.dbg[0], 1ull); atomicAdd(&zg.dbg[1], tp[1] + tp[4]); atomicAdd(&zg.dbg[2], tp[2]); atomicAdd(&zg.dbg[3], tp[3]);
     atomicAdd(&zg.dbg[4], tk1 - tk0); atomicAdd(&zg.dbg[5], __builtin_amdgcn_s_memtime() - tk0);
   }
 #undef ZT_TIC
