@@ -169,8 +169,9 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
             const double en = enr[i], mhv = mh[i];
             const double mno = mhv - pold * en;
             const double V = NORMAL ? sgr[i] : mhv;
-            a0 = a0 + en * (((double)mr[i] - mno) / V);
-            a1 = a1 + (a_n * (en * en)) * (1.0 / V);
+            const double rV = 1.0 / V;                     // one reciprocal serves both sums (stream spec)
+            a0 = a0 + en * (((double)mr[i] - mno) * rV);
+            a1 = a1 + (a_n * (en * en)) * rV;
           }
         }
         if (wave < S) {
@@ -186,8 +187,9 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
             const double mhv = row[g];
             const double mno = mhv - pold * en;                                            // Mhat_no_n
             const double V = NORMAL ? d.sigmasq[g] : mhv;                                  // sigmasq_kg :137-147
-            a0 = a0 + en * (((double)Mk[g] - mno) / V);                                    // :155-161
-            a1 = a1 + (a_n * (en * en)) * (1.0 / V);                                       // :163-169
+            const double rV = 1.0 / V;
+            a0 = a0 + en * (((double)Mk[g] - mno) * rV);                                   // :155-161
+            a1 = a1 + (a_n * (en * en)) * rV;                                              // :163-169
           }
           a0 = wave_tree64(a0); a1 = wave_tree64(a1);
           if (lane == 0) { part[s] = a0; part[S + s] = a1; }
@@ -322,8 +324,9 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol(Dev d, uint32_t t, int mhstep
               const double mh = mhc[kk];
               const double mno = mh - (pn * a_n) * eold;
               const double V = normal ? sg_col : mh;
-              s1 = s1 + pn * (((double)d.M[kk + (size_t)K * g] - mno) / V);
-              s2 = s2 + (a_n * (pn * pn)) * (1.0 / V);
+              const double rV = 1.0 / V;
+              s1 = s1 + pn * (((double)d.M[kk + (size_t)K * g] - mno) * rV);
+              s2 = s2 + (a_n * (pn * pn)) * rV;
             }
           }
           s1 = wave_bcast0(wave_tree64(s1)); s2 = wave_bcast0(wave_tree64(s2));
@@ -501,8 +504,9 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol16(Dev d, uint32_t t, const in
             if (j + GW * r < K) {
               const double mno = mh[r] - (pn[r] * a_n) * eold;
               const double V = normal ? sg_col : mh[r];
-              a1[r % NS] = a1[r % NS] + pn[r] * (((double)mr[r] - mno) / V);
-              a2[r % NS] = a2[r % NS] + (a_n * (pn[r] * pn[r])) * (1.0 / V);
+              const double rV = 1.0 / V;
+              a1[r % NS] = a1[r % NS] + pn[r] * (((double)mr[r] - mno) * rV);
+              a2[r % NS] = a2[r % NS] + (a_n * (pn[r] * pn[r])) * rV;
             }
           }
           s1 = grp_bcast0<GW>(grp_tree<GW>(a1), lane); s2 = grp_bcast0<GW>(grp_tree<GW>(a2), lane);

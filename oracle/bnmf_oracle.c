@@ -596,8 +596,9 @@ static void sample_P_seq(orc_handle* o, uint32_t t) {
           double en = AR(ID_E)[n + N * g];
           double mno = row[g] - pa * en;                                           /* Mhat_no_n */
           double V = normal ? AR(ID_SIGMASQ)[g] : row[g];                          /* sigmasq_kg :137-147 */
-          x1[g] = en * (((double)o->M[k + K * g] - mno) / V);                      /* :155-161 */
-          x2[g] = (a_n * (en * en)) * (1.0 / V);                                   /* :163-169 */
+          double rV = 1.0 / V;                                                     /* one reciprocal serves both sums (stream spec) */
+          x1[g] = en * (((double)o->M[k + K * g] - mno) * rV);                     /* :155-161 */
+          x2[g] = (a_n * (en * en)) * rV;                                          /* :163-169 */
         }
         num1 = canon_rowsum(x1, G); den = canon_rowsum(x2, G);
       }
@@ -659,8 +660,9 @@ static void sample_E_seq(orc_handle* o, uint32_t t) {
           double pn = AR(ID_P)[k + K * n];
           double mno = mhc[k] - (pn * a_n) * eold;
           double V = normal ? sg : mhc[k];
-          x1[k] = pn * (((double)o->M[k + K * g] - mno) / V);
-          x2[k] = (a_n * (pn * pn)) * (1.0 / V);
+          double rV = 1.0 / V;
+          x1[k] = pn * (((double)o->M[k + K * g] - mno) * rV);
+          x2[k] = (a_n * (pn * pn)) * rV;
         }
         num1 = orc_canon_sum(x1, K, 1, 64); den = orc_canon_sum(x2, K, 1, 64);
       }
