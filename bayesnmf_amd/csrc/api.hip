@@ -40,6 +40,7 @@ struct bnmf_handle {
   hipStream_t side2 = nullptr;         // second side stream: k_side P part (starts right after k_pdraw) and Esum
   hipEvent_t ev_draw = nullptr, ev_side = nullptr, ev_sideP = nullptr, ev_p = nullptr, ev_z = nullptr, ev_red = nullptr;
   bool side_valid = false;             // k_side of iteration iter+1 has been issued
+  bool mh_prep_valid = false;          // MH / Normal models: Et, nzE are current and nzP is zero (k_mh_tail of the previous iteration)
   const void* z_attr_kernel = nullptr;   // allocation kernel whose dynamic-LDS limit has been raised for this handle
   bool red_pending = false, red_issued = false; uint32_t red_t = 0; int red_row = 0;   // k_reduce of the previous iteration, issued late
   int iter = 0;
@@ -434,6 +435,7 @@ int bnmf_set_array(bnmf_handle* h, int id, const double* x, size_t n) {
   HIPCHK(hipStreamSynchronize(h->side));
   HIPCHK(hipStreamSynchronize(h->side2));
   h->side_valid = false;                 // state changed: the pre-issued k_side must be redone
+  h->mh_prep_valid = false;
   if (id == BNMF_R) { int r = (int)x[0]; HIPCHK(hipMemcpy(h->dR, &r, sizeof(int), hipMemcpyHostToDevice)); h->arr[BNMF_R].set = true; return 0; }
   if (id == BNMF_ZSUMK || id == BNMF_ZSUMG || id == BNMF_Z) {
     int32_t* dst = id == BNMF_ZSUMK ? h->dZsumK : id == BNMF_ZSUMG ? h->dZsumG : h->dZ;
@@ -782,16 +784,18 @@ static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged) {
   const int K = h->cfg.K, N = h->cfg.N, G = h->cfg.G, S = h->mh_S;
   const bool normal = h->cfg.likelihood == BNMF_NORMAL;
   const int mhstep = (h->cfg.MH && converged && !normal) ? 1 : 0;
-  hipMemsetAsync(h->dNzE, 0, 2 * N * sizeof(int), h->stream);           // nzE[N], nzP[N]
-  hipLaunchKernelGGL(k_mh_nz, dim3(N), dim3(256), 0, h->stream, h->dev, h->dNzE);
+  if (!h->mh_prep_valid) {                                   // first sweep after init / set_array; afterwards k_mh_tail prepares them
+    hipMemsetAsync(h->dNzE, 0, 2 * N * sizeof(int), h->stream);         // nzE[N], nzP[N]
+    hipLaunchKernelGGL(k_mh_nz, dim3(N), dim3(256), 0, h->stream, h->dev, h->dNzE);
+    h->mh_prep_valid = true;
+  }
   double* accP = h->arr[BNMF_ACC_P].d; double* accE = h->arr[BNMF_ACC_E].d;
   const bool regP = S <= MHP_W;                              // one 320-column segment per wave: the row's cells stay in registers
-  const size_t ldsP = (4 * (size_t)S + N + 2 + ((regP && mhstep) ? (size_t)MH_CPL * MHP_T : 0)) * sizeof(double);
-  auto goP = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(K), dim3(MHP_T), ldsP, h->stream, h->dev, t, S, (const int*)h->dNzE, accP, h->dMhat, h->dMhat + (size_t)K * h->cfg.G); };
+  const size_t ldsP = (4 * (size_t)S + 2 * N + 2 + ((regP && mhstep) ? (size_t)MH_CPL * MHP_T : 0)) * sizeof(double);
+  auto goP = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(K), dim3(MHP_T), ldsP, h->stream, h->dev, t, S, (const int*)h->dNzE, h->dNzE + N, accP, h->dMhat, h->dMhat + (size_t)K * h->cfg.G); };
   if (normal) { if (regP) goP(k_mh_prow<true, true, false>); else goP(k_mh_prow<true, false, false>); }
   else if (mhstep) { if (regP) goP(k_mh_prow<false, true, true>); else goP(k_mh_prow<false, false, true>); }
   else { if (regP) goP(k_mh_prow<false, true, false>); else goP(k_mh_prow<false, false, false>); }
-  hipLaunchKernelGGL(k_mh_nzp, dim3(N), dim3(64), 0, h->stream, h->dev, h->dNzE + N);
   int grid = (G + 3) / 4; if (grid > 2048) grid = 2048;
   if (K <= MHE16_KMAX) {                                   // several columns per wave
     // lanes per column: 16 for the Gibbs-only sweep, 32 with the MH step (measured at config 3: 117 / 126 us and 276 / 205 us)
@@ -820,8 +824,10 @@ static void launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells) {
       hipLaunchKernelGGL(k_mh_ecol<true>, dim3(grid), dim3(MHE_T), h->mhe_lds, h->stream, h->dev, t, 0, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
     }
   }
-  hipLaunchKernelGGL(k_lp_p, dim3(N), dim3(64), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_P].d, accPn_slot(h, t));
-  hipLaunchKernelGGL(k_lp_e, dim3(h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_E].d, accEp_slot(h, t));
+  // log-priors and acceptance sums, and (for the next iteration's P sweep) Et, nzE, nzP = 0: one launch
+  hipLaunchKernelGGL(k_mh_tail, dim3(2 * N + h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_P].d, accPn_slot(h, t),
+                     (const double*)h->arr[BNMF_ACC_E].d, accEp_slot(h, t), h->dNzE, h->dNzE + N, h->nblkE);
+  h->mh_prep_valid = true;
 }
 static int sweep_mh(bnmf_handle* h, int row, int converged, Timer& tm) {
   h->iter += 1;

@@ -99,7 +99,7 @@ constexpr int MH_CPL = MH_SEG / 64;                       // cells per lane and 
 // exposures stay in registers for the whole sweep, the next factor's exposures are requested one factor ahead; otherwise
 // Mhat lives in `mhrow`.
 template <bool NORMAL, bool REG, bool MHSTEP /* the Metropolis-Hastings step runs (after convergence) */>
-__global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, const int* nzE, double* accP, double* mhrow, double* mhlog) {
+__global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, const int* nzE, int* nzP, double* accP, double* mhrow, double* mhlog) {
   constexpr int mhstep = MHSTEP ? 1 : 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,13 +107,14 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
   double* part = (double*)smem;                         // [4][S] segment partial sums
   double* pa = part + 4 * (size_t)S;                    // [N] P[k,j] * A[j]
   double* bc = pa + N;                                  // [2] broadcast: proposal, accept flag
-  double* lgc = bc + 2 + tid;                           // REG && MHSTEP: [MH_CPL][MHP_T] this step's candidate logarithms
+  double* pcur = bc + 2;                                // [N] the row's current P[k, .] (thread 0 keeps it): for nzP at the end
+  double* lgc = pcur + N + tid;                         // REG && MHSTEP: [MH_CPL][MHP_T] this step's candidate logarithms
   double* row = mhrow + (size_t)k * G;
   double* lrow = mhlog + (size_t)k * G;                 // !REG: log(max(Mhat, 1e-6)) of the row; candidates at lrow + K G
   double* lcand = lrow + (size_t)K * G;
   const double LOG1 = dlog(1.0);
   const int32_t* Mk = d.Mt + (size_t)G * k;             // M[k, g] at Mt[g + G k]
-  for (int j = tid; j < N; j += MHP_T) pa[j] = d.P[k + (size_t)K * j] * d.A[j];
+  for (int j = tid; j < N; j += MHP_T) { const double pj = d.P[k + (size_t)K * j]; pa[j] = pj * d.A[j]; pcur[j] = pj; }
   __syncthreads();
   double mh[REG ? MH_CPL : 1], enr[REG ? MH_CPL : 1], enx[REG ? MH_CPL : 1], sgr[(REG && NORMAL) ? MH_CPL : 1];
   double lg[(REG && MHSTEP) ? MH_CPL : 1];              // log(max(Mhat, 1e-6)) of the lane's cells
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
         for (int i = 0; i < MH_CPL; ++i) { const int g = g0r + 64 * i; if (wave < S && g < min(G, (wave + 1) * MH_SEG)) enx[i] = d.Et[g + (size_t)G * (n + 1)]; }
       }
     }
-    if (a_n == 0.0) { if (tid == 0) d.P[e] = prior_draw<0>(d, e, t); continue; }          // sample_Pn :12
+    if (a_n == 0.0) { if (tid == 0) { const double x = prior_draw<0>(d, e, t); d.P[e] = x; pcur[n] = x; } continue; }          // sample_Pn :12
     const bool allzero = nzE[n] == 0;
     const double pold = pa[n];                                                             // P[k,n] * A[n]
     const double* En = d.Et + (size_t)G * n;
@@ -265,10 +266,13 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
           for (int g = g0 + lane; g < gend; g += 64) { const double en = En[g]; row[g] = (row[g] - pold * en) + pnew * en; if (mhstep) lrow[g] = lcand[g]; }
         }
       }
-      if (tid == 0) { d.P[e] = pr; pa[n] = pnew; }
+      if (tid == 0) { d.P[e] = pr; pa[n] = pnew; pcur[n] = pr; }
     }
     __syncthreads();                                      // part / bc are reused by the next factor
   }
+  // nzP[n] = number of non-zero entries of column n of P after the sweep (all(P[,n] == 0) test of sample_En_normal :56);
+  // zeroed by k_mh_tail of the previous iteration (or the host before the first one)
+  for (int j = tid; j < N; j += MHP_T) if (pcur[j] != 0.0) atomicAdd(&nzP[j], 1);
 }
 
 // ---- E side: one wave per column, all factors in order; METRICS_ONLY skips the updates (iteration 1) ----
@@ -614,6 +618,53 @@ __global__ __launch_bounds__(ES_T) void k_lp_e(Dev d, uint32_t t, const double* 
     __syncthreads();
     const double r2 = block_tree<ES_T>(ac, buf, tid);
     if (tid == 0) accE_part[blockIdx.x] = r2;
+  }
+}
+
+// ---- k_mh_tail: what follows the P / E sweeps of the MH / Normal models, in ONE launch (they were five) ----
+//   blocks [0, N)                 : log-prior of column n of P and its acceptance sum (k_lp_p)
+//   blocks [N, N + nblkE)         : log-prior / acceptance partial sums of 256 elements of E (k_lp_e)
+//   blocks [N + nblkE, 2N + nblkE): for the NEXT iteration's P sweep: Et = transpose of E, nzE[n] = number of non-zero
+//                                   entries of row n of E (k_mh_nz), and nzP[n] = 0 (k_mh_prow accumulates it)
+__global__ __launch_bounds__(ES_T) void k_mh_tail(Dev d, uint32_t t, const double* accP, double* accPn, const double* accE, double* accE_part, int* nzE, int* nzP, int nblkE) {
+  __shared__ double buf[ES_T];
+  __shared__ int cnt;
+  const int tid = threadIdx.x, blk = blockIdx.x;
+  if (blk < d.N) {
+    if (tid >= 64) return;
+    const int n = blk;
+    double a = 0.0, b = 0.0;
+    for (int k = tid; k < d.K; k += 64) { const int e = k + d.K * n; a = a + prior_logdens<0>(d, e, d.P[e], t); if (accP) b = b + accP[e]; }
+    a = wave_tree64(a); b = wave_tree64(b);
+    if (tid == 0) { d.lpPn[n] = a; if (accPn) accPn[n] = b; }
+  } else if (blk < d.N + nblkE) {
+    const int be = blk - d.N;
+    const long e = (long)be * ES_T + tid;
+    double lp = 0.0, ac = 0.0;
+    if (e < (long)d.lenE) {
+      lp = prior_logdens<1>(d, (int)e, d.E[e], t);
+      if (accE) ac = (d.A[e % d.N] == 1.0) ? accE[e] : 0.0;
+    }
+    const double r = block_tree<ES_T>(lp, buf, tid);
+    if (tid == 0) d.lpE_part[be] = r;
+    if (accE) {
+      __syncthreads();
+      const double r2 = block_tree<ES_T>(ac, buf, tid);
+      if (tid == 0) accE_part[be] = r2;
+    }
+  } else {
+    const int n = blk - d.N - nblkE;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    int c = 0;
+    for (int g = tid; g < d.G; g += ES_T) {
+      const double e = d.E[n + (size_t)d.N * g];
+      d.Et[g + (size_t)d.G * n] = e;
+      c += e != 0.0 ? 1 : 0;
+    }
+    if (c) atomicAdd(&cnt, c);
+    __syncthreads();
+    if (tid == 0) { nzE[n] = cnt; nzP[n] = 0; }
   }
 }
 
