@@ -576,14 +576,16 @@ static void issue_reduce(bnmf_handle* h, uint32_t t, int row, Timer& tm) {
   tm.end(KN_REDUCE, h->side);
   hipEventRecord(h->ev_red, h->side); h->red_issued = true;
 }
-static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm) {
+static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm, bool publish = false) {
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
   const int nbE = (int)(((size_t)h->cfg.N * h->cfg.G + RT - 1) / RT);
   hipEventRecord(h->ev_draw, h->stream);
   hipStreamWaitEvent(h->side, h->ev_draw, 0);
   tm.begin(KN_SIDE, h->side);
-  hipLaunchKernelGGL(k_side, dim3(h->cfg.N + nbP + nbE), dim3(RT), 0, h->side, h->dev, t, nbP, 0, rec_at(h, t, fused_rec(h)), SideDone{});
-  h->flags_valid = false;
+  // publish (MH / Normal sweeps): the last workgroup raises flag [1] = t, which the next P-row kernel polls (no barrier packet)
+  hipLaunchKernelGGL(k_side, dim3(h->cfg.N + nbP + nbE), dim3(RT), 0, h->side, h->dev, t, nbP, 0, rec_at(h, t, fused_rec(h)),
+                     publish ? SideDone{h->dFlags, h->dFlags + 1, (unsigned)(h->cfg.N + nbP + nbE), t} : SideDone{});
+  h->flags_valid = publish;
   tm.end(KN_SIDE, h->side);
   hipEventRecord(h->ev_side, h->side);
   hipEventRecord(h->ev_sideP, h->side);
@@ -780,7 +782,7 @@ static void flush_reduce(bnmf_handle* h, Timer& tm) {
   h->red_pending = false;
 }
 // P and E updates of the MH models (R/sample_params.R:56-64 with sample_Pn/_En -> *_normal -> MH_*_poisson)
-static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged) {
+static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged, bool poll = false) {
   const int K = h->cfg.K, N = h->cfg.N, G = h->cfg.G, S = h->mh_S;
   const bool normal = h->cfg.likelihood == BNMF_NORMAL;
   const int mhstep = (h->cfg.MH && converged && !normal) ? 1 : 0;
@@ -792,7 +794,8 @@ static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged) {
   double* accP = h->arr[BNMF_ACC_P].d; double* accE = h->arr[BNMF_ACC_E].d;
   const bool regP = S <= MHP_W;                              // one 320-column segment per wave: the row's cells stay in registers
   const size_t ldsP = (4 * (size_t)S + 2 * N + 2 + ((regP && mhstep) ? (size_t)MH_CPL * MHP_T : 0)) * sizeof(double);
-  auto goP = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(K), dim3(MHP_T), ldsP, h->stream, h->dev, t, S, (const int*)h->dNzE, h->dNzE + N, accP, h->dMhat, h->dMhat + (size_t)K * h->cfg.G); };
+  auto goP = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(K), dim3(MHP_T), ldsP, h->stream, h->dev, t, S, (const int*)h->dNzE, h->dNzE + N, accP, h->dMhat, h->dMhat + (size_t)K * h->cfg.G,
+                                                poll ? SideWait{h->dFlags + 1, h->dFlags + 1, t, (int*)(h->dFlags + 4)} : SideWait{}); };
   if (normal) { if (regP) goP(k_mh_prow<true, true, false>); else goP(k_mh_prow<true, false, false>); }
   else if (mhstep) { if (regP) goP(k_mh_prow<false, true, true>); else goP(k_mh_prow<false, false, true>); }
   else { if (regP) goP(k_mh_prow<false, true, false>); else goP(k_mh_prow<false, false, false>); }
@@ -834,10 +837,12 @@ static int sweep_mh(bnmf_handle* h, int row, int converged, Timer& tm) {
   const uint32_t t = (uint32_t)h->iter;
   use_slot(h, t);
   if (!h->side_valid) launch_side(h, t, tm);
-  hipStreamWaitEvent(h->stream, h->ev_side, 0);
-  hipStreamWaitEvent(h->stream, h->ev_sideP, 0);
-  tm.begin(KN_MH, h->stream); launch_mh_PE(h, t, converged); tm.end(KN_MH, h->stream);
-  launch_side(h, t + 1, tm);
+  // prior parameters of iteration t: in the steady state the P-row kernel polls the flag k_side publishes (a stream wait is a
+  // barrier packet: ~16 us of bubble per iteration here); after init / set_array / in profile mode a stream wait
+  const bool poll = h->flags_valid && !tm.on;
+  if (!poll) { hipStreamWaitEvent(h->stream, h->ev_side, 0); hipStreamWaitEvent(h->stream, h->ev_sideP, 0); }
+  tm.begin(KN_MH, h->stream); launch_mh_PE(h, t, converged, poll); tm.end(KN_MH, h->stream);
+  launch_side(h, t + 1, tm, !tm.on);
   if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
   tm.begin(KN_OTHER, h->stream); launch_mh_metrics(h, t, h->cfg.learning_rank != 0); tm.end(KN_OTHER, h->stream);
   if (int rc = launch_record(h, t)) return rc;              // after sample_sigmasq, like record_sample (:279) after sample_params (:276)
@@ -1012,7 +1017,7 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
   {
     int ferr = 0;
     HIPCHK(hipMemcpy(&ferr, h->dFlags + 4, sizeof(int), hipMemcpyDeviceToHost));
-    if (ferr) return fail(BNMF_EHIP, "bnmf_run: k_pdraw timed out waiting for the hyper-parameter sweep of its iteration");
+    if (ferr) return fail(BNMF_EHIP, "bnmf_run: a draw kernel timed out waiting for the hyper-parameter sweep of its iteration");
   }
   if (h->dRankSync) {
     int err = 0;

@@ -99,8 +99,9 @@ constexpr int MH_CPL = MH_SEG / 64;                       // cells per lane and 
 // exposures stay in registers for the whole sweep, the next factor's exposures are requested one factor ahead; otherwise
 // Mhat lives in `mhrow`.
 template <bool NORMAL, bool REG, bool MHSTEP /* the Metropolis-Hastings step runs (after convergence) */>
-__global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, const int* nzE, int* nzP, double* accP, double* mhrow, double* mhlog) {
+__global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, const int* nzE, int* nzP, double* accP, double* mhrow, double* mhlog, SideWait sw) {
   constexpr int mhstep = MHSTEP ? 1 : 0;
+  side_wait(sw, threadIdx.x);                           // prior parameters of iteration t (k_side on the side stream)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = d.K, G = d.G, N = d.N, k = blockIdx.x;
