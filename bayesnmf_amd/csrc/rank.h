@@ -81,6 +81,16 @@ BNMF_DEV double rank_cell_ll(const Dev& d, int m, double c, double sg, double lg
   const double h = c < 1e-6 ? 1e-6 : c;
   return ((double)m * dlog(h) - h) - lgf;
 }
+template <bool NORMAL>
+BNMF_DEV double rank_cell_ll_t(int m, double c, double sg, double lgf) {   // rank_cell_ll without the run-time model branch
+  if (NORMAL) {
+    const double sd = dsqrt(sg);
+    const double z = ((double)m - c) / sd;
+    return (-0.91893853320467274178 - dlog(sd)) - 0.5 * (z * z);
+  }
+  const double h = c < 1e-6 ? 1e-6 : c;
+  return ((double)m * dlog(h) - h) - lgf;
+}
 BNMF_DEV double rank_lgf(const Dev& d, int m) { return d.lgfact[m < 0 ? 0 : (m > d.maxM ? d.maxM : m)]; }
 // All-gather of the block sums without a separate barrier: a value is published as two 8-byte granules
 // {tag, low word}, {tag, high word} (one agent-scope relaxed store each: write-through, never torn), tag = a number
@@ -172,6 +182,7 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
   for (int j = tid; j < N; j += RK_T) Ash[j] = d.A[j];
   __syncthreads();
   double mh[REG ? RK_MAXC : 1][2], sgc[(REG && NORMAL) ? RK_MAXC : 1];
+  double lg[(REG && !NORMAL) ? RK_MAXC : 1][2];          // lgamma(M + 1) of the wave's cells (constant over the sweep)
   int mm[REG ? RK_MAXC : 1][2];
   // ---- phase 0: fresh Mhat and the log-likelihood of the current state
   unsigned long long* gran = granbuf;
@@ -182,7 +193,8 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
     for (int c = 0; c < RK_MAXC; ++c) {
       const int g = wg * RK_MAXC + c;
       if (NORMAL) sgc[c] = 1.0;
-      mh[c][0] = mh[c][1] = 0.0; mm[c][0] = mm[c][1] = 0;   // cells beyond G / K: harmless values (mm indexes the lgamma table)
+      mh[c][0] = mh[c][1] = 0.0; mm[c][0] = mm[c][1] = 0;   // cells beyond G / K: harmless values (never added)
+      if (!NORMAL) lg[c][0] = lg[c][1] = 0.0;
       if (g < G) {
         const double sg = normal ? d.sigmasq[g] : 1.0;
         if (NORMAL) sgc[c] = sg;
@@ -195,7 +207,9 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
             for (int j = 0; j < N; ++j) cc = cc + (d.P[kk + (size_t)K * j] * Ash[j]) * d.E[j + (size_t)N * g];
             const int m = d.M[kk + (size_t)K * g];
             mh[c][r] = cc; mm[c][r] = m;
-            acc = acc + rank_cell_ll(d, m, cc, sg, rank_lgf(d, m));
+            const double lgf = rank_lgf(d, m);
+            if (!NORMAL) lg[NORMAL ? 0 : c][r] = lgf;
+            acc = acc + rank_cell_ll(d, m, cc, sg, lgf);
           }
         }
         bs = bs + wave_tree64(acc);                      // lane 0: block sum, columns in ascending order
@@ -255,26 +269,27 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
 #pragma unroll
       for (int c = 0; c < RK_MAXC; ++c) en_[c] = nen[c];
       if (n + 1 < N) prefetch(n + 1);
-      double bs = 0.0;
-      {
+      // straight-line code: the 16 cell terms and then the 8 column trees are independent chains the scheduler can
+      // interleave (per-column / per-cell branches kept them apart: 5.3 us of pure latency per factor); cells beyond K and
+      // columns beyond G hold harmless values and are never added
+      double accv[RK_MAXC];
 #pragma unroll
       for (int c = 0; c < RK_MAXC; ++c) {
-        const int g = wg * RK_MAXC + c;
-        if (g < G) {
-          double acc = 0.0;
+        double acc = 0.0;
 #pragma unroll
-          for (int r = 0; r < 2; ++r) {
-            const int kk = (r << 6) + lane;
-            if (kk < K) {
-              const double tt = (r ? p1 : p0) * en_[c];
-              const double alt = (a_old == 1.0) ? mh[c][r] - tt : mh[c][r] + tt;
-              acc = acc + rank_cell_ll(d, mm[c][r], alt, NORMAL ? sgc[c] : 1.0, NORMAL ? 0.0 : rank_lgf(d, mm[c][r]));
-            }
-          }
-          bs = bs + wave_tree64(acc);
+        for (int r = 0; r < 2; ++r) {
+          const double tt = (r ? p1 : p0) * en_[c];
+          const double alt = (a_old == 1.0) ? mh[c][r] - tt : mh[c][r] + tt;
+          const double ll = rank_cell_ll_t<NORMAL>(mm[c][r], alt, NORMAL ? sgc[NORMAL ? c : 0] : 1.0, NORMAL ? 0.0 : lg[NORMAL ? 0 : c][r]);
+          acc = ((r << 6) + lane < K) ? acc + ll : acc;
         }
+        accv[c] = acc;
       }
-      }
+#pragma unroll
+      for (int c = 0; c < RK_MAXC; ++c) accv[c] = wave_tree64(accv[c]);
+      double bs = 0.0;
+#pragma unroll
+      for (int c = 0; c < RK_MAXC; ++c) bs = (wg * RK_MAXC + c < G) ? bs + accv[c] : bs;   // lane 0: block sum, columns in ascending order
       if (lane == 0 && wg < NB) rank_publish(gran, wg, tag0 + phase, bs);
     } else {
       for (int b = wg; b < NB; b += Wt) {
