@@ -248,7 +248,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
     const bool nrm0 = cfg->likelihood == BNMF_NORMAL;
     const long cap_reg = (long)fit(nrm0 ? (const void*)k_rank_sweep<true, true> : (const void*)k_rank_sweep<true, false>) * prop0.multiProcessorCount;
     const long cap_gen = (long)fit(nrm0 ? (const void*)k_rank_sweep<false, true> : (const void*)k_rank_sweep<false, false>) * prop0.multiProcessorCount;
-    h->rank_reg = K <= 128 && wg_needed <= cap_reg;
+    h->rank_reg = K <= 96 && wg_needed <= cap_reg;       // register variant: rows 64..95 of two columns share a register (rank.h)
     // (a wider grid with the blocks dealt wave-major over all CUs was measured: no gain, the sweep is bound by the
     // per-factor exchange, not by VALU contention)
     h->rank_grid = (int)std::min<long>(wg_needed, h->rank_reg ? cap_reg : cap_gen);

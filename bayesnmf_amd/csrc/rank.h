@@ -160,8 +160,17 @@ BNMF_DEV double rank_decide(const Dev& d, uint32_t t, int n, double ll0, double 
   return (runif(s) < p) ? 1.0 : 0.0;
 }
 
-// REG: one block of 8 columns per wave, its cells (8 columns x 2 row passes, K <= 128) in registers for the whole
-// sweep; otherwise a wave walks its blocks b = w, w + Wt, ... and Mhat lives in the global scratch mhg[k + K g].
+// REG (K <= 96): one block of 8 columns per wave, its cells in registers for the whole sweep: rows 0..63 of every
+// column (slot 0: lane = row), and rows 64..95 of TWO columns per register (slot 1: lanes 0..31 column 2p, lanes 32..63
+// column 2p + 1, row 64 + (lane & 31)), so that no lane idles on a half-empty second pass; the upper half's terms are
+// brought down with v_permlane32_swap before they are added to their column's accumulators (lane i = rows i, i + 64, as
+// the canonical sum demands).  Otherwise a wave walks its blocks b = w, w + Wt, ... and Mhat lives in the global scratch.
+BNMF_DEV double down32(double v) {                        // lane l < 32 gets lane l + 32's value
+  const unsigned lo = (unsigned)__double_as_longlong(v), hi = (unsigned)(__double_as_longlong(v) >> 32);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __longlong_as_double(((long long)b[1] << 32) | (unsigned)a[1]);
+}
 template <bool REG, bool NORMAL>
 __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsigned long long* granbuf /* [2][2 NB] */, int NB, int* err, double* mhg, unsigned long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -181,40 +190,52 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
   double* vals = Ash + N;                                // [NB] gathered block sums
   for (int j = tid; j < N; j += RK_T) Ash[j] = d.A[j];
   __syncthreads();
-  double mh[REG ? RK_MAXC : 1][2], sgc[(REG && NORMAL) ? RK_MAXC : 1];
-  double lg[(REG && !NORMAL) ? RK_MAXC : 1][2];          // lgamma(M + 1) of the wave's cells (constant over the sweep)
-  int mm[REG ? RK_MAXC : 1][2];
+  constexpr int RK_P = RK_MAXC / 2;                       // column pairs of the second row slot
+  double mh0[REG ? RK_MAXC : 1], mh1[REG ? RK_P : 1], sgc[(REG && NORMAL) ? RK_MAXC : 1];
+  double lg0[(REG && !NORMAL) ? RK_MAXC : 1], lg1[(REG && !NORMAL) ? RK_P : 1];   // lgamma(M + 1) of the wave's cells
+  int mm0[REG ? RK_MAXC : 1], mm1[REG ? RK_P : 1];
+  const int half = lane >> 5, row1 = 64 + (lane & 31);    // slot 1: this lane's column of the pair and its row
+  const bool lowv1 = lane < 32 && 64 + lane < K;          // lanes that own an accumulator with a second row
   // ---- phase 0: fresh Mhat and the log-likelihood of the current state
   unsigned long long* gran = granbuf;
   unsigned phase = 1;
   if (REG) {
-    double bs = 0.0;
+    double accv[RK_MAXC];
+    auto fresh = [&](int kk, int g, double sg, double& mhv, int& mv, double& lgv) {   // Mhat, M, lgamma(M+1) and the cell's term
+      double cc = 0.0;
+      for (int j = 0; j < N; ++j) cc = cc + (d.P[kk + (size_t)K * j] * Ash[j]) * d.E[j + (size_t)N * g];
+      const int m = d.M[kk + (size_t)K * g];
+      const double lgf = rank_lgf(d, m);
+      mhv = cc; mv = m; lgv = lgf;
+      return rank_cell_ll(d, m, cc, sg, lgf);
+    };
 #pragma unroll
-    for (int c = 0; c < RK_MAXC; ++c) {
+    for (int c = 0; c < RK_MAXC; ++c) {                   // slot 0: rows 0..63 (cells beyond G / K: harmless values, never added)
       const int g = wg * RK_MAXC + c;
       if (NORMAL) sgc[c] = 1.0;
-      mh[c][0] = mh[c][1] = 0.0; mm[c][0] = mm[c][1] = 0;   // cells beyond G / K: harmless values (never added)
-      if (!NORMAL) lg[c][0] = lg[c][1] = 0.0;
+      mh0[c] = 0.0; mm0[c] = 0; accv[c] = 0.0;
+      double lgv = 0.0;
       if (g < G) {
         const double sg = normal ? d.sigmasq[g] : 1.0;
         if (NORMAL) sgc[c] = sg;
-        double acc = 0.0;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const int kk = (r << 6) + lane;
-          if (kk < K) {
-            double cc = 0.0;
-            for (int j = 0; j < N; ++j) cc = cc + (d.P[kk + (size_t)K * j] * Ash[j]) * d.E[j + (size_t)N * g];
-            const int m = d.M[kk + (size_t)K * g];
-            mh[c][r] = cc; mm[c][r] = m;
-            const double lgf = rank_lgf(d, m);
-            if (!NORMAL) lg[NORMAL ? 0 : c][r] = lgf;
-            acc = acc + rank_cell_ll(d, m, cc, sg, lgf);
-          }
-        }
-        bs = bs + wave_tree64(acc);                      // lane 0: block sum, columns in ascending order
+        if (lane < K) accv[c] = accv[c] + fresh(lane, g, sg, mh0[c], mm0[c], lgv);
       }
+      if (!NORMAL) lg0[NORMAL ? 0 : c] = lgv;
     }
+#pragma unroll
+    for (int p = 0; p < RK_P; ++p) {                      // slot 1: rows 64..95 of columns 2p (lanes 0..31) and 2p + 1 (lanes 32..63)
+      const int g = wg * RK_MAXC + 2 * p + half;
+      mh1[p] = 0.0; mm1[p] = 0;
+      double lgv = 0.0, v = 0.0;
+      if (g < G && row1 < K) v = fresh(row1, g, normal ? d.sigmasq[g] : 1.0, mh1[p], mm1[p], lgv);
+      if (!NORMAL) lg1[NORMAL ? 0 : p] = lgv;
+      const double w = down32(v);
+      if (lowv1 && wg * RK_MAXC + 2 * p < G) accv[2 * p] = accv[2 * p] + v;
+      if (lowv1 && wg * RK_MAXC + 2 * p + 1 < G) accv[2 * p + 1] = accv[2 * p + 1] + w;
+    }
+    double bs = 0.0;
+#pragma unroll
+    for (int c = 0; c < RK_MAXC; ++c) { const double tr = wave_tree64(accv[c]); if (wg * RK_MAXC + c < G) bs = bs + tr; }   // lane 0: block sum, columns in ascending order
     if (lane == 0 && wg < NB) rank_publish(gran, wg, tag0 + phase, bs);
   } else {
     for (int b = wg; b < NB; b += Wt) {
@@ -253,7 +274,7 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
   double np0 = 0.0, np1 = 0.0, nen[REG ? RK_MAXC : 1];
   auto prefetch = [&](int n) {
     const double* Pq = d.P + (size_t)K * n;
-    np0 = lane < K ? Pq[lane] : 0.0; np1 = 64 + lane < K ? Pq[64 + lane] : 0.0;
+    np0 = lane < K ? Pq[lane] : 0.0; np1 = row1 < K ? Pq[row1] : 0.0;   // slot 1: both half-waves hold rows 64 + (lane & 31)
 #pragma unroll
     for (int c = 0; c < (REG ? RK_MAXC : 1); ++c) { const int g = wg * RK_MAXC + c; nen[c] = g < G ? d.E[n + (size_t)N * g] : 0.0; }
   };
@@ -274,16 +295,21 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
       // columns beyond G hold harmless values and are never added
       double accv[RK_MAXC];
 #pragma unroll
-      for (int c = 0; c < RK_MAXC; ++c) {
-        double acc = 0.0;
+      for (int c = 0; c < RK_MAXC; ++c) {                 // slot 0
+        const double tt = p0 * en_[c];
+        const double alt = (a_old == 1.0) ? mh0[c] - tt : mh0[c] + tt;
+        const double ll = rank_cell_ll_t<NORMAL>(mm0[c], alt, NORMAL ? sgc[NORMAL ? c : 0] : 1.0, NORMAL ? 0.0 : lg0[NORMAL ? 0 : c]);
+        accv[c] = (lane < K) ? 0.0 + ll : 0.0;
+      }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const double tt = (r ? p1 : p0) * en_[c];
-          const double alt = (a_old == 1.0) ? mh[c][r] - tt : mh[c][r] + tt;
-          const double ll = rank_cell_ll_t<NORMAL>(mm[c][r], alt, NORMAL ? sgc[NORMAL ? c : 0] : 1.0, NORMAL ? 0.0 : lg[NORMAL ? 0 : c][r]);
-          acc = ((r << 6) + lane < K) ? acc + ll : acc;
-        }
-        accv[c] = acc;
+      for (int p = 0; p < RK_P; ++p) {                    // slot 1: two columns per register
+        const double tt = p1 * (half ? en_[2 * p + 1] : en_[2 * p]);
+        const double alt = (a_old == 1.0) ? mh1[p] - tt : mh1[p] + tt;
+        const double sg = NORMAL ? (half ? sgc[NORMAL ? 2 * p + 1 : 0] : sgc[NORMAL ? 2 * p : 0]) : 1.0;
+        const double v = rank_cell_ll_t<NORMAL>(mm1[p], alt, sg, NORMAL ? 0.0 : lg1[NORMAL ? 0 : p]);
+        const double w = down32(v);
+        accv[2 * p] = lowv1 ? accv[2 * p] + v : accv[2 * p];
+        accv[2 * p + 1] = lowv1 ? accv[2 * p + 1] + w : accv[2 * p + 1];
       }
 #pragma unroll
       for (int c = 0; c < RK_MAXC; ++c) accv[c] = wave_tree64(accv[c]);
@@ -333,13 +359,9 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
     if (a_new != a_old) {
       if (REG) {
 #pragma unroll
-        for (int c = 0; c < RK_MAXC; ++c) {
-          const int g = wg * RK_MAXC + c;
-          if (g < G) {
+        for (int c = 0; c < RK_MAXC; ++c) { const double tt = p0 * en_[c]; mh0[c] = (a_old == 1.0) ? mh0[c] - tt : mh0[c] + tt; }
 #pragma unroll
-            for (int r = 0; r < 2; ++r) { const double tt = (r ? p1 : p0) * en_[c]; mh[c][r] = (a_old == 1.0) ? mh[c][r] - tt : mh[c][r] + tt; }
-          }
-        }
+        for (int p = 0; p < RK_P; ++p) { const double tt = p1 * (half ? en_[2 * p + 1] : en_[2 * p]); mh1[p] = (a_old == 1.0) ? mh1[p] - tt : mh1[p] + tt; }
       } else {
         for (int b = wg; b < NB; b += Wt)
           for (int c = 0; c < RK_MAXC; ++c) {
