@@ -38,7 +38,7 @@ struct bnmf_handle {
   hipStream_t stream = nullptr;        // main stream: draws, k_zalloc, reductions
   hipStream_t side = nullptr;          // side stream: k_side (E part) of the next iteration (overlaps k_zalloc), k_reduce
   hipStream_t side2 = nullptr;         // second side stream: k_side P part (starts right after k_pdraw) and Esum
-  hipEvent_t ev_draw = nullptr, ev_side = nullptr, ev_sideP = nullptr, ev_p = nullptr, ev_z = nullptr, ev_red = nullptr;
+  hipEvent_t ev_draw = nullptr, ev_side = nullptr, ev_sideP = nullptr, ev_p = nullptr, ev_z = nullptr, ev_red = nullptr, ev_rank = nullptr;
   bool side_valid = false;             // k_side of iteration iter+1 has been issued
   bool mh_prep_valid = false;          // MH / Normal models: Et, nzE are current and nzP is zero (k_mh_tail of the previous iteration)
   const void* z_attr_kernel = nullptr;   // allocation kernel whose dynamic-LDS limit has been raised for this handle
@@ -194,6 +194,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   HIPCHK(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_sideP, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_p, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_rank, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_z, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_red, hipEventDisableTiming));
   HIPCHK(hipMalloc(&h->dM, K * G * sizeof(int32_t)));
@@ -417,7 +418,7 @@ int bnmf_destroy(bnmf_handle* h) {
   if (h->dMhatZ) hipFree(h->dMhatZ);
   if (h->dMhat) hipFree(h->dMhat); if (h->dAccPn) hipFree(h->dAccPn); if (h->dAccEpart) hipFree(h->dAccEpart); if (h->dNzE) hipFree(h->dNzE);
   if (h->dEt) hipFree(h->dEt); if (h->dMt) hipFree(h->dMt); if (h->zring) hipFree(h->zring);
-  if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); if (h->side) hipStreamDestroy(h->side); if (h->side2) hipStreamDestroy(h->side2);
+  if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_rank) hipEventDestroy(h->ev_rank); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); if (h->side) hipStreamDestroy(h->side); if (h->side2) hipStreamDestroy(h->side2);
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
   if (h->dMap) hipFree(h->dMap);
   if (h->dFlags) hipFree(h->dFlags);
@@ -621,6 +622,32 @@ static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm) {   // ev_draw 
   h->flags_valid = true;
   // ONE event for the main stream: ev_side fires when the E part (side) AND the P part / Esum / k_lpe (side2) are done.
   // (A wait costs a barrier packet on the main stream, ~8 us even when the event has long fired.)
+  hipStreamWaitEvent(h->side, h->ev_sideP, 0);
+  hipEventRecord(h->ev_side, h->side);
+  h->side_valid = true;
+  if (h->red_pending) { issue_reduce(h, h->red_t, h->red_row, tm); h->red_pending = false; }
+}
+// Rank learning: the hyper sweep of t+1 in two parts.  Early (released by k_edraw): the k_side kernels.  They hold 64+ VGPRs
+// and cannot be scheduled on a CU whose SIMDs carry two waves of the rank sweep (230 VGPRs each): they run on the ~100 CUs
+// the rank sweep leaves free and are done before k_zalloc starts.  Late (released by the rank sweep): the small log-prior
+// kernels (16-28 VGPRs), which DO fit beside rank-sweep waves and delayed the whole co-resident grid at every factor.
+static void launch_side_early(bnmf_handle* h, uint32_t t) {
+  const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
+  const int nbE = (int)(((size_t)h->cfg.N * h->cfg.G + RT - 1) / RT);
+  hipStreamWaitEvent(h->side2, h->ev_draw, 0);
+  hipLaunchKernelGGL(k_side, dim3(nbP), dim3(RT), 0, h->side2, h->dev, t, nbP, h->cfg.N, rec_at(h, t, fused_rec(h)), SideDone{});
+  hipLaunchKernelGGL(k_side, dim3(h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)h->cfg.N, t});
+  hipStreamWaitEvent(h->side, h->ev_draw, 0);
+  hipLaunchKernelGGL(k_side, dim3(nbE), dim3(RT), 0, h->side, h->dev, t, nbP, h->cfg.N + nbP, rec_at(h, t, fused_rec(h)), SideDone{h->dFlags, h->dFlags + 1, (unsigned)nbE, t});
+  h->flags_valid = true;
+}
+static void launch_side_late(bnmf_handle* h, uint32_t t, Timer& tm) {
+  hipStreamWaitEvent(h->side2, h->ev_rank, 0);
+  // k_lpp rewrites lpPn slot (t-1) % 3, last read by k_reduce of iteration t-4 (side stream): order behind it
+  if (h->red_issued) hipStreamWaitEvent(h->side2, h->ev_red, 0);
+  hipLaunchKernelGGL(k_lpp, dim3(h->cfg.N), dim3(64), 0, h->side2, h->dev, t - 1);   // log-prior of the P just drawn
+  hipLaunchKernelGGL(k_lpe, dim3(h->nblkE), dim3(ES_T), 0, h->side2, h->dev, t - 1); // ... and of the E just drawn
+  hipEventRecord(h->ev_sideP, h->side2);
   hipStreamWaitEvent(h->side, h->ev_sideP, 0);
   hipEventRecord(h->ev_side, h->side);
   h->side_valid = true;
@@ -873,13 +900,12 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
       hipExtLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, 0, 0, rec_at(h, t, rec).E);
       launch_side_E(h, t + 1, tm);                         // overlaps k_zalloc below
     } else {
-      // rank learning: every workgroup of the rank sweep waits for all others at every factor, so a hyper-sweep
-      // workgroup sharing a CU with one of them delays the whole grid.  The hyper sweep of t+1 starts when the rank sweep
-      // is done (ev_draw rides on its dispatch) and overlaps k_zalloc only.
-      hipLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, 0, 0, rec_at(h, t, rec).E);
-      launch_rank(h, t, h->ev_draw);
-      launch_side_P(h, t + 1, h->ev_draw);
-      launch_side_E(h, t + 1, tm);
+      // rank learning: every workgroup of the rank sweep waits for all others at every factor, so a kernel sharing a CU
+      // with one of them delays the whole grid: see launch_side_early / launch_side_late
+      hipExtLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, 0, 0, rec_at(h, t, rec).E);
+      launch_side_early(h, t + 1);
+      launch_rank(h, t, h->ev_rank);
+      launch_side_late(h, t + 1, tm);
     }
   }
   if (h->cfg.learning_rank && tm.on) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
