@@ -40,6 +40,7 @@ struct bnmf_handle {
   hipStream_t side2 = nullptr;         // second side stream: k_side P part (starts right after k_pdraw) and Esum
   hipEvent_t ev_draw = nullptr, ev_side = nullptr, ev_sideP = nullptr, ev_p = nullptr, ev_z = nullptr, ev_red = nullptr, ev_rank = nullptr;
   bool side_valid = false;             // k_side of iteration iter+1 has been issued
+  double* E_alt = nullptr;             // Gibbs sweep: the other E buffer (k_edraw of t+1 does not overwrite what k_lpe of t still reads)
   bool mh_prep_valid = false;          // MH / Normal models: Et, nzE are current and nzP is zero (k_mh_tail of the previous iteration)
   const void* z_attr_kernel = nullptr;   // allocation kernel whose dynamic-LDS limit has been raised for this handle
   bool red_pending = false, red_issued = false; uint32_t red_t = 0; int red_row = 0;   // k_reduce of the previous iteration, issued late
@@ -240,7 +241,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
     // workgroups of each variant fit a CU (registers, LDS); where the answer is SGPR-limited (>= 6 per CU) the query can
     // be one high (MI355X_MICROARCH.md), so one is kept in reserve there; never plan more than two per CU.  Should the
     // grid still not be co-resident, the bounded spins time out and bnmf_run reports it (no hang).
-    const size_t rlds = ((size_t)N + NB) * sizeof(double);
+    const size_t rlds = ((size_t)N + NB + N + 1) * sizeof(double);
     auto fit = [&](const void* fn) {
       int nb = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, RK_T, rlds) != hipSuccess || nb < 1) nb = 1;
@@ -415,6 +416,7 @@ int bnmf_destroy(bnmf_handle* h) {
   hipFree(h->dM); hipFree(h->dZsumK); hipFree(h->dZsumG); if (h->dZ) hipFree(h->dZ);
   hipFree(h->dR); hipFree(h->dRedraw); hipFree(h->dEsum); hipFree(h->dPsum); hipFree(h->dlpPn);
   hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol); if (h->dRankMhat) hipFree(h->dRankMhat); if (h->dRankSync) hipFree(h->dRankSync);
+  if (h->E_alt) hipFree(h->E_alt);
   if (h->dMhatZ) hipFree(h->dMhatZ);
   if (h->dMhat) hipFree(h->dMhat); if (h->dAccPn) hipFree(h->dAccPn); if (h->dAccEpart) hipFree(h->dAccEpart); if (h->dNzE) hipFree(h->dNzE);
   if (h->dEt) hipFree(h->dEt); if (h->dMt) hipFree(h->dMt); if (h->zring) hipFree(h->zring);
@@ -630,13 +632,13 @@ static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm) {   // ev_draw 
 // Rank learning: the hyper sweep of t+1 in two parts.  Early (released by k_edraw): the k_side kernels.  They hold 64+ VGPRs
 // and cannot be scheduled on a CU whose SIMDs carry two waves of the rank sweep (230 VGPRs each): they run on the ~100 CUs
 // the rank sweep leaves free and are done before k_zalloc starts.  Late (released by the rank sweep): the small log-prior
-// kernels (16-28 VGPRs), which DO fit beside rank-sweep waves and delayed the whole co-resident grid at every factor.
+// kernels (16-28 VGPRs), which DO fit beside rank-sweep waves and delayed the whole co-resident grid at every factor, and
+// Esum, whose flag releases the next iteration's draws and therefore has to come after them.
 static void launch_side_early(bnmf_handle* h, uint32_t t) {
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
   const int nbE = (int)(((size_t)h->cfg.N * h->cfg.G + RT - 1) / RT);
   hipStreamWaitEvent(h->side2, h->ev_draw, 0);
   hipLaunchKernelGGL(k_side, dim3(nbP), dim3(RT), 0, h->side2, h->dev, t, nbP, h->cfg.N, rec_at(h, t, fused_rec(h)), SideDone{});
-  hipLaunchKernelGGL(k_side, dim3(h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)h->cfg.N, t});
   hipStreamWaitEvent(h->side, h->ev_draw, 0);
   hipLaunchKernelGGL(k_side, dim3(nbE), dim3(RT), 0, h->side, h->dev, t, nbP, h->cfg.N + nbP, rec_at(h, t, fused_rec(h)), SideDone{h->dFlags, h->dFlags + 1, (unsigned)nbE, t});
   h->flags_valid = true;
@@ -647,6 +649,9 @@ static void launch_side_late(bnmf_handle* h, uint32_t t, Timer& tm) {
   if (h->red_issued) hipStreamWaitEvent(h->side2, h->ev_red, 0);
   hipLaunchKernelGGL(k_lpp, dim3(h->cfg.N), dim3(64), 0, h->side2, h->dev, t - 1);   // log-prior of the P just drawn
   hipLaunchKernelGGL(k_lpe, dim3(h->nblkE), dim3(ES_T), 0, h->side2, h->dev, t - 1); // ... and of the E just drawn
+  // Esum last: its flag [3] releases the next iteration's draws, which overwrite the P and E the two kernels above read
+  const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
+  hipLaunchKernelGGL(k_side, dim3(h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)h->cfg.N, t});
   hipEventRecord(h->ev_sideP, h->side2);
   hipStreamWaitEvent(h->side, h->ev_sideP, 0);
   hipEventRecord(h->ev_side, h->side);
@@ -715,13 +720,14 @@ static int launch_zalloc(bnmf_handle* h, uint32_t t) {
   }
 }
 // sample_R then sample_An for n = 1..N (R/sample_params.R:67-74): one persistent launch for the N sequential updates
-static void launch_rank(bnmf_handle* h, uint32_t t, hipEvent_t stop = nullptr) {
+// row >= 0 (Gibbs sweep): the kernel also records A, R and sum(A) of the iteration (k_sumA's work)
+static void launch_rank(bnmf_handle* h, uint32_t t, hipEvent_t stop = nullptr, int row = -1) {
   const int N = h->cfg.N;
-  hipLaunchKernelGGL(k_rank_R, dim3(1), dim3(64), (size_t)(N + 1) * sizeof(double), h->stream, h->dev, t, 0);
   const int NB = (h->cfg.G + RK_MAXC - 1) / RK_MAXC;
-  const size_t lds = ((size_t)N + NB) * sizeof(double);
+  const size_t lds = ((size_t)N + NB + N + 1) * sizeof(double);
+  const RecDst rr = row >= 0 ? rec_at(h, t, fused_rec(h)) : RecDst{};
   auto go = [&](auto kern) {
-    hipExtLaunchKernelGGL(kern, dim3(h->rank_grid), dim3(RK_T), (uint32_t)lds, h->stream, nullptr, stop, 0, h->dev, t, (unsigned long long*)h->dRankCol, NB, (int*)(h->dRankSync + 4), h->dRankMhat, (unsigned long long*)h->dRankDbg);
+    hipExtLaunchKernelGGL(kern, dim3(h->rank_grid), dim3(RK_T), (uint32_t)lds, h->stream, nullptr, stop, 0, h->dev, t, (unsigned long long*)h->dRankCol, NB, (int*)(h->dRankSync + 4), h->dRankMhat, (unsigned long long*)h->dRankDbg, row, rr.A, rr.R);
   };
   const bool nrm = h->cfg.likelihood == BNMF_NORMAL;
   if (h->rank_reg) { if (nrm) go(k_rank_sweep<true, true>); else go(k_rank_sweep<true, false>); }
@@ -795,8 +801,9 @@ static int launch_record(bnmf_handle* h, uint32_t t) {
 }
 // k_reduce of iteration t: on the side stream, after the main stream has finished k_zalloc / metrics of t
 // metrics of iteration t: sum(A) now (main stream, right after the rank update); the canonical reductions later
-static void launch_reduce(bnmf_handle* h, uint32_t t, int row, Timer& tm) {
-  if (h->cfg.learning_rank) hipLaunchKernelGGL(k_sumA, dim3(1), dim3(64), 0, h->stream, h->dev, row, (const double*)accPn_slot(h, t), rec_at(h, t, fused_rec(h)));
+static void launch_reduce(bnmf_handle* h, uint32_t t, int row, Timer& tm, bool rank_wrote = false) {   // rank_wrote: k_rank_sweep recorded A, R, sum(A)
+  // sum(A) and the A-masked acceptance sum (MH / Normal sweeps, init); the Gibbs sweep's rank kernel writes sum(A), A, R itself
+  if (h->cfg.learning_rank && !rank_wrote) hipLaunchKernelGGL(k_sumA, dim3(1), dim3(64), 0, h->stream, h->dev, row, (const double*)accPn_slot(h, t), rec_at(h, t, fused_rec(h)));
   h->red_pending = true; h->red_t = t; h->red_row = row;
 }
 // ... or at once (init, end of a run): the side stream waits for everything issued on the main stream so far
@@ -882,6 +889,15 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   use_slot(h, t);
   const bool rec = fused_rec(h);
   if (!h->side_valid) launch_side(h, t, tm);               // first sweep after init / set_array
+  // E is double-buffered: this iteration's k_edraw writes the buffer that held E_{t-2}, so the log-prior kernel of
+  // iteration t-1 (k_lpe, side stream, ordered only behind its own inputs) can never see its E overwritten.  Nothing below
+  // reads E_{t-1}: the draws use ZsumK / Psum / Esum, everything after k_edraw works on E_t.
+  if (!h->E_alt) {
+    HIPCHK(hipMalloc(&h->E_alt, (size_t)h->cfg.N * h->cfg.G * sizeof(double)));
+    HIPCHK(hipMemsetAsync(h->E_alt, 0, (size_t)h->cfg.N * h->cfg.G * sizeof(double), h->stream));
+  }
+  std::swap(h->arr[BNMF_E].d, h->E_alt);
+  h->dev.E = h->arr[BNMF_E].d;
   // prior parameters + Esum of iteration t: in the steady state k_pdraw polls the flags their kernels publish (no barrier
   // packet on the main stream); after init / set_array / in profile mode a stream wait
   const bool poll = h->flags_valid && !tm.on;
@@ -904,14 +920,14 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
       // with one of them delays the whole grid: see launch_side_early / launch_side_late
       hipExtLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, 0, 0, rec_at(h, t, rec).E);
       launch_side_early(h, t + 1);
-      launch_rank(h, t, h->ev_rank);
+      launch_rank(h, t, h->ev_rank, row);
       launch_side_late(h, t + 1, tm);
     }
   }
-  if (h->cfg.learning_rank && tm.on) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
+  if (h->cfg.learning_rank && tm.on) { tm.begin(KN_RANK, h->stream); launch_rank(h, t, nullptr, row); tm.end(KN_RANK, h->stream); }
   tm.begin(KN_ZALLOC, h->stream); if (int rc = launch_zalloc(h, t)) return rc; tm.end(KN_ZALLOC, h->stream);
   record_Z(h, t);
-  launch_reduce(h, t, row, tm);
+  launch_reduce(h, t, row, tm, h->cfg.learning_rank != 0);
   return 0;
 }
 

@@ -172,7 +172,8 @@ BNMF_DEV double down32(double v) {                        // lane l < 32 gets la
   return __longlong_as_double(((long long)b[1] << 32) | (unsigned)a[1]);
 }
 template <bool REG, bool NORMAL>
-__global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsigned long long* granbuf /* [2][2 NB] */, int NB, int* err, double* mhg, unsigned long long* dbg) {
+__global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsigned long long* granbuf /* [2][2 NB] */, int NB, int* err, double* mhg, unsigned long long* dbg,
+                                                         int row /* metrics row, or -1 */, double* recA, double* recR) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double buf[RK_T];
   __shared__ double bc[2];
@@ -188,8 +189,35 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
   // workgroups inside the launch (the global A is written for the kernels that follow)
   double* Ash = (double*)smem;                           // [N]
   double* vals = Ash + N;                                // [NB] gathered block sums
+  double* wR = vals + NB;                                // [N+1] weights of sample_R
+  __shared__ int Rsh;
   for (int j = tid; j < N; j += RK_T) Ash[j] = d.A[j];
   __syncthreads();
+  // sample_R :217-241 (was a launch of its own): every workgroup draws the same R from the same stream; the N+1 weights
+  // are evaluated one per lane of wave 0, then added and scanned in r order by its lane 0
+  if (wave == 0) {
+    Stream s(d.k0, d.k1, BNMF_V_R, 0u, t);
+    const double u = runif(s);
+    const double T = temp_at(d, t);
+    double sA = 0.0;
+    for (int n = 0; n < N; ++n) sA = sA + Ash[n];
+    for (int r = lane; r <= N; r += 64) {
+      const double p1 = prior_prob_1((double)r, (double)N);
+      wR[r] = dexp(T * (sA * dlog(p1) + ((double)N - sA) * dlog(1.0 - p1)));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      double tot = 0.0;
+      for (int r = 0; r <= N; ++r) tot = tot + wR[r];
+      const double target = u * tot;
+      double cum = 0.0;
+      int pick = N;
+      for (int r = 0; r <= N; ++r) { cum = cum + wR[r]; if (target < cum) { pick = r; break; } }
+      Rsh = pick;
+      if (blockIdx.x == 0) *d.R = pick;
+    }
+  }
   constexpr int RK_P = RK_MAXC / 2;                       // column pairs of the second row slot
   double mh0[REG ? RK_MAXC : 1], mh1[REG ? RK_P : 1], sgc[(REG && NORMAL) ? RK_MAXC : 1];
   double lg0[(REG && !NORMAL) ? RK_MAXC : 1], lg1[(REG && !NORMAL) ? RK_P : 1];   // lgamma(M + 1) of the wave's cells
@@ -265,7 +293,7 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
   RankConst rc{};
   double sumA = 0.0;
   if (tid == 0) {
-    const double pi1 = prior_prob_1((double)*d.R, (double)N);
+    const double pi1 = prior_prob_1((double)Rsh, (double)N);   // written by this thread (wave 0, lane 0) above
     rc.l1mp = dlog(1.0 - pi1); rc.lpi = dlog(pi1); rc.lgG = dlog((double)G); rc.T = temp_at(d, t);
     for (int j = 0; j < N; ++j) sumA = sumA + Ash[j];
   }
@@ -378,6 +406,16 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
     if (tid == 0) { Ash[n] = a_new; if (blockIdx.x == 0) d.A[n] = a_new; }
     __syncthreads();
     RKSTAMP(4);
+  }
+  // what k_sumA did in a launch of its own (Gibbs sweep): A, R into the ring, sum(A) into the raw metrics row
+  if (blockIdx.x == 0 && row >= 0) {
+    if (recA) for (int j = tid; j < N; j += RK_T) recA[j] = Ash[j];
+    if (tid == 0) {
+      if (recR) *recR = (double)Rsh;
+      double sA = 0.0;
+      for (int j = 0; j < N; ++j) sA = sA + Ash[j];
+      d.raw[(size_t)row * 8 + 5] = sA;
+    }
   }
 }
 
