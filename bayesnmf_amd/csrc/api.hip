@@ -557,6 +557,7 @@ struct Timer {   // optional per-kernel HIP-event bracketing (serialises the two
 };
 static RecDst rec_at(const bnmf_handle* h, uint32_t t, bool on);
 static bool fused_rec(const bnmf_handle* h);
+static double* ring_at(const bnmf_handle* h, int id, uint32_t t);
 static RecDst rec_pdraw(const bnmf_handle* h, uint32_t t, bool on) {   // what k_pdraw records
   RecDst r = rec_at(h, t, on);
   if (h->cfg.learning_rank) { r.A = nullptr; r.R = nullptr; }          // then k_sumA records them, after the rank update
@@ -602,6 +603,10 @@ static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm, bool publish = fa
 // Esum follows it once k_edraw is done; both are over long before k_zalloc, so that the event the next k_pdraw
 // waits for is already satisfied when the main stream reaches it (a late cross-stream event costs ~12 us).
 // The E-side sweep (needed only by the next k_edraw) shares the CUs with k_zalloc and ends with it.
+// what k_lpe reads as E_t: the ring slot of iteration t when the sweep records (safe for a whole window), else the live E
+// (then sweep() double-buffers E)
+static bool lpe_from_ring(const bnmf_handle* h) { return fused_rec(h) && h->arr[BNMF_E].ring != nullptr; }
+static const double* lpe_src(const bnmf_handle* h, uint32_t t) { return lpe_from_ring(h) ? ring_at(h, BNMF_E, t) : h->dev.E; }
 static void launch_side_P(bnmf_handle* h, uint32_t t, hipEvent_t after = nullptr) {   // ev_p = completion of k_pdraw(t-1)
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
   hipStreamWaitEvent(h->side2, after ? after : h->ev_p, 0);
@@ -617,7 +622,7 @@ static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm) {   // ev_draw 
   // Esum closes the side2 work the next k_pdraw needs (the P part ran before it on the same stream): it publishes flag [3]
   hipLaunchKernelGGL(k_side, dim3(h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)h->cfg.N, t});
   // log-prior of the E just drawn (iteration t-1, whose slot pointers h->dev still holds): off the critical path
-  hipLaunchKernelGGL(k_lpe, dim3(h->nblkE), dim3(ES_T), 0, h->side2, h->dev, t - 1);
+  hipLaunchKernelGGL(k_lpe, dim3(h->nblkE), dim3(ES_T), 0, h->side2, h->dev, t - 1, lpe_src(h, t - 1));
   hipEventRecord(h->ev_sideP, h->side2);
   hipStreamWaitEvent(h->side, h->ev_draw, 0);
   hipLaunchKernelGGL(k_side, dim3(nbE), dim3(RT), 0, h->side, h->dev, t, nbP, h->cfg.N + nbP, rec_at(h, t, fused_rec(h)), SideDone{h->dFlags, h->dFlags + 1, (unsigned)nbE, t});
@@ -648,7 +653,7 @@ static void launch_side_late(bnmf_handle* h, uint32_t t, Timer& tm) {
   // k_lpp rewrites lpPn slot (t-1) % 3, last read by k_reduce of iteration t-4 (side stream): order behind it
   if (h->red_issued) hipStreamWaitEvent(h->side2, h->ev_red, 0);
   hipLaunchKernelGGL(k_lpp, dim3(h->cfg.N), dim3(64), 0, h->side2, h->dev, t - 1);   // log-prior of the P just drawn
-  hipLaunchKernelGGL(k_lpe, dim3(h->nblkE), dim3(ES_T), 0, h->side2, h->dev, t - 1); // ... and of the E just drawn
+  hipLaunchKernelGGL(k_lpe, dim3(h->nblkE), dim3(ES_T), 0, h->side2, h->dev, t - 1, lpe_src(h, t - 1)); // ... and of the E just drawn
   // Esum last: its flag [3] releases the next iteration's draws, which overwrite the P and E the two kernels above read
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
   hipLaunchKernelGGL(k_side, dim3(h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)h->cfg.N, t});
@@ -889,15 +894,18 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   use_slot(h, t);
   const bool rec = fused_rec(h);
   if (!h->side_valid) launch_side(h, t, tm);               // first sweep after init / set_array
-  // E is double-buffered: this iteration's k_edraw writes the buffer that held E_{t-2}, so the log-prior kernel of
-  // iteration t-1 (k_lpe, side stream, ordered only behind its own inputs) can never see its E overwritten.  Nothing below
-  // reads E_{t-1}: the draws use ZsumK / Psum / Esum, everything after k_edraw works on E_t.
-  if (!h->E_alt) {
-    HIPCHK(hipMalloc(&h->E_alt, (size_t)h->cfg.N * h->cfg.G * sizeof(double)));
-    HIPCHK(hipMemsetAsync(h->E_alt, 0, (size_t)h->cfg.N * h->cfg.G * sizeof(double), h->stream));
+  // The log-prior kernel of iteration t-1 (k_lpe, side stream) is ordered only behind its own inputs, not before this
+  // iteration's k_edraw.  With recording on it reads E_{t-1} from the ring; without a ring E is double-buffered: this k_edraw
+  // writes the buffer that held E_{t-2}.  Nothing below reads E_{t-1}: the draws use ZsumK / Psum / Esum, everything after
+  // k_edraw works on E_t.  (The P side needs nothing: k_lpp precedes Esum, whose flag releases k_pdraw.)
+  if (!lpe_from_ring(h)) {
+    if (!h->E_alt) {
+      HIPCHK(hipMalloc(&h->E_alt, (size_t)h->cfg.N * h->cfg.G * sizeof(double)));
+      HIPCHK(hipMemsetAsync(h->E_alt, 0, (size_t)h->cfg.N * h->cfg.G * sizeof(double), h->stream));
+    }
+    std::swap(h->arr[BNMF_E].d, h->E_alt);
+    h->dev.E = h->arr[BNMF_E].d;
   }
-  std::swap(h->arr[BNMF_E].d, h->E_alt);
-  h->dev.E = h->arr[BNMF_E].d;
   // prior parameters + Esum of iteration t: in the steady state k_pdraw polls the flags their kernels publish (no barrier
   // packet on the main stream); after init / set_array / in profile mode a stream wait
   const bool poll = h->flags_valid && !tm.on;

@@ -278,12 +278,14 @@ __global__ __launch_bounds__(64) void k_lpp(Dev d, uint32_t t) {
   if (lane == 0) d.lpPn[n] = acc;
 }
 // log-prior partials of E_t under iteration t's prior parameters, same 256-element blocks and tree as k_edraw
-__global__ __launch_bounds__(ES_T) void k_lpe(Dev d, uint32_t t) {
+// Esrc: the E of iteration t — its record_sample ring slot when recording is on (not overwritten for a whole window; d.E is
+// overwritten by the next k_edraw, which is not ordered behind this kernel), else d.E (then the host double-buffers E)
+__global__ __launch_bounds__(ES_T) void k_lpe(Dev d, uint32_t t, const double* Esrc) {
   __shared__ double buf[ES_T];
   const int tid = threadIdx.x;
   const long e = (long)blockIdx.x * ES_T + tid;
   double lp = 0.0;
-  if (e < (long)d.lenE) lp = prior_logdens<1>(d, (int)e, d.E[e], t);
+  if (e < (long)d.lenE) lp = prior_logdens<1>(d, (int)e, Esrc[e], t);
   const double r = block_tree<ES_T>(lp, buf, tid);
   if (tid == 0) d.lpE_part[blockIdx.x] = r;
 }
