@@ -19,7 +19,7 @@ t0 = time.time()
 for case in range(n_cases):
     model = rng.choice(["gamma", "exponential", "tn_mh", "exp_mh", "normal_tn", "normal_exp"])
     K = int(rng.choice([3, 12, 31, 64, 65, 96, 97, 128, 130, 200]))
-    G = int(rng.integers(1, 90))
+    G = int(rng.integers(1, int(os.environ.get("FUZZ_GMAX", "90"))))
     N = int(rng.choice([1, 2, 5, 9, 17, 21, 25, 26, 33, 50, 70]))
     lr = bool(rng.random() < 0.4) and N > 1
     window = int(rng.choice([0, 3]))
