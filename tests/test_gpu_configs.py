@@ -307,3 +307,13 @@ def test_abi_error_codes():
     e.run(2)
     assert len(e.window("P", 3)) == 3
     e.close()
+
+
+def test_randomised_parity_sweep():
+    """tools/fuzz_parity.py: 60 random (model, K, G, N, rank learning, window) cases, engine against the oracle, bit-exact
+    (NaN = NaN); tiny shapes, where the asynchronous side-stream work is most likely to be caught out of order."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FUZZ_N="60", FUZZ_SEED="77")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
