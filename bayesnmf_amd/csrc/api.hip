@@ -61,7 +61,7 @@ struct bnmf_handle {
   int wcap = 0;                        // ring capacity = window + 1: the hyper sweep of iteration t+1 is issued (and, in the
                                        // Gibbs sweep, recorded) during iteration t, one slot ahead of the oldest kept sample
   int z_grid = 0, z_zw = 8, z_ablate = 0; bool z_reg = false; size_t z_lds = 0; ZGeom zg{};
-  bool z_tile = false; ZTGeom ztg{}; double* dMhatZ = nullptr;   // k_zalloc_tile (zalloc_tile.h): N > 25 / large K
+  bool z_tile = false, z_lean = false; ZTGeom ztg{}; double* dMhatZ = nullptr;   // k_zalloc_tile (zalloc_tile.h): N > 25 / large K
   hipEvent_t ev[2 * BNMF_NKERNEL]{};
   bool have_ev = false;
   double* dMap = nullptr; size_t map_words = 0;   // scratch of bnmf_map (grown on demand)
@@ -371,9 +371,12 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
       for (int per_cu = 1; per_cu <= 2; ++per_cu)
         for (int w : {8, 6, 4, 2}) {
           const size_t lds = (shw + (size_t)w * tg.slab_words) * 4;
-          // at most 8 waves per CU: the kernel holds ~190 VGPRs (double-buffered LDS reads), i.e. two waves per SIMD
+          // 8 waves per CU: the kernel holds ~190 VGPRs (double-buffered LDS reads), i.e. two waves per SIMD
           if (lds * per_cu <= 160 * 1024 && w * per_cu <= 8 && w * per_cu > ttot) { ttot = w * per_cu; tw = w; tper = per_cu; }
         }
+      // ... or 16 (one workgroup of 1024 lanes) with the register-lean variant, where LDS allows it
+      h->z_lean = false;
+      if ((shw + 16 * (size_t)tg.slab_words) * 4 <= 160 * 1024 && !getenv("BNMF_ZNOLEAN")) { ttot = 16; tw = 16; tper = 1; h->z_lean = true; }
       if (want_tile && ttot >= 2) {
         h->z_tile = true;
         h->z_zw = tw;
@@ -686,9 +689,9 @@ static int launch_zreg_t(bnmf_handle* h, uint32_t t) {
     default: return launch_z(h, t, k_zalloc_reg<SZ, ZT_, 24, DIAG>, za, ZT_);
   }
 }
-template <bool SZ, int ZT_>
+template <bool SZ, int ZT_, bool LEAN_>
 static int launch_ztile(bnmf_handle* h, uint32_t t) {
-  auto kern = k_zalloc_tile<SZ, ZT_>;
+  auto kern = k_zalloc_tile<SZ, ZT_, LEAN_>;
   if (h->z_attr_kernel != (const void*)kern) {
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     h->z_attr_kernel = (const void*)kern;
@@ -709,7 +712,7 @@ static int launch_ztile(bnmf_handle* h, uint32_t t) {
 }
 template <bool SZ, int ZT_>
 static int launch_zalloc_t(bnmf_handle* h, uint32_t t) {
-  if (h->z_tile) return launch_ztile<SZ, ZT_>(h, t);
+  if (h->z_tile) return (h->z_lean && ZT_ == 1024) ? launch_ztile<SZ, ZT_, (ZT_ == 1024)>(h, t) : launch_ztile<SZ, ZT_, false>(h, t);
   if (!h->z_reg) return launch_z(h, t, k_zalloc<SZ, ZT_>, h->dev, ZT_);
   return h->z_ablate ? launch_zreg_t<SZ, ZT_, true>(h, t) : launch_zreg_t<SZ, ZT_, false>(h, t);   // DIAG build honours BNMF_ABLATE
 }

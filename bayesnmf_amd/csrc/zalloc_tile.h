@@ -37,8 +37,10 @@ inline size_t ztile_slab_words(int N, int HW, bool save_Z) {
   return (w + 1) & ~(size_t)1;
 }
 
-template <bool SAVE_Z, int ZT>
-__global__ __launch_bounds__(ZT) void k_zalloc_tile(ZArgs d, double* __restrict__ Mhat, uint32_t t, ZTGeom zg) {
+// LEAN: single-buffered phase 1 and at most 128 VGPRs, for shapes whose LDS need allows 16 waves per CU (N <= ~50):
+// four waves per SIMD hide the latency the double buffering hides at two
+template <bool SAVE_Z, int ZT, bool LEAN = false>
+__global__ __launch_bounds__(ZT, LEAN ? 4 : 2) void k_zalloc_tile(ZArgs d, double* __restrict__ Mhat, uint32_t t, ZTGeom zg) {
   constexpr int ZW = ZT / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -122,12 +124,16 @@ __global__ __launch_bounds__(ZT) void k_zalloc_tile(ZArgs d, double* __restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const double p = pv[j] * av[j]; c_own = c_own + p; nl_own = p > 0.0 ? n0 + j : nl_own; }
       };
-      ld(0, pa, aa);
-      for (int n0 = 0; n0 < N; n0 += 16) {
-        if (n0 + 8 < N) ld(n0 + 8, pb, ab);
-        acc(n0, pa, aa);
-        if (n0 + 16 < N) ld(n0 + 16, pa, aa);
-        if (n0 + 8 < N) acc(n0 + 8, pb, ab);
+      if (LEAN) {
+        for (int n0 = 0; n0 < N; n0 += 8) { ld(n0, pa, aa); acc(n0, pa, aa); }
+      } else {
+        ld(0, pa, aa);
+        for (int n0 = 0; n0 < N; n0 += 16) {
+          if (n0 + 8 < N) ld(n0 + 8, pb, ab);
+          acc(n0, pa, aa);
+          if (n0 + 16 < N) ld(n0 + 16, pa, aa);
+          if (n0 + 8 < N) acc(n0 + 8, pb, ab);
+        }
       }
     }
     if (cellok && (half == 0 || liveB)) Mhat[k0 + cellL + (size_t)K * gmine] = c_own;
@@ -160,12 +166,16 @@ __global__ __launch_bounds__(ZT) void k_zalloc_tile(ZArgs d, double* __restrict_
           if (n < ne) tcol[n * ZTR] = (n >= nl || tt >= 4294967295.0) ? 0xFFFFFFFFu : (uint32_t)tt;
         }
       };
-      ld(0, pa, aa);
-      for (int i0 = 0; i0 < LB; i0 += 16) {
-        if (i0 + 8 < LB) ld(i0 + 8, pb, ab);
-        put(i0, pa, aa);
-        if (i0 + 16 < LB) ld(i0 + 16, pa, aa);
-        if (i0 + 8 < LB) put(i0 + 8, pb, ab);
+      if (LEAN) {
+        for (int i0 = 0; i0 < LB; i0 += 8) { ld(i0, pa, aa); put(i0, pa, aa); }
+      } else {
+        ld(0, pa, aa);
+        for (int i0 = 0; i0 < LB; i0 += 16) {
+          if (i0 + 8 < LB) ld(i0 + 8, pb, ab);
+          put(i0, pa, aa);
+          if (i0 + 16 < LB) ld(i0 + 16, pa, aa);
+          if (i0 + 8 < LB) put(i0 + 8, pb, ab);
+        }
       }
     }
     const int q = (act && half == 0) ? (m + 3) >> 2 : 0;
