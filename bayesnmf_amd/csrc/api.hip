@@ -575,13 +575,14 @@ static void launch_edraw(bnmf_handle* h, uint32_t t, int from_prior, bool rec) {
 }
 // k_side for iteration t (reads P_{t-1}, E_{t-1}): issued on the side stream right after the draws
 // of iteration t-1, so that it overlaps k_zalloc of iteration t-1
-static void issue_reduce(bnmf_handle* h, uint32_t t, int row, Timer& tm) {
+static void issue_reduce(bnmf_handle* h, uint32_t t, int row, Timer& tm, hipStream_t st = nullptr) {
+  if (!st) st = h->side;
   Dev dr = h->dev;
   set_slot(h, dr, t);
-  tm.begin(KN_REDUCE, h->side);
-  hipLaunchKernelGGL(k_reduce, dim3(h->cfg.MH ? 5 : 4), dim3(RT), 0, h->side, dr, row, h->nblkE, (const double*)accPn_slot(h, t), (const double*)accEp_slot(h, t));
-  tm.end(KN_REDUCE, h->side);
-  hipEventRecord(h->ev_red, h->side); h->red_issued = true;
+  tm.begin(KN_REDUCE, st);
+  hipLaunchKernelGGL(k_reduce, dim3(h->cfg.MH ? 5 : 4), dim3(RT), 0, st, dr, row, h->nblkE, (const double*)accPn_slot(h, t), (const double*)accEp_slot(h, t));
+  tm.end(KN_REDUCE, st);
+  hipEventRecord(h->ev_red, st); h->red_issued = true;
 }
 static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm, bool publish = false) {
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
@@ -626,6 +627,10 @@ static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm) {   // ev_draw 
   hipLaunchKernelGGL(k_side, dim3(h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)h->cfg.N, t});
   // log-prior of the E just drawn (iteration t-1, whose slot pointers h->dev still holds): off the critical path
   hipLaunchKernelGGL(k_lpe, dim3(h->nblkE), dim3(ES_T), 0, h->side2, h->dev, t - 1, lpe_src(h, t - 1));
+  // k_reduce of the PREVIOUS iteration here, behind the kernels that produce its inputs on this stream (k_lpp, k_lpe) and
+  // behind ev_draw (k_zalloc of that iteration): on the E part's stream it sat in front of the next E-side sweep, and the
+  // P part waited for its event
+  if (h->red_pending) { issue_reduce(h, h->red_t, h->red_row, tm, h->side2); h->red_pending = false; }
   hipEventRecord(h->ev_sideP, h->side2);
   hipStreamWaitEvent(h->side, h->ev_draw, 0);
   hipLaunchKernelGGL(k_side, dim3(nbE), dim3(RT), 0, h->side, h->dev, t, nbP, h->cfg.N + nbP, rec_at(h, t, fused_rec(h)), SideDone{h->dFlags, h->dFlags + 1, (unsigned)nbE, t});
@@ -635,7 +640,6 @@ static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm) {   // ev_draw 
   hipStreamWaitEvent(h->side, h->ev_sideP, 0);
   hipEventRecord(h->ev_side, h->side);
   h->side_valid = true;
-  if (h->red_pending) { issue_reduce(h, h->red_t, h->red_row, tm); h->red_pending = false; }
 }
 // Rank learning: the hyper sweep of t+1 in two parts.  Early (released by k_edraw): the k_side kernels.  They hold 64+ VGPRs
 // and cannot be scheduled on a CU whose SIMDs carry two waves of the rank sweep (230 VGPRs each): they run on the ~100 CUs
