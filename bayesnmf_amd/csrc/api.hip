@@ -110,6 +110,7 @@ static void refresh_dev(bnmf_handle* h) {
   d.K = c.K; d.G = c.G; d.N = c.N;
   d.prior = c.prior; d.likelihood = c.likelihood; d.MH = c.MH; d.learning_rank = c.learning_rank;
   d.rank_method = c.rank_method; d.save_Z = c.save_Z;
+  d.zsumk_accum = h->z_tile ? 1 : 0;
   d.k0 = (uint32_t)c.seed; d.k1 = (uint32_t)(c.seed >> 32) ^ c.chain_id;
   d.maxM = h->maxM;
   d.M = h->dM; d.Mt = h->dMt; d.Et = h->dEt; d.R = h->dR;
@@ -701,7 +702,6 @@ static int launch_ztile(bnmf_handle* h, uint32_t t) {
     h->z_attr_kernel = (const void*)kern;
   }
   const ZArgs za = zargs(h);
-  hipMemsetAsync(h->dZsumK, 0, (size_t)h->cfg.N * h->cfg.G * sizeof(int32_t), h->stream);   // accumulated across the row chunks
   hipLaunchKernelGGL(kern, dim3(h->z_grid), dim3(ZT_), h->z_lds, h->stream, za, h->dMhatZ, t, h->ztg);
   hipLaunchKernelGGL(k_colmetrics<256>, dim3((h->cfg.G + 3) / 4), dim3(256), 0, h->stream, za, (const double*)h->dMhatZ);
   if (h->ztg.dbg) {                                        // BNMF_ZTDBG: section cycles (100 MHz s_memtime ticks) per launch

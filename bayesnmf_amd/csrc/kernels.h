@@ -21,6 +21,7 @@ BNMF_DEV double hy(const HRef& h, int e) { return h.p[(size_t)e * h.stride]; }
 struct Dev {
   int K, G, N;
   int prior, likelihood, MH, learning_rank, rank_method, save_Z;
+  int zsumk_accum;      // the allocation kernel accumulates ZsumK across row chunks (k_zalloc_tile): k_edraw zeroes what it has consumed
   uint32_t k0, k1;
   int maxM;
   const int32_t* M;
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(ES_T) void k_edraw(Dev d, uint32_t t, int from_prio
     }
     d.E[e] = x;
     if (recE) recE[e] = x;
+    if (d.zsumk_accum) d.ZsumK[e] = 0;               // consumed; k_zalloc_tile accumulates the next one
     if (with_lp) lp = prior_logdens<1>(d, (int)e, x, t);
   }
   if (!with_lp) return;                                 // the log-prior is then computed off the critical path (k_lpe)
