@@ -792,11 +792,11 @@ static RecDst rec_at(const bnmf_handle* h, uint32_t t, bool on) {
   for (int i = 0; i < 4; ++i) r.pp[i] = pp[i] >= 0 ? ring_at(h, pp[i], t) : nullptr;
   return r;
 }
-static int launch_record(bnmf_handle* h, uint32_t t) {
+static int record_args(bnmf_handle* h, uint32_t t, RecArgs& ra) {
+  ra = RecArgs{}; ra.n = 0; ra.R = nullptr; ra.Rdst = nullptr;
   const int W = h->cfg.window;
   if (W <= 0) return 0;
   const size_t slot = (size_t)((t - 1) % (uint32_t)h->wcap);
-  RecArgs ra{}; ra.n = 0; ra.R = nullptr; ra.Rdst = nullptr;
   for (int id : recorded_ids(h)) {
     Arr& a = h->arr[id];
     const size_t len = id_len(h, id);
@@ -808,7 +808,12 @@ static int launch_record(bnmf_handle* h, uint32_t t) {
     ra.len[ra.n] = len;
     ra.n++;
   }
-  hipLaunchKernelGGL(k_record, dim3(512), dim3(256), 0, h->stream, ra);
+  return 0;
+}
+static int launch_record(bnmf_handle* h, uint32_t t) {
+  RecArgs ra;
+  if (int rc = record_args(h, t, ra)) return rc;
+  if (ra.n > 0 || ra.Rdst) hipLaunchKernelGGL(k_record, dim3(512), dim3(256), 0, h->stream, ra);
   return 0;
 }
 // k_reduce of iteration t: on the side stream, after the main stream has finished k_zalloc / metrics of t
@@ -857,7 +862,7 @@ static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged, bool poll = 
   } else
   hipLaunchKernelGGL(k_mh_ecol<false>, dim3(grid), dim3(MHE_T), h->mhe_lds, h->stream, h->dev, t, mhstep, (const int*)(h->dNzE + N), accE, 0);
 }
-static void launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells) {
+static int launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells, bool with_record = false) {   // with_record: record_sample inside k_mh_tail
   const int draw_sig = h->cfg.likelihood == BNMF_NORMAL ? 1 : 0;
   if (draw_sig) cells = true;                 // sigmasq is drawn after R, A (R/sample_params.R:86-88) in the metrics pass
   const int N = h->cfg.N, G = h->cfg.G;
@@ -873,10 +878,14 @@ static void launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells) {
       hipLaunchKernelGGL(k_mh_ecol<true>, dim3(grid), dim3(MHE_T), h->mhe_lds, h->stream, h->dev, t, 0, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
     }
   }
-  // log-priors and acceptance sums, and (for the next iteration's P sweep) Et, nzE, nzP = 0: one launch
-  hipLaunchKernelGGL(k_mh_tail, dim3(2 * N + h->nblkE), dim3(ES_T), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_P].d, accPn_slot(h, t),
-                     (const double*)h->arr[BNMF_ACC_E].d, accEp_slot(h, t), h->dNzE, h->dNzE + N, h->nblkE);
+  // log-priors and acceptance sums, (for the next iteration's P sweep) Et, nzE, nzP = 0, and record_sample: one launch
+  RecArgs ra{};
+  if (with_record) { if (int rc = record_args(h, t, ra)) return rc; }
+  const int nrec = (ra.n > 0 || ra.Rdst) ? 256 : 0;
+  hipLaunchKernelGGL(k_mh_tail, dim3(2 * N + h->nblkE + nrec), dim3(ES_T), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_P].d, accPn_slot(h, t),
+                     (const double*)h->arr[BNMF_ACC_E].d, accEp_slot(h, t), h->dNzE, h->dNzE + N, h->nblkE, ra);
   h->mh_prep_valid = true;
+  return 0;
 }
 static int sweep_mh(bnmf_handle* h, int row, int converged, Timer& tm) {
   h->iter += 1;
@@ -890,8 +899,8 @@ static int sweep_mh(bnmf_handle* h, int row, int converged, Timer& tm) {
   tm.begin(KN_MH, h->stream); launch_mh_PE(h, t, converged, poll); tm.end(KN_MH, h->stream);
   launch_side(h, t + 1, tm, !tm.on);
   if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
-  tm.begin(KN_OTHER, h->stream); launch_mh_metrics(h, t, h->cfg.learning_rank != 0); tm.end(KN_OTHER, h->stream);
-  if (int rc = launch_record(h, t)) return rc;              // after sample_sigmasq, like record_sample (:279) after sample_params (:276)
+  // record_sample rides in k_mh_tail: after sample_sigmasq, like record_sample (:279) after sample_params (:276)
+  tm.begin(KN_OTHER, h->stream); if (int rc = launch_mh_metrics(h, t, h->cfg.learning_rank != 0, true)) return rc; tm.end(KN_OTHER, h->stream);
   launch_reduce(h, t, row, tm);
   return 0;
 }

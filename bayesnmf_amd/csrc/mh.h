@@ -627,7 +627,8 @@ __global__ __launch_bounds__(ES_T) void k_lp_e(Dev d, uint32_t t, const double* 
 //   blocks [N, N + nblkE)         : log-prior / acceptance partial sums of 256 elements of E (k_lp_e)
 //   blocks [N + nblkE, 2N + nblkE): for the NEXT iteration's P sweep: Et = transpose of E, nzE[n] = number of non-zero
 //                                   entries of row n of E (k_mh_nz), and nzP[n] = 0 (k_mh_prow accumulates it)
-__global__ __launch_bounds__(ES_T) void k_mh_tail(Dev d, uint32_t t, const double* accP, double* accPn, const double* accE, double* accE_part, int* nzE, int* nzP, int nblkE) {
+//   blocks [2N + nblkE, ...)      : record_sample of the iteration (k_record's copy into the rings), when ra.n > 0
+__global__ __launch_bounds__(ES_T) void k_mh_tail(Dev d, uint32_t t, const double* accP, double* accPn, const double* accE, double* accE_part, int* nzE, int* nzP, int nblkE, RecArgs ra) {
   __shared__ double buf[ES_T];
   __shared__ int cnt;
   const int tid = threadIdx.x, blk = blockIdx.x;
@@ -653,6 +654,11 @@ __global__ __launch_bounds__(ES_T) void k_mh_tail(Dev d, uint32_t t, const doubl
       const double r2 = block_tree<ES_T>(ac, buf, tid);
       if (tid == 0) accE_part[be] = r2;
     }
+  } else if (blk >= 2 * d.N + nblkE) {
+    const size_t rt = (size_t)(blk - 2 * d.N - nblkE) * ES_T + tid, nth = (size_t)(gridDim.x - 2 * d.N - nblkE) * ES_T;
+    for (int j = 0; j < ra.n; ++j)
+      for (size_t i = rt; i < ra.len[j]; i += nth) ra.dst[j][i] = ra.src[j][i];
+    if (rt == 0 && ra.Rdst) *ra.Rdst = (double)*ra.R;
   } else {
     const int n = blk - d.N - nblkE;
     if (tid == 0) cnt = 0;
