@@ -61,7 +61,7 @@ struct bnmf_handle {
   int wcap = 0;                        // ring capacity = window + 1: the hyper sweep of iteration t+1 is issued (and, in the
                                        // Gibbs sweep, recorded) during iteration t, one slot ahead of the oldest kept sample
   int z_grid = 0, z_zw = 8, z_ablate = 0; bool z_reg = false; size_t z_lds = 0; ZGeom zg{};
-  bool z_tile = false, z_lean = false; ZTGeom ztg{}; double* dMhatZ = nullptr;   // k_zalloc_tile (zalloc_tile.h): N > 25 / large K
+  bool z_tile = false, z_lean = false; ZTGeom ztg{}; double* dMhatZ = nullptr;   // k_zalloc_tile (zalloc_tile.h): N > 24 / large K
   hipEvent_t ev[2 * BNMF_NKERNEL]{};
   bool have_ev = false;
   double* dMap = nullptr; size_t map_words = 0;   // scratch of bnmf_map (grown on demand)
@@ -293,12 +293,12 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   hipLaunchKernelGGL(k_luts, dim3((mx + 256) / 256), dim3(256), 0, h->stream, h->dLut, h->dLut + (mx + 1), mx);
   HIPCHK(hipGetLastError());
   // Allocation-kernel geometry: independent waves, one LDS slab per wave, zacc (and P) shared per workgroup.
-  // N <= 25 takes k_zalloc_reg (zalloc_reg.h), larger N the general LDS-search kernel k_zalloc (kernels.h).
+  // N <= 24 takes k_zalloc_reg (zalloc_reg.h), larger N the general LDS-search kernel k_zalloc (kernels.h).
   {
     ZGeom& zg = h->zg;
     zg.KP = (K % 32 == 0) ? (int)K + 1 : (int)(K | 1);
     zg.HW = (int)((N + 3) / 4);
-    zg.TR = N <= 9 ? 8 : N <= 17 ? 16 : N <= 21 ? 20 : 24;   // threshold registers of the k_zalloc_reg instantiation
+    zg.TR = N <= 8 ? 8 : N <= 16 ? 16 : N <= 20 ? 20 : 24;   // threshold registers of the k_zalloc_reg instantiation
     h->z_reg = N <= (size_t)ZNMAX;
     if (const char* e = getenv("BNMF_ZREG")) h->z_reg = h->z_reg && atoi(e) != 0;   // diagnostics only
     long colmax = 0;
@@ -344,7 +344,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
     geometry(force_chunk && !h->z_reg);
     pick();
     // the register path keeps (K+1) threshold rows per wave and a workgroup copy of P: for large K (e.g. K = 1,536
-    // with N <= 25) that exceeds LDS, so fall back to the general kernel, which can walk the rows in chunks
+    // with N <= 24) that exceeds LDS, so fall back to the general kernel, which can walk the rows in chunks
     if (h->z_reg && best_total < 2) { h->z_reg = false; geometry(force_chunk); pick(); }
     if (!h->z_reg && best_total < 2 && !force_chunk) { geometry(true); pick(); }
     if (const char* e = getenv("BNMF_ZW")) { best_w = atoi(e); best_per_cu = (shared_words + (size_t)best_w * slab) * 4 * 2 <= 160 * 1024 ? 2 : 1; }
@@ -357,7 +357,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
     const long want = ((long)G + best_w - 1) / best_w;
     h->z_grid = (int)(want < resident ? want : resident);
     if (const char* e = getenv("BNMF_ZGRID")) h->z_grid = atoi(e);          // diagnostics only
-    // N > 25 (or K too large for the register kernel): the tile kernel, when at least two waves per CU fit
+    // N > 24 (or K too large for the register kernel): the tile kernel, when at least two waves per CU fit
     if (!h->z_reg) {
       bool want_tile = true;
       if (const char* e = getenv("BNMF_ZTILE")) want_tile = atoi(e) != 0;   // diagnostics / tests: 0 = k_zalloc

@@ -1,4 +1,4 @@
-// bayesnmf_amd/csrc/zalloc_reg.h — k_zalloc_reg: the Z-allocation kernel for N <= 25 (the metric
+// bayesnmf_amd/csrc/zalloc_reg.h — k_zalloc_reg: the Z-allocation kernel for N <= 24 (the metric
 // configuration has N = 20).
 //
 // Same stream spec and bit-identical results as k_zalloc (kernels.h), different machine mapping.
@@ -27,7 +27,7 @@ namespace bnmf {
 #define ZTOC(i)
 #endif
 
-constexpr int ZNMAX = 25;          // max N of the register path (<= 24 thresholds)
+constexpr int ZNMAX = 24;          // max N of the register path (<= 23 thresholds: the last slot of a row stays a pad)
 
 // b_j += (T <= u_j) for four counts at once.  Measured on gfx950 (tools/ubench.hip): the plain C++
 // form (v_cmp -> VCC -> v_addc, with the compiler's hazard nops) issues at ~2.2 cycles per
@@ -93,8 +93,9 @@ constexpr int zreg_row_words(int trc) { return 4 * (zreg_hdr_u4(trc) + trc / 4);
 template <bool SAVE_Z, int ZT, int TRC /* threshold slots: multiple of 4, >= N-1 */, bool DIAG = false /* honour `ablate` */>
 __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(ZArgs d, uint32_t t, ZGeom zg, int ablate) {
   constexpr int ZW = ZT / 64;
-  constexpr int NC = TRC + 1;                            // factors covered by this instantiation
-  constexpr int NMIN = TRC == 8 ? 1 : TRC == 16 ? 10 : TRC - 2;   // smallest N routed here (api.hip: zg.TR)
+  constexpr int NC = TRC;                                // factors covered by this instantiation: at most TRC - 1 thresholds,
+                                                         // so slot TRC - 1 of every row is a pad (2^32 - 1 = "never")
+  constexpr int NMIN = TRC == 8 ? 1 : TRC == 16 ? 9 : TRC - 3;    // smallest N routed here (api.hip: zg.TR)
   constexpr int NB = TRC / 4;                            // threshold blocks per cell
   constexpr int NPV = NB - 1;                            // pivots: last threshold of every block but the last
   constexpr int HB = zreg_hdr_u4(TRC);
@@ -323,13 +324,15 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(ZArgs d, uint32_t t, ZGeom
           uint32_t v0 = u0, v1 = u1, v2 = u2, v3 = u3, i0 = j0, i1 = j1, i2 = j2, i3 = j3, ncell = cell; int nnd = nd;
           if (more) ZQUAD(qi + 1, v0, v1, v2, v3, i0, i1, i2, i3, ncell, nnd);
           __builtin_amdgcn_sched_barrier(0);
-          // (5) four compares per count finish the search of quad qi
+          // (5) three compares per count finish the search of quad qi
           uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
           if (!(DIAG && (ablate & 8))) {
-            b0 = 4 * j0 + (k0.x <= u0) + (k0.y <= u0) + (k0.z <= u0) + (k0.w <= u0);
-            b1 = 4 * j1 + (k1.x <= u1) + (k1.y <= u1) + (k1.z <= u1) + (k1.w <= u1);
-            b2 = 4 * j2 + (k2.x <= u2) + (k2.y <= u2) + (k2.z <= u2) + (k2.w <= u2);
-            b3 = 4 * j3 + (k3.x <= u3) + (k3.y <= u3) + (k3.z <= u3) + (k3.w <= u3);
+            // three, not four: the block's last slot is the pivot that already stopped the count (thresholds ascend,
+            // so pivot j > u for the block j chosen), or, in the last block, the pad
+            b0 = 4 * j0 + (k0.x <= u0) + (k0.y <= u0) + (k0.z <= u0);
+            b1 = 4 * j1 + (k1.x <= u1) + (k1.y <= u1) + (k1.z <= u1);
+            b2 = 4 * j2 + (k2.x <= u2) + (k2.y <= u2) + (k2.z <= u2);
+            b3 = 4 * j3 + (k3.x <= u3) + (k3.y <= u3) + (k3.z <= u3);
           }
           if (DIAG && (ablate & 4)) { if (b0 + b1 + b2 + b3 == 0xFFFFFFF0u) ztarget[cell] = u0; }
           // (6) the link loaded in (2) is committed only here: a copy right behind the load (what the compiler

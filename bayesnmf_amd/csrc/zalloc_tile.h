@@ -1,4 +1,4 @@
-// bayesnmf_amd/csrc/zalloc_tile.h — k_zalloc_tile: the Z-allocation kernel for N > 25 (and for N <= 25 when K is
+// bayesnmf_amd/csrc/zalloc_tile.h — k_zalloc_tile: the Z-allocation kernel for N > 24 (and for N <= 24 when K is
 // too large for the register kernel's per-column list).
 //
 // Same stream spec and bit-identical results as k_zalloc (kernels.h); different machine mapping.  k_zalloc gives a

@@ -159,7 +159,7 @@ def test_config5_full_size_properties():
 
 @pytest.mark.parametrize("K,G,N", [(1536, 12, 5), (700, 9, 20)])
 def test_large_K_small_N_falls_back_to_general_kernel(K, G, N):
-    """N <= 25 normally takes the register kernel, whose per-wave LDS slab grows with K; when it does not fit
+    """N <= 24 normally takes the register kernel, whose per-wave LDS slab grows with K; when it does not fit
     (K = 1,536: SBS-1536 catalogues) create falls back to the general kernel instead of failing.  Bit-exact."""
     import oracle as O
     from bayesnmf_amd import Engine
