@@ -222,7 +222,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   HIPCHK(hipMalloc(&h->dlpE, 3 * (size_t)h->nblkE * sizeof(double)));
   HIPCHK(hipMalloc(&h->dcol, 3 * 3 * G * sizeof(double)));   // per-column partials, 3 slots (t % 3)
   if (cfg->learning_rank) {
-    const size_t gran_words = 2 * 2 * ((G + RK_MAXC - 1) / RK_MAXC);        // [2 parities][2 granules per block sum]
+    const size_t gran_words = 4 * 2 * ((G + RK_MAXC - 1) / RK_MAXC);        // [4 buffers][2 granules per block sum]
     HIPCHK(hipMalloc(&h->dRankCol, gran_words * sizeof(double)));
     HIPCHK(hipMemset(h->dRankCol, 0, gran_words * sizeof(double)));           // tag 0 is never used
     if (((size_t)N + (G + RK_MAXC - 1) / RK_MAXC) * sizeof(double) > 60 * 1024) {
@@ -242,7 +242,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
     // workgroups of each variant fit a CU (registers, LDS); where the answer is SGPR-limited (>= 6 per CU) the query can
     // be one high (MI355X_MICROARCH.md), so one is kept in reserve there; never plan more than two per CU.  Should the
     // grid still not be co-resident, the bounded spins time out and bnmf_run reports it (no hang).
-    const size_t rlds = ((size_t)N + NB + N + 1) * sizeof(double);
+    const size_t rlds = ((size_t)N + NB + N + 1 + N) * sizeof(double);
     auto fit = [&](const void* fn) {
       int nb = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, RK_T, rlds) != hipSuccess || nb < 1) nb = 1;
@@ -736,7 +736,7 @@ static int launch_zalloc(bnmf_handle* h, uint32_t t) {
 static void launch_rank(bnmf_handle* h, uint32_t t, hipEvent_t stop = nullptr, int row = -1) {
   const int N = h->cfg.N;
   const int NB = (h->cfg.G + RK_MAXC - 1) / RK_MAXC;
-  const size_t lds = ((size_t)N + NB + N + 1) * sizeof(double);
+  const size_t lds = ((size_t)N + NB + N + 1 + N) * sizeof(double);   // A, block sums, sample_R weights, sample_An uniforms
   const RecDst rr = row >= 0 ? rec_at(h, t, fused_rec(h)) : RecDst{};
   auto go = [&](auto kern) {
     hipExtLaunchKernelGGL(kern, dim3(h->rank_grid), dim3(RK_T), (uint32_t)lds, h->stream, nullptr, stop, 0, h->dev, t, (unsigned long long*)h->dRankCol, NB, (int*)(h->dRankSync + 4), h->dRankMhat, (unsigned long long*)h->dRankDbg, row, rr.A, rr.R);

@@ -102,24 +102,44 @@ BNMF_DEV void rank_publish(unsigned long long* gran, int b, unsigned tag, double
   __hip_atomic_store(gran + 2 * (size_t)b, ((unsigned long long)tag << 32) | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(gran + 2 * (size_t)b + 1, ((unsigned long long)tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-BNMF_DEV bool rank_gather(const unsigned long long* gran, int NB, unsigned tag, double* vals /* LDS [NB] */, int* err, int tid) {
+// A lane's granules are requested GB blocks at a time (one round trip to the memory side for all of them instead of one per
+// block).  rank_request issues the loads of the lane's first GB blocks; rank_gather takes them (pre != nullptr) or loads them
+// itself, polls every block whose tags do not match yet, and handles the blocks beyond the first GB in the same way.
+constexpr int RK_GB = 3;
+struct RankPre { unsigned long long g0[RK_GB], g1[RK_GB]; };
+BNMF_DEV void rank_request(const unsigned long long* gran, int NB, int tid, RankPre& pre) {
+#pragma unroll
+  for (int i = 0; i < RK_GB; ++i) {
+    const int b = tid + i * RK_T;
+    pre.g0[i] = pre.g1[i] = 0ull;                         // tag 0 is never used: an unrequested block fails the match and is polled
+    if (b < NB) {
+      pre.g0[i] = __hip_atomic_load(gran + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pre.g1[i] = __hip_atomic_load(gran + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+BNMF_DEV bool rank_gather(const unsigned long long* gran, int NB, unsigned tag, double* vals /* LDS [NB] */, int* err, int tid, const RankPre* pre = nullptr) {
   __shared__ int bad_s;
   if (tid == 0) bad_s = 0;
   __syncthreads();
   bool bad = false;
-  for (int b = tid; b < NB; b += RK_T) {
-    unsigned spins = 0;
-    for (;;) {
-      const unsigned long long g0 = __hip_atomic_load(gran + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long g1 = __hip_atomic_load(gran + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag) {
-        vals[b] = __longlong_as_double((long long)((g0 & 0xFFFFFFFFull) | (g1 << 32)));
-        break;
+  for (int b0 = tid; b0 < NB && !bad; b0 += RK_GB * RK_T) {
+    RankPre cur;
+    if (pre && b0 == tid) cur = *pre; else rank_request(gran + 2 * (size_t)(b0 - tid), NB - (b0 - tid), tid, cur);
+#pragma unroll
+    for (int i = 0; i < RK_GB; ++i) {
+      const int b = b0 + i * RK_T;
+      if (b >= NB || bad) continue;
+      unsigned long long h0 = cur.g0[i], h1 = cur.g1[i];
+      unsigned spins = 0;
+      while ((unsigned)(h0 >> 32) != tag || (unsigned)(h1 >> 32) != tag) {
+        if (spins) __builtin_amdgcn_s_sleep(1);
+        if (++spins > RK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { bad = true; break; }
+        h0 = __hip_atomic_load(gran + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        h1 = __hip_atomic_load(gran + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > RK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { bad = true; break; }
+      if (!bad) vals[b] = __longlong_as_double((long long)((h0 & 0xFFFFFFFFull) | (h1 << 32)));
     }
-    if (bad) break;
   }
   if (bad) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bad_s = 1; }
   __syncthreads();
@@ -139,7 +159,7 @@ BNMF_DEV double canon1024_by512(const double* x, long L, double* buf, int tid) {
 }
 // tempered Bernoulli of sample_An :108-166 from the two log-likelihoods (the sweep's constants are hoisted by the caller)
 struct RankConst { double l1mp, lpi, lgG, T; };
-BNMF_DEV double rank_decide(const Dev& d, uint32_t t, int n, double ll0, double ll1, double a_old, double sumA, const RankConst& rc) {
+BNMF_DEV double rank_decide(const Dev& d, double u /* the factor's uniform: block 0 of stream (BNMF_V_A, n, t) */, double ll0, double ll1, double a_old, double sumA, const RankConst& rc) {
   const int K = d.K, G = d.G;
   const double sumA0 = sumA - a_old, sumA1 = sumA0 + 1.0;
   double s0 = ll0, s1 = ll1;
@@ -156,8 +176,7 @@ BNMF_DEV double rank_decide(const Dev& d, uint32_t t, int n, double ll0, double 
     if (lp1 != lp1 && lp0 != lp0) p = 0.5; else if (lp1 != lp1) p = 0.0; else if (lp0 != lp0) p = 1.0;
     else if (lp1 > lp0) p = 1.0; else if (lp1 < lp0) p = 0.0; else p = 0.5;
   }
-  Stream s(d.k0, d.k1, BNMF_V_A, (uint32_t)n, t);
-  return (runif(s) < p) ? 1.0 : 0.0;
+  return (u < p) ? 1.0 : 0.0;
 }
 
 // REG (K <= 96): one block of 8 columns per wave, its cells in registers for the whole sweep: rows 0..63 of every
@@ -172,7 +191,7 @@ BNMF_DEV double down32(double v) {                        // lane l < 32 gets la
   return __longlong_as_double(((long long)b[1] << 32) | (unsigned)a[1]);
 }
 template <bool REG, bool NORMAL>
-__global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsigned long long* granbuf /* [2][2 NB] */, int NB, int* err, double* mhg, unsigned long long* dbg,
+__global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsigned long long* granbuf /* [4][2 NB] */, int NB, int* err, double* mhg, unsigned long long* dbg,
                                                          int row /* metrics row, or -1 */, double* recA, double* recR) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double buf[RK_T];
@@ -184,14 +203,17 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
   // blocks over all CUs (about one busy wave per SIMD instead of two on 60 % of the CUs)
   const int wg = wave * gridDim.x + blockIdx.x, Wt = gridDim.x * RK_W;
   constexpr bool normal = NORMAL;
-  const unsigned tag0 = t * (unsigned)(N + 2);           // tags of this launch: tag0 + phase, unique over the chain
+  // tags of this launch, unique over the chain: tag0 + 1 = log-likelihood of the current state, tag0 + 2 + 2n + redo = the
+  // alternative of factor n (redo = 1: evaluated again after factor n-1 flipped, see the factor loop)
+  const unsigned tag0 = t * (unsigned)(2 * N + 4);
   // the workgroup's own copy of A: every workgroup takes every decision itself, so A is never read across
   // workgroups inside the launch (the global A is written for the kernels that follow)
   double* Ash = (double*)smem;                           // [N]
   double* vals = Ash + N;                                // [NB] gathered block sums
   double* wR = vals + NB;                                // [N+1] weights of sample_R
+  double* uA = wR + (N + 1);                             // [N] the factors' uniforms (sample_An's rbinom), drawn up front by N lanes
   __shared__ int Rsh;
-  for (int j = tid; j < N; j += RK_T) Ash[j] = d.A[j];
+  for (int j = tid; j < N; j += RK_T) { Ash[j] = d.A[j]; Stream sa(d.k0, d.k1, BNMF_V_A, (uint32_t)j, t); uA[j] = runif(sa); }
   __syncthreads();
   // sample_R :217-241 (was a launch of its own): every workgroup draws the same R from the same stream; the N+1 weights
   // are evaluated one per lane of wave 0, then added and scanned in r order by its lane 0
@@ -225,8 +247,8 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
   const int half = lane >> 5, row1 = 64 + (lane & 31);    // slot 1: this lane's column of the pair and its row
   const bool lowv1 = lane < 32 && 64 + lane < K;          // lanes that own an accumulator with a second row
   // ---- phase 0: fresh Mhat and the log-likelihood of the current state
-  unsigned long long* gran = granbuf;
-  unsigned phase = 1;
+  unsigned long long* gran = granbuf;                    // buffer 0 of 4
+  const unsigned phase = 1;
   if (REG) {
     double accv[RK_MAXC];
     auto fresh = [&](int kk, int g, double sg, double& mhv, int& mv, double& lgv) {   // Mhat, M, lgamma(M+1) and the cell's term
@@ -288,17 +310,17 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
       if (lane == 0) rank_publish(gran, b, tag0 + phase, bs);
     }
   }
-  if (!rank_gather(gran, NB, tag0 + phase, vals, err, tid)) return;
-  double ll_cur = canon1024_by512(vals, NB, buf, tid);  // valid on thread 0, which carries it
-  RankConst rc{};
-  double sumA = 0.0;
-  if (tid == 0) {
-    const double pi1 = prior_prob_1((double)Rsh, (double)N);   // written by this thread (wave 0, lane 0) above
-    rc.l1mp = dlog(1.0 - pi1); rc.lpi = dlog(pi1); rc.lgG = dlog((double)G); rc.T = temp_at(d, t);
-    for (int j = 0; j < N; ++j) sumA = sumA + Ash[j];
-  }
-  // ---- factors in order.  REG: column n of P and row n of E (this wave's 8 columns) are requested one factor ahead,
-  // so that their L2 latency is not at the head of every factor's critical path
+  // ---- factors in order, one step ahead of the decisions.  The alternative log-likelihood of factor n+1 depends on the
+  // decision for factor n only through Mhat, and most decisions leave A[n] as it was.  So a workgroup evaluates and publishes
+  // the alternative of factor n+1 BEFORE it gathers the block sums of factor n: by the time it has finished, every other
+  // workgroup's sums of factor n (published one step earlier) have arrived, and the gather is a read instead of a wait for the
+  // slowest publisher.  When factor n does flip, Mhat is updated and the alternative of n+1 is evaluated and published again
+  // under the `redo` tag; every workgroup takes the same decision, so all of them know which tag to gather.  Same values,
+  // same order of operations, same draws as the one-factor-at-a-time sweep.
+  // Four granule buffers: a workgroup in step n writes buffer (n+2)&3 while the slowest one may still read (n-1)&3 .. (n+1)&3.
+  auto gbuf = [&](int n) { return granbuf + (size_t)((n + 1) & 3) * 2 * NB; };
+  auto tagof = [&](int n, unsigned redo) { return tag0 + 2u + 2u * (unsigned)n + redo; };
+  // REG: column n of P and row n of E (this wave's 8 columns) are requested one factor ahead of their use
   double np0 = 0.0, np1 = 0.0, nen[REG ? RK_MAXC : 1];
   auto prefetch = [&](int n) {
     const double* Pq = d.P + (size_t)K * n;
@@ -306,18 +328,19 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
 #pragma unroll
     for (int c = 0; c < (REG ? RK_MAXC : 1); ++c) { const int g = wg * RK_MAXC + c; nen[c] = g < G ? d.E[n + (size_t)N * g] : 0.0; }
   };
-  if (REG) prefetch(0);
-  for (int n = 0; n < N; ++n) {
-    const double a_old = Ash[n];
-    gran = granbuf + (size_t)((n + 1) & 1) * 2 * NB;
-    ++phase;
-    const double* Pn = d.P + (size_t)K * n;
-    double p0 = 0.0, p1 = 0.0, en_[REG ? RK_MAXC : 1];
-    if (REG) {
-      p0 = np0; p1 = np1;
+  double p0 = 0.0, p1 = 0.0, en_[REG ? RK_MAXC : 1];      // REG: the factor whose alternative is evaluated next
+  auto take_prefetched = [&](int n_next) {                 // current <- prefetched, request factor n_next
+    p0 = np0; p1 = np1;
 #pragma unroll
-      for (int c = 0; c < RK_MAXC; ++c) en_[c] = nen[c];
-      if (n + 1 < N) prefetch(n + 1);
+    for (int c = 0; c < (REG ? RK_MAXC : 1); ++c) en_[c] = nen[c];
+    if (n_next < N) prefetch(n_next);
+  };
+  // evaluate the alternative of factor f (A[f] flipped) on the current Mhat and publish this wave's block sums
+  auto publish_alt = [&](int f, unsigned redo) {
+    const double a_f = Ash[f];
+    unsigned long long* gr = gbuf(f);
+    const unsigned tg = tagof(f, redo);
+    if (REG) {
       // straight-line code: the 16 cell terms and then the 8 column trees are independent chains the scheduler can
       // interleave (per-column / per-cell branches kept them apart: 5.3 us of pure latency per factor); cells beyond K and
       // columns beyond G hold harmless values and are never added
@@ -325,14 +348,14 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
 #pragma unroll
       for (int c = 0; c < RK_MAXC; ++c) {                 // slot 0
         const double tt = p0 * en_[c];
-        const double alt = (a_old == 1.0) ? mh0[c] - tt : mh0[c] + tt;
+        const double alt = (a_f == 1.0) ? mh0[c] - tt : mh0[c] + tt;
         const double ll = rank_cell_ll_t<NORMAL>(mm0[c], alt, NORMAL ? sgc[NORMAL ? c : 0] : 1.0, NORMAL ? 0.0 : lg0[NORMAL ? 0 : c]);
         accv[c] = (lane < K) ? 0.0 + ll : 0.0;
       }
 #pragma unroll
       for (int p = 0; p < RK_P; ++p) {                    // slot 1: two columns per register
         const double tt = p1 * (half ? en_[2 * p + 1] : en_[2 * p]);
-        const double alt = (a_old == 1.0) ? mh1[p] - tt : mh1[p] + tt;
+        const double alt = (a_f == 1.0) ? mh1[p] - tt : mh1[p] + tt;
         const double sg = NORMAL ? (half ? sgc[NORMAL ? 2 * p + 1 : 0] : sgc[NORMAL ? 2 * p : 0]) : 1.0;
         const double v = rank_cell_ll_t<NORMAL>(mm1[p], alt, sg, NORMAL ? 0.0 : lg1[NORMAL ? 0 : p]);
         const double w = down32(v);
@@ -344,64 +367,102 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
       double bs = 0.0;
 #pragma unroll
       for (int c = 0; c < RK_MAXC; ++c) bs = (wg * RK_MAXC + c < G) ? bs + accv[c] : bs;   // lane 0: block sum, columns in ascending order
-      if (lane == 0 && wg < NB) rank_publish(gran, wg, tag0 + phase, bs);
+      if (lane == 0 && wg < NB) rank_publish(gr, wg, tg, bs);
     } else {
+      const double* Pf = d.P + (size_t)K * f;
       for (int b = wg; b < NB; b += Wt) {
         double bs = 0.0;
         for (int c = 0; c < RK_MAXC; ++c) {
           const int g = b * RK_MAXC + c;
           if (g >= G) break;
           const double sg = normal ? d.sigmasq[g] : 1.0;
-          const double en = d.E[n + (size_t)N * g];
+          const double en = d.E[f + (size_t)N * g];
           double acc = 0.0;
           for (int r = 0; r < KR; ++r) {
             const int kk = (r << 6) + lane;
             if (kk < K) {
-              const double tt = Pn[kk] * en;
+              const double tt = Pf[kk] * en;
               const double cur = mhg[kk + (size_t)K * g];
-              const double alt = (a_old == 1.0) ? cur - tt : cur + tt;
+              const double alt = (a_f == 1.0) ? cur - tt : cur + tt;
               const int m = d.M[kk + (size_t)K * g];
               acc = acc + rank_cell_ll(d, m, alt, sg, rank_lgf(d, m));
             }
           }
           bs = bs + wave_tree64(acc);
         }
-        if (lane == 0) rank_publish(gran, b, tag0 + phase, bs);
+        if (lane == 0) rank_publish(gr, b, tg, bs);
       }
     }
+  };
+  // Mhat <- Mhat -/+ the term of factor f (its A flipped from a_was): the same operations as the alternative just evaluated
+  auto flip_mhat = [&](int f, double a_was) {
+    const double* Pf = d.P + (size_t)K * f;
+    if (REG) {
+      const double q0 = lane < K ? Pf[lane] : 0.0, q1 = row1 < K ? Pf[row1] : 0.0;
+#pragma unroll
+      for (int c = 0; c < RK_MAXC; ++c) {
+        const int g = wg * RK_MAXC + c;
+        const double tt = q0 * (g < G ? d.E[f + (size_t)N * g] : 0.0);
+        mh0[c] = (a_was == 1.0) ? mh0[c] - tt : mh0[c] + tt;
+      }
+#pragma unroll
+      for (int p = 0; p < RK_P; ++p) {
+        const int g = wg * RK_MAXC + 2 * p + half;
+        const double tt = q1 * (g < G ? d.E[f + (size_t)N * g] : 0.0);
+        mh1[p] = (a_was == 1.0) ? mh1[p] - tt : mh1[p] + tt;
+      }
+    } else {
+      for (int b = wg; b < NB; b += Wt)
+        for (int c = 0; c < RK_MAXC; ++c) {
+          const int g = b * RK_MAXC + c;
+          if (g >= G) break;
+          const double en = d.E[f + (size_t)N * g];
+          for (int r = 0; r < KR; ++r) {
+            const int kk = (r << 6) + lane;
+            if (kk < K) { const double tt = Pf[kk] * en; const double cur = mhg[kk + (size_t)K * g]; mhg[kk + (size_t)K * g] = (a_was == 1.0) ? cur - tt : cur + tt; }
+          }
+        }
+    }
+  };
+  if (REG) { prefetch(0); take_prefetched(1); }
+  publish_alt(0, 0u);                                      // alternative of factor 0: needs no decision
+  if (!rank_gather(gran, NB, tag0 + phase, vals, err, tid)) return;
+  double ll_cur = canon1024_by512(vals, NB, buf, tid);  // valid on thread 0, which carries it
+  RankConst rc{};
+  double sumA = 0.0;
+  if (tid == 0) {
+    const double pi1 = prior_prob_1((double)Rsh, (double)N);   // written by this thread (wave 0, lane 0) above
+    rc.l1mp = dlog(1.0 - pi1); rc.lpi = dlog(pi1); rc.lgG = dlog((double)G); rc.T = temp_at(d, t);
+    for (int j = 0; j < N; ++j) sumA = sumA + Ash[j];
+  }
+  unsigned redo = 0;                                       // which publication of factor n's alternative is the valid one
+  for (int n = 0; n < N; ++n) {
+    const double a_old = Ash[n];
 #define RKSTAMP(i) if (dbg && tid == 0 && n < 16) dbg[(blockIdx.x * 16 + n) * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
     RKSTAMP(0);
-    if (!rank_gather(gran, NB, tag0 + phase, vals, err, tid)) return;
+    RankPre pre;                                           // factor n's sums were published a step ago: their loads fly under the
+    rank_request(gbuf(n), NB, tid, pre);                   // evaluation below (after a flip they are not there yet and are polled)
+    if (n + 1 < N) {                                       // one step ahead: factor n+1 on the Mhat as it is
+      if (REG) take_prefetched(n + 2);
+      publish_alt(n + 1, 0u);
+    }
     RKSTAMP(1);
-    const double ll_alt = canon1024_by512(vals, NB, buf, tid);
+    if (!rank_gather(gbuf(n), NB, tagof(n, redo), vals, err, tid, &pre)) return;
     RKSTAMP(2);
+    const double ll_alt = canon1024_by512(vals, NB, buf, tid);
     if (tid == 0) {
       const double ll0 = (a_old == 1.0) ? ll_alt : ll_cur, ll1 = (a_old == 1.0) ? ll_cur : ll_alt;
-      const double a_new = rank_decide(d, t, n, ll0, ll1, a_old, sumA, rc);
+      const double a_new = rank_decide(d, uA[n], ll0, ll1, a_old, sumA, rc);
       if (a_new != a_old) { ll_cur = ll_alt; sumA = (sumA - a_old) + a_new; }
       bc[0] = a_new;
     }
     RKSTAMP(3);
     __syncthreads();
     const double a_new = bc[0];
-    if (a_new != a_old) {
-      if (REG) {
-#pragma unroll
-        for (int c = 0; c < RK_MAXC; ++c) { const double tt = p0 * en_[c]; mh0[c] = (a_old == 1.0) ? mh0[c] - tt : mh0[c] + tt; }
-#pragma unroll
-        for (int p = 0; p < RK_P; ++p) { const double tt = p1 * (half ? en_[2 * p + 1] : en_[2 * p]); mh1[p] = (a_old == 1.0) ? mh1[p] - tt : mh1[p] + tt; }
-      } else {
-        for (int b = wg; b < NB; b += Wt)
-          for (int c = 0; c < RK_MAXC; ++c) {
-            const int g = b * RK_MAXC + c;
-            if (g >= G) break;
-            const double en = d.E[n + (size_t)N * g];
-            for (int r = 0; r < KR; ++r) {
-              const int kk = (r << 6) + lane;
-              if (kk < K) { const double tt = Pn[kk] * en; const double cur = mhg[kk + (size_t)K * g]; mhg[kk + (size_t)K * g] = (a_old == 1.0) ? cur - tt : cur + tt; }
-            }
-          }
-      }
+    redo = 0;
+    if (a_new != a_old) {                                  // the step ahead was taken on a stale Mhat: again
+      flip_mhat(n, a_old);                                 // (general variant: a lane re-reads only the Mhat cells it wrote itself)
+      if (n + 1 < N) { publish_alt(n + 1, 1u); redo = 1; }
     }
     if (tid == 0) { Ash[n] = a_new; if (blockIdx.x == 0) d.A[n] = a_new; }
     __syncthreads();
