@@ -74,6 +74,33 @@ def test_rank_sweep_general_path_bitexact(K, G, N, lik, prior, MH):
     e.close()
 
 
+@pytest.mark.parametrize("K,G,N", [(8, 13000, 4), (100, 12500, 3)])
+def test_rank_sweep_wide_G_bitexact(K, G, N):
+    """More than 3 x 512 column blocks (G > 12,288): a lane of the rank sweep then gathers its block sums in more than one
+    batch, and the sums of factor n+1 are published a step ahead of the decision for factor n (again after a flip).
+    K = 8: register-resident variant; K = 100: Mhat in global scratch."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    rng = np.random.default_rng(K + G)
+    M = rng.poisson(rng.gamma(1.0, 6.0, size=(K, G))).astype(np.int32)
+    kw = dict(learning_rank=True, seed=23, temperature=_temp_schedule(40))
+    o = _mk(O.Oracle, M, N, "gamma", nthreads=8, **kw)
+    e = _mk(Engine, M, N, "gamma", **kw)
+    o.init(); e.init()
+    flips = 0
+    prev = o.get("A").copy()
+    for step in range(12):
+        n_it = 1 if step < 8 else 4                               # single iterations while the temperature is ~0 (A flips freely)
+        mo, me = o.run(n_it), e.run(n_it)
+        assert np.array_equal(o.get("A"), e.get("A")), step
+        flips += int((o.get("A") != prev).sum()); prev = o.get("A").copy()
+        for nm in ("P", "E"):
+            assert np.array_equal(o.get(nm).view(np.uint64), e.get(nm).view(np.uint64)), (nm, step)
+        assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), step
+    assert flips > 0, "no factor ever flipped: the redo path was not exercised"
+    e.close()
+
+
 def test_config4_full_size_properties():
     """Config 4 at full size (K = 96, G = 10,000, N = 50, SBFI): sum_n Z = M for every cell, Z = 0 wherever
     A[n] = 0, marginals consistent."""
