@@ -167,19 +167,18 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(ZArgs d, uint32_t t, ZGeom
       int q = 0, m = 0;
       double c = 0.0;
       const double* Pk = Pl + min(kk, K - 1);             // P[kk, n] = Pl[kk + K n] (workgroup copy in LDS)
+      // the row of P: requested in one go (one LDS round trip under the other waves' quad-loop traffic instead of one per group
+      // of four) and kept for the threshold pass below
+      double pk[NC];
+#pragma unroll
+      for (int n = 0; n < NC; ++n) pk[n] = (n < NMIN || n < N) ? Pk[(size_t)K * n] : 0.0;
       if (kk < K) {
         m = r == 0 ? mc0 : r == 1 ? mc1 : d.M[kk + (size_t)K * g];
         const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
         const double lgf = d.lgfact[mi], lgm = d.logm[mi];   // requested now, used after the factor loop
-        // Mhat = sum_n P[k,n] (A[n] E[n,g]) in factor order; LDS reads issued four at a time
+        // Mhat = sum_n P[k,n] (A[n] E[n,g]) in factor order
 #pragma unroll
-        for (int n0 = 0; n0 < NC; n0 += 4) {
-          double pk[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { const int n = n0 + i; pk[i] = (n < NC && (n < NMIN || n < N)) ? Pk[(size_t)K * n] : 0.0; }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { const int n = n0 + i; if (n < NC && (n < NMIN || n < N)) c = c + pk[i] * ae[n]; }
-        }
+        for (int n = 0; n < NC; ++n) if (n < NMIN || n < N) c = c + pk[n] * ae[n];
         if (c > 0.0 && m > 0) q = (m + 3) >> 2;
         const double dd = c - (double)m;
         const double mh = c < 1e-6 ? 1e-6 : c;
@@ -203,15 +202,12 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(ZArgs d, uint32_t t, ZGeom
         double c2 = 0.0;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-          double pk[4];
           uint32_t tv[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { const int n = 4 * j + i; pk[i] = (n < NMIN - 1 || n < nthr) ? Pk[(size_t)K * n] : 0.0; }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int n = 4 * j + i;
             tv[i] = 0xFFFFFFFFu;
-            if (n < NMIN - 1 || n < nthr) { c2 = c2 + pk[i] * ae[n]; tv[i] = cvt_u32_sat(c2 * scale); }
+            if (n < NC && (n < NMIN - 1 || n < nthr)) { c2 = c2 + pk[n < NC ? n : 0] * ae[n]; tv[i] = cvt_u32_sat(c2 * scale); }
           }
           row[HB + j] = u4{tv[0], tv[1], tv[2], tv[3]};
           pvt[j] = tv[3];
