@@ -1,4 +1,4 @@
-"""Run a few iterations of one BASELINE.json configuration (for rocprofv3 --kernel-trace --stats).  CFG=3|3c|4|5|m"""
+"""Run a few iterations of one BASELINE.json configuration (for rocprofv3 --kernel-trace --stats).  CFG=2|3|3c|4|5|m"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,6 +12,8 @@ elif cfg == "4":
     M, _, _ = synth_counts(96, 10000, 12, 20250222); N, prior, kw = 50, "gamma", dict(learning_rank=True, temperature=np.ones(8000))
 elif cfg == "5":
     M, _, _ = synth_counts(1536, int(os.environ.get("G5", "5000")), 30, 20250223); N, prior, kw = 100, "gamma", dict()
+elif cfg == "2":
+    M, _, _ = synth_counts(96, 2000, 8, 20250218); N, prior, kw = 20, "gamma", dict()
 else:
     M, _, _ = synth_counts(96, 10000, 8, 20250218); N, prior, kw = 20, "gamma", dict()
 e = Engine(M, N, prior=prior, seed=1, window=int(os.environ.get("WINDOW", "100")), **kw)
