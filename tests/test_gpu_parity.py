@@ -260,12 +260,42 @@ def test_ragged_and_edge_shapes():
         assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), (K, G, N)
 
 
+@pytest.mark.parametrize("N", [1, 2, 8, 9, 16, 17, 20, 21, 24, 25])
+def test_register_kernel_threshold_row_boundaries(N):
+    """k_zalloc_reg is instantiated for 8 / 16 / 20 / 24 threshold slots per cell (N <= 8 / 16 / 20 / 24); the last slot of a
+    row is always a pad, which is what lets the in-block search stop at three compares.  Every boundary N, the first N of the
+    next instantiation, and N = 25 (the first N of the tile kernel), bit-exact against the oracle, with and without Z."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import apply_hyperprior_params
+    K, G = 96, 40
+    rng = np.random.default_rng(100 + N)
+    M = rng.poisson(rng.gamma(0.6, 30.0, size=(K, G))).astype(np.int32)
+    M[:, 3] = 0
+    M[7, :] = 0
+    for save_Z in (False, True):
+        o = O.Oracle(M, N, prior="gamma", seed=4, save_Z=True, nthreads=4)
+        e = Engine(M, N, prior="gamma", seed=4, save_Z=save_Z)
+        apply_hyperprior_params(o, "gamma", M, N)
+        apply_hyperprior_params(e, "gamma", M, N)
+        o.init(); e.init()
+        mo, me = o.run(5), e.run(5)
+        if save_Z:
+            assert np.array_equal(o.get("Z").astype(np.int32), e.get("Z")), N
+        assert np.array_equal(o.get("ZsumK").astype(np.int32), e.get("ZsumK")), N
+        assert np.array_equal(o.get("ZsumG").astype(np.int32), e.get("ZsumG")), N
+        for nm in ("P", "E"):
+            assert np.array_equal(o.get(nm).view(np.uint64), e.get(nm).view(np.uint64)), (nm, N)
+        assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), N
+        e.close()
+
+
 @pytest.mark.parametrize("kernel", ["tile", "wave"])
 @pytest.mark.parametrize("shape,force", [((200, 9, 30), True), ((33, 17, 26), True), ((130, 12, 40), True),
                                          ((1536, 12, 100), False), ((96, 300, 50), False), ((70, 40, 128), False),
                                          ((45, 23, 140), False)])
 def test_general_allocation_kernels(shape, force, kernel, monkeypatch):
-    """N > 25 (BASELINE configs 4 and 5: N = 50, K = 96; N = 100, K = 1,536).  "tile": k_zalloc_tile, the default
+    """N > 24 (BASELINE configs 4 and 5: N = 50, K = 96; N = 100, K = 1,536).  "tile": k_zalloc_tile, the default
     (workgroup per 32-row chunk, P chunk in LDS, ZsumK accumulated across the chunks, metrics from the Mhat it writes).
     "wave": k_zalloc (BNMF_ZTILE=0), one wave per column; where the column's thresholds do not fit one wave's LDS slab
     it walks the rows in chunks of 64 and keeps ZsumG in global memory (forced on small shapes with BNMF_ZCHUNK=1, taken
