@@ -5,6 +5,7 @@
 #include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
@@ -30,7 +31,9 @@ __global__ void k_busy(Stamp* st, unsigned long long ticks, unsigned* counter, u
 }
 
 int main(int argc, char** argv) {
-  const int iters = 60, nA = 782, nB = 256, nC = 782;
+  const int iters = 60, nB = 256, nC = 782;
+  const int nA = argc > 1 ? atoi(argv[1]) : 782, tA = argc > 2 ? atoi(argv[2]) : 256;   // producer grid: workgroups x lanes
+  printf("producer kernel: %d workgroups x %d lanes\n", nA, tA);
   int can = 0;
   CHK(hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, 0));
   printf("hipDeviceAttributeCanUseStreamWaitValue = %d\n", can);
@@ -50,11 +53,11 @@ int main(int argc, char** argv) {
       const unsigned epoch = (unsigned)(mode * 1000 + i + 1);
       Stamp *sa = st + 3 * i, *sb = sa + 1, *sc = sa + 2;
       if (mode == 0) {        // events
-        hipExtLaunchKernelGGL(k_busy, dim3(nA), dim3(256), 0, mainS, nullptr, ev, 0, sa, 1000ull, counter, (unsigned*)nullptr, epoch);
+        hipExtLaunchKernelGGL(k_busy, dim3(nA), dim3(tA), 0, mainS, nullptr, ev, 0, sa, 1000ull, counter, (unsigned*)nullptr, epoch);
         CHK(hipStreamWaitEvent(side, ev, 0));
       } else {                // flag in signal memory (1), or in plain device memory (2)
         unsigned* f = mode == 1 ? sig : counter + 8;
-        hipLaunchKernelGGL(k_busy, dim3(nA), dim3(256), 0, mainS, sa, 1000ull, counter, f, epoch);
+        hipLaunchKernelGGL(k_busy, dim3(nA), dim3(tA), 0, mainS, sa, 1000ull, counter, f, epoch);
         CHK(hipStreamWaitValue32(side, f, epoch, hipStreamWaitValueGte, 0xFFFFFFFFu));
       }
       hipLaunchKernelGGL(k_busy, dim3(nC), dim3(256), 0, side, sc, 3000ull, counter + 4, (unsigned*)nullptr, epoch);
