@@ -617,17 +617,19 @@ static void launch_side_P(bnmf_handle* h, uint32_t t, hipEvent_t after = nullptr
   hipStreamWaitEvent(h->side2, after ? after : h->ev_p, 0);
   // k_lpp below rewrites lpPn slot (t-1) % 3, last read by k_reduce of iteration t-4 (side stream): order behind it
   if (h->red_issued) hipStreamWaitEvent(h->side2, h->ev_red, 0);
-  hipLaunchKernelGGL(k_side, dim3(nbP), dim3(RT), 0, h->side2, h->dev, t, nbP, h->cfg.N, rec_at(h, t, fused_rec(h)), SideDone{});
-  hipLaunchKernelGGL(k_lpp, dim3(h->cfg.N), dim3(64), 0, h->side2, h->dev, t - 1);   // log-prior of the P just drawn
+  // ... and the log-prior of the P just drawn (k_lpp's work, iteration t-1) in the same launch
+  hipLaunchKernelGGL(k_side_lp, dim3(nbP + h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, h->cfg.N, rec_at(h, t, fused_rec(h)), SideDone{},
+                     SideExtra{nbP, h->cfg.N, 0, t - 1, nullptr});
 }
 static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm) {   // ev_draw = completion of k_edraw(t-1)
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
   const int nbE = (int)(((size_t)h->cfg.N * h->cfg.G + RT - 1) / RT);
   hipStreamWaitEvent(h->side2, h->ev_draw, 0);
   // Esum closes the side2 work the next k_pdraw needs (the P part ran before it on the same stream): it publishes flag [3]
-  hipLaunchKernelGGL(k_side, dim3(h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)h->cfg.N, t});
-  // log-prior of the E just drawn (iteration t-1, whose slot pointers h->dev still holds): off the critical path
-  hipLaunchKernelGGL(k_lpe, dim3(h->nblkE), dim3(ES_T), 0, h->side2, h->dev, t - 1, lpe_src(h, t - 1));
+  // ... and, in the same launch, the log-prior of the E just drawn (k_lpe's work; iteration t-1, whose slot pointers h->dev
+  // still holds): off the critical path
+  hipLaunchKernelGGL(k_side_lp, dim3(h->cfg.N + h->nblkE), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)h->cfg.N, t},
+                     SideExtra{h->cfg.N, 0, h->nblkE, t - 1, lpe_src(h, t - 1)});
   // k_reduce of the PREVIOUS iteration here, behind the kernels that produce its inputs on this stream (k_lpp, k_lpe) and
   // behind ev_draw (k_zalloc of that iteration): on the E part's stream it sat in front of the next E-side sweep, and the
   // P part waited for its event

@@ -175,13 +175,11 @@ BNMF_DEV double canon1024_by256(const double* x, long L, long stride, double* bu
 //   blocks [0, N)            : Esum[n] = canonical sum_g E[n,g]   (rate of P's Gamma, R/sample_Pn.R:103-106)
 //   blocks [N, N+nbP)        : hyper sweep of the P-side prior parameters (R/sample_priors.R:150-200)
 //   blocks [N+nbP, ...)      : hyper sweep of the E-side prior parameters
-__global__ __launch_bounds__(RT, 4) void k_side(Dev d, uint32_t t, int nbP, int blk0, RecDst rec, SideDone sd) {
-  __shared__ double buf[RT];
-  const int tid = threadIdx.x, blk = blockIdx.x + blk0;   // one launch (blk0 = 0) or one launch per part
+BNMF_DEV void side_body(const Dev& d, uint32_t t, int nbP, int blk, int nblocks, const RecDst& rec, const SideDone& sd, double* buf, int tid) {
   // The small launches (P part, Esum: a few dozen workgroups) share the CUs with k_zalloc, whose older waves win the
   // instruction arbitration: without a raised priority these few young waves starve (Esum took 56 us for a 10,000-term
   // reduction) although the event the next k_pdraw waits for hangs on them.  Too few waves to slow k_zalloc down.
-  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);
+  if (nblocks <= 64) __builtin_amdgcn_s_setprio(3);
   if (blk < d.N) {
     const double r = canon1024_by256(d.E + blk, d.G, d.N, buf, tid);
     if (tid == 0) st_wt(&d.Esum[blk], r);
@@ -193,6 +191,10 @@ __global__ __launch_bounds__(RT, 4) void k_side(Dev d, uint32_t t, int nbP, int 
     if (e < (long)d.lenE) hyper_elem<1>(d, (int)e, t, d.E[e], rec.pp[2], rec.pp[3]);
   }
   side_done(sd, tid);
+}
+__global__ __launch_bounds__(RT, 4) void k_side(Dev d, uint32_t t, int nbP, int blk0, RecDst rec, SideDone sd) {
+  __shared__ double buf[RT];
+  side_body(d, t, nbP, blockIdx.x + blk0, gridDim.x, rec, sd, buf, threadIdx.x);   // one launch (blk0 = 0) or one launch per part
 }
 
 // ---- k_pdraw: one workgroup of 128 lanes per factor n ----
@@ -271,25 +273,41 @@ __global__ __launch_bounds__(ES_T) void k_edraw(Dev d, uint32_t t, int from_prio
 }
 
 // log-prior of column n of P_t under iteration t's prior parameters: canonical W = 64 over k, as in k_pdraw
-__global__ __launch_bounds__(64) void k_lpp(Dev d, uint32_t t) {
+BNMF_DEV void lpp_body(const Dev& d, uint32_t t, int n, int lane) {
   __builtin_amdgcn_s_setprio(3);                        // N one-wave workgroups beside k_zalloc (see k_side)
-  const int n = blockIdx.x, lane = threadIdx.x, K = d.K;
+  const int K = d.K;
   double acc = 0.0;
   for (int k = lane; k < K; k += 64) { const int e = k + K * n; acc = acc + prior_logdens<0>(d, e, d.P[e], t); }
   acc = wave_tree64(acc);
   if (lane == 0) d.lpPn[n] = acc;
 }
+__global__ __launch_bounds__(64) void k_lpp(Dev d, uint32_t t) { lpp_body(d, t, blockIdx.x, threadIdx.x); }
 // log-prior partials of E_t under iteration t's prior parameters, same 256-element blocks and tree as k_edraw
 // Esrc: the E of iteration t — its record_sample ring slot when recording is on (not overwritten for a whole window; d.E is
 // overwritten by the next k_edraw, which is not ordered behind this kernel), else d.E (then the host double-buffers E)
-__global__ __launch_bounds__(ES_T) void k_lpe(Dev d, uint32_t t, const double* Esrc) {
-  __shared__ double buf[ES_T];
-  const int tid = threadIdx.x;
-  const long e = (long)blockIdx.x * ES_T + tid;
+BNMF_DEV void lpe_body(const Dev& d, uint32_t t, int blk, const double* Esrc, double* buf, int tid) {
+  const long e = (long)blk * ES_T + tid;
   double lp = 0.0;
   if (e < (long)d.lenE) lp = prior_logdens<1>(d, (int)e, Esrc[e], t);
   const double r = block_tree<ES_T>(lp, buf, tid);
-  if (tid == 0) d.lpE_part[blockIdx.x] = r;
+  if (tid == 0) d.lpE_part[blk] = r;
+}
+__global__ __launch_bounds__(ES_T) void k_lpe(Dev d, uint32_t t, const double* Esrc) {
+  __shared__ double buf[ES_T];
+  lpe_body(d, t, blockIdx.x, Esrc, buf, threadIdx.x);
+}
+// k_side and the log-prior workgroups of the iteration before in ONE launch (the fixed-rank Gibbs sweep: two runtime calls fewer
+// per iteration — small problems are bound by the host's enqueue rate).  Workgroups [0, first): k_side's (blk0 as there);
+// then n_lpp workgroups with k_lpp's work (one wave each), then n_lpe with k_lpe's.  The two kinds are independent of each
+// other; side_done counts the k_side workgroups only.
+struct SideExtra { int first, n_lpp, n_lpe; uint32_t t_lp; const double* Esrc; };
+static_assert(ES_T == RT, "k_side_lp: one block size for both kinds of workgroup");
+__global__ __launch_bounds__(RT, 4) void k_side_lp(Dev d, uint32_t t, int nbP, int blk0, RecDst rec, SideDone sd, SideExtra ex) {
+  __shared__ double buf[RT];
+  const int j = (int)blockIdx.x - ex.first;
+  if (j < 0) side_body(d, t, nbP, blockIdx.x + blk0, ex.first, rec, sd, buf, threadIdx.x);
+  else if (j < ex.n_lpp) { if (threadIdx.x < 64) lpp_body(d, ex.t_lp, j, threadIdx.x); }
+  else lpe_body(d, ex.t_lp, j - ex.n_lpp, ex.Esrc, buf, threadIdx.x);
 }
 
 // ---- k_zalloc: the general Z-allocation kernel (any N, any K); the metric configuration runs k_zalloc_reg ----
