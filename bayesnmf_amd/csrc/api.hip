@@ -40,6 +40,8 @@ struct bnmf_handle {
   hipStream_t side2 = nullptr;         // second side stream: k_side P part (starts right after k_pdraw) and Esum
   hipEvent_t ev_draw = nullptr, ev_side = nullptr, ev_sideP = nullptr, ev_p = nullptr, ev_z = nullptr, ev_red = nullptr, ev_rank = nullptr;
   bool side_valid = false;             // k_side of iteration iter+1 has been issued
+  bool side_ev_stale = false;          // ev_sideP / ev_side not recorded since the last side launches (fixed-rank sweep: recorded on demand)
+  bool red_on_side2 = false;           // the last k_reduce was issued on side2 (then side2 needs no event to be ordered behind it)
   double* E_alt = nullptr;             // Gibbs sweep: the other E buffer (k_edraw of t+1 does not overwrite what k_lpe of t still reads)
   bool mh_prep_valid = false;          // MH / Normal models: Et, nzE are current and nzP is zero (k_mh_tail of the previous iteration)
   const void* z_attr_kernel = nullptr;   // allocation kernel whose dynamic-LDS limit has been raised for this handle
@@ -542,9 +544,10 @@ static int ensure_metrics(bnmf_handle* h, size_t rows) {
   return 0;
 }
 // Per-iteration partial sums (per-column metric terms, log-prior partials, MH acceptance partials) live in
-// three slots (t % 3): k_reduce of iteration t is issued during iteration t+1 (see launch_side), and the
-// next writers of its slot are the kernels of iteration t+3: k_zalloc / k_lpe behind it through ev_side, k_lpp (side2)
-// through ev_red.
+// three slots (t % 3): k_reduce of iteration t is issued during iteration t+1 (see launch_side / launch_side_E), and the
+// next writers of its slot are the kernels of iteration t+3.  Fixed-rank sweep: k_reduce(t) sits on side2 in front of
+// Esum(t+2), whose flag releases k_pdraw(t+2) and with it everything of iteration t+2 and later on the main stream; the
+// log-prior workgroups of side2 follow it in stream order.  Other sweeps: through ev_side (main stream) and ev_red (side2).
 static void set_slot(const bnmf_handle* h, Dev& d, uint32_t t) {
   const size_t sl = t % 3u, G = h->cfg.G, N = h->cfg.N;
   d.colsse = h->dcol + sl * 3 * G; d.colll = d.colsse + G; d.colkl = d.colsse + 2 * G;
@@ -583,7 +586,20 @@ static void issue_reduce(bnmf_handle* h, uint32_t t, int row, Timer& tm, hipStre
   tm.begin(KN_REDUCE, st);
   hipLaunchKernelGGL(k_reduce, dim3(h->cfg.MH ? 5 : 4), dim3(RT), 0, st, dr, row, h->nblkE, (const double*)accPn_slot(h, t), (const double*)accEp_slot(h, t));
   tm.end(KN_REDUCE, st);
-  hipEventRecord(h->ev_red, st); h->red_issued = true;
+  // k_lpp's workgroups (side2) rewrite an lpPn slot this kernel read three iterations earlier: side2 waits for ev_red, unless the
+  // reduce was issued on side2 itself (the fixed-rank sweep), where stream order does it without two runtime calls
+  h->red_on_side2 = st == h->side2;
+  if (!h->red_on_side2) { hipEventRecord(h->ev_red, st); h->red_issued = true; }
+}
+// ev_sideP (side2 done) and ev_side (side done, behind ev_sideP) are what a main-stream wait or flush_reduce needs; in the
+// steady state of the fixed-rank sweep nobody waits for them (k_pdraw polls flags), so they are recorded on demand: a later
+// record covers everything enqueued before it
+static void refresh_side_events(bnmf_handle* h) {
+  if (!h->side_ev_stale) return;
+  hipEventRecord(h->ev_sideP, h->side2);
+  hipStreamWaitEvent(h->side, h->ev_sideP, 0);
+  hipEventRecord(h->ev_side, h->side);
+  h->side_ev_stale = false;
 }
 static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm, bool publish = false) {
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
@@ -598,6 +614,7 @@ static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm, bool publish = fa
   tm.end(KN_SIDE, h->side);
   hipEventRecord(h->ev_side, h->side);
   hipEventRecord(h->ev_sideP, h->side);
+  h->side_ev_stale = false;
   h->side_valid = true;
   // k_reduce of the PREVIOUS iteration: its inputs are complete once the draws of this iteration have run
   // (main-stream order), which ev_draw above implies, so the main stream needs no marker after k_zalloc
@@ -616,7 +633,7 @@ static void launch_side_P(bnmf_handle* h, uint32_t t, hipEvent_t after = nullptr
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
   hipStreamWaitEvent(h->side2, after ? after : h->ev_p, 0);
   // k_lpp below rewrites lpPn slot (t-1) % 3, last read by k_reduce of iteration t-4 (side stream): order behind it
-  if (h->red_issued) hipStreamWaitEvent(h->side2, h->ev_red, 0);
+  if (h->red_issued && !h->red_on_side2) hipStreamWaitEvent(h->side2, h->ev_red, 0);
   // ... and the log-prior of the P just drawn (k_lpp's work, iteration t-1) in the same launch
   hipLaunchKernelGGL(k_side_lp, dim3(nbP + h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, h->cfg.N, rec_at(h, t, fused_rec(h)), SideDone{},
                      SideExtra{nbP, h->cfg.N, 0, t - 1, nullptr});
@@ -634,14 +651,11 @@ static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm) {   // ev_draw 
   // behind ev_draw (k_zalloc of that iteration): on the E part's stream it sat in front of the next E-side sweep, and the
   // P part waited for its event
   if (h->red_pending) { issue_reduce(h, h->red_t, h->red_row, tm, h->side2); h->red_pending = false; }
-  hipEventRecord(h->ev_sideP, h->side2);
   hipStreamWaitEvent(h->side, h->ev_draw, 0);
   hipLaunchKernelGGL(k_side, dim3(nbE), dim3(RT), 0, h->side, h->dev, t, nbP, h->cfg.N + nbP, rec_at(h, t, fused_rec(h)), SideDone{h->dFlags, h->dFlags + 1, (unsigned)nbE, t});
   h->flags_valid = true;
-  // ONE event for the main stream: ev_side fires when the E part (side) AND the P part / Esum / k_lpe (side2) are done.
-  // (A wait costs a barrier packet on the main stream, ~8 us even when the event has long fired.)
-  hipStreamWaitEvent(h->side, h->ev_sideP, 0);
-  hipEventRecord(h->ev_side, h->side);
+  // ev_side (the E part AND the P part / Esum / log-priors done) for a main-stream wait: on demand, see refresh_side_events
+  h->side_ev_stale = true;
   h->side_valid = true;
 }
 // Rank learning: the hyper sweep of t+1 in two parts.  Early (released by k_edraw): the k_side kernels.  They hold 64+ VGPRs
@@ -670,6 +684,7 @@ static void launch_side_late(bnmf_handle* h, uint32_t t, Timer& tm) {
   hipEventRecord(h->ev_sideP, h->side2);
   hipStreamWaitEvent(h->side, h->ev_sideP, 0);
   hipEventRecord(h->ev_side, h->side);
+  h->side_ev_stale = false;
   h->side_valid = true;
   if (h->red_pending) { issue_reduce(h, h->red_t, h->red_row, tm); h->red_pending = false; }
 }
@@ -830,6 +845,7 @@ static void flush_reduce(bnmf_handle* h, Timer& tm) {
   if (!h->red_pending) return;
   hipEventRecord(h->ev_z, h->stream);
   hipStreamWaitEvent(h->side, h->ev_z, 0);
+  refresh_side_events(h);
   hipStreamWaitEvent(h->side, h->ev_sideP, 0);             // k_lpe of the last iteration (side2)
   issue_reduce(h, h->red_t, h->red_row, tm);
   h->red_pending = false;
@@ -897,7 +913,7 @@ static int sweep_mh(bnmf_handle* h, int row, int converged, Timer& tm) {
   // prior parameters of iteration t: in the steady state the P-row kernel polls the flag k_side publishes (a stream wait is a
   // barrier packet: ~16 us of bubble per iteration here); after init / set_array / in profile mode a stream wait
   const bool poll = h->flags_valid && !tm.on;
-  if (!poll) { hipStreamWaitEvent(h->stream, h->ev_side, 0); hipStreamWaitEvent(h->stream, h->ev_sideP, 0); }
+  if (!poll) { refresh_side_events(h); hipStreamWaitEvent(h->stream, h->ev_side, 0); hipStreamWaitEvent(h->stream, h->ev_sideP, 0); }
   tm.begin(KN_MH, h->stream); launch_mh_PE(h, t, converged, poll); tm.end(KN_MH, h->stream);
   launch_side(h, t + 1, tm, !tm.on);
   if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
@@ -927,7 +943,7 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   // prior parameters + Esum of iteration t: in the steady state k_pdraw polls the flags their kernels publish (no barrier
   // packet on the main stream); after init / set_array / in profile mode a stream wait
   const bool poll = h->flags_valid && !tm.on;
-  if (!poll) hipStreamWaitEvent(h->stream, h->ev_side, 0);
+  if (!poll) { refresh_side_events(h); hipStreamWaitEvent(h->stream, h->ev_side, 0); }
   if (tm.on) {                                             // profile mode: one kernel at a time
     tm.begin(KN_PDRAW, h->stream); launch_pdraw(h, t, 0, rec); tm.end(KN_PDRAW, h->stream);
     tm.begin(KN_EDRAW, h->stream); launch_edraw(h, t, 0, rec); tm.end(KN_EDRAW, h->stream);
