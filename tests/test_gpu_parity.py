@@ -479,6 +479,40 @@ def test_user_supplied_initial_values():
     assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64))
 
 
+@pytest.mark.parametrize("prior", ["gamma", "exponential"])
+def test_fixed_rank_with_excluded_factors(prior):
+    """A supplied by the user with zeros and the rank NOT learned: the excluded factors' P and E are drawn from the prior in
+    every sweep (R/sample_Pn.R:12-30, R/sample_En.R:12-30) and receive no counts: bit-exact over 40 sweeps, recorded
+    window included."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    M, _, _ = synth_counts(96, 700, 3, 77)
+    N = 5
+    A0 = np.array([[1.0, 0.0, 1.0, 1.0, 0.0]])
+    o = O.Oracle(M, N, prior=prior, seed=12, save_Z=True, nthreads=8)
+    e = Engine(M, N, prior=prior, seed=12, save_Z=True, window=3)
+    for c in (o, e):
+        apply_hyperprior_params(c, prior, M, N)
+        c.set("A", A0)
+    o.init(); e.init()
+    for step in range(4):
+        mo, me = o.run(10), e.run(10)
+        for nm in ("P", "E"):
+            assert np.array_equal(o.get(nm).view(np.uint64), e.get(nm).view(np.uint64)), (nm, step)
+        assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), step
+    Z = e.get("Z")
+    assert np.array_equal(o.get("Z").astype(np.int32), Z)
+    assert (Z[:, [1, 4], :] == 0).all() and (Z.sum(1) == M).all()
+    kept = []
+    for _ in range(3):
+        o.run(1); kept.append(o.get("E").copy())
+    e.run(3)
+    for wo, we in zip(kept, e.window("E", 3)):
+        assert np.array_equal(wo.view(np.uint64), np.ascontiguousarray(we).view(np.uint64))
+    e.close()
+
+
 def _match_cosine(P, Pt):
     """Best one-to-one cosine match of the columns of P to the columns of Pt (assignment problem)."""
     from scipy.optimize import linear_sum_assignment
