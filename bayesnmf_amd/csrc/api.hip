@@ -67,7 +67,9 @@ struct bnmf_handle {
   hipEvent_t ev[2 * BNMF_NKERNEL]{};
   bool have_ev = false;
   double* dMap = nullptr; size_t map_words = 0;   // scratch of bnmf_map (grown on demand)
-  unsigned* dFlags = nullptr;                     // [0] counter, [1] flag of the E-side hyper sweep; [2], [3] of P part + Esum; [4] time-out
+  unsigned* dFlags = nullptr;                     // [0] counter, [1] flag of the E-side hyper sweep; [2], [3] of P part + Esum
+  int* hErr = nullptr; int* dErr = nullptr;       // time-out words of the bounded in-kernel waits, in mapped host memory (read without a copy):
+                                                  // [0] a draw kernel waiting for the hyper sweep, [1] the rank sweep's exchange
   bool flags_valid = false;                       // the side work of the next iteration publishes its flags
   std::vector<double> hist;                       // [wcap][4]: loglikelihood, logposterior, P / E mean acceptance of the last iterations
   std::vector<double> temp_host;                  // temperature schedule (host copy, for the convergence rule)
@@ -213,6 +215,9 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   if (cfg->save_Z) HIPCHK(hipMalloc(&h->dZ, K * N * G * sizeof(int32_t)));
   HIPCHK(hipMalloc(&h->dFlags, 64));
   HIPCHK(hipMemset(h->dFlags, 0, 64));
+  HIPCHK(hipHostMalloc((void**)&h->hErr, 64, hipHostMallocMapped));
+  memset(h->hErr, 0, 64);
+  HIPCHK(hipHostGetDevicePointer((void**)&h->dErr, h->hErr, 0));
   HIPCHK(hipMalloc(&h->dR, sizeof(int)));
   int Rinit = (int)N;
   HIPCHK(hipMemcpy(h->dR, &Rinit, sizeof(int), hipMemcpyHostToDevice));
@@ -429,7 +434,7 @@ int bnmf_destroy(bnmf_handle* h) {
   if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_rank) hipEventDestroy(h->ev_rank); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); if (h->side) hipStreamDestroy(h->side); if (h->side2) hipStreamDestroy(h->side2);
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
   if (h->dMap) hipFree(h->dMap);
-  if (h->dFlags) hipFree(h->dFlags);
+  if (h->dFlags) hipFree(h->dFlags); if (h->hErr) hipHostFree(h->hErr);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -756,7 +761,7 @@ static void launch_rank(bnmf_handle* h, uint32_t t, hipEvent_t stop = nullptr, i
   const size_t lds = ((size_t)N + NB + N + 1 + N) * sizeof(double);   // A, block sums, sample_R weights, sample_An uniforms
   const RecDst rr = row >= 0 ? rec_at(h, t, fused_rec(h)) : RecDst{};
   auto go = [&](auto kern) {
-    hipExtLaunchKernelGGL(kern, dim3(h->rank_grid), dim3(RK_T), (uint32_t)lds, h->stream, nullptr, stop, 0, h->dev, t, (unsigned long long*)h->dRankCol, NB, (int*)(h->dRankSync + 4), h->dRankMhat, (unsigned long long*)h->dRankDbg, row, rr.A, rr.R);
+    hipExtLaunchKernelGGL(kern, dim3(h->rank_grid), dim3(RK_T), (uint32_t)lds, h->stream, nullptr, stop, 0, h->dev, t, (unsigned long long*)h->dRankCol, NB, h->dErr + 1, h->dRankMhat, (unsigned long long*)h->dRankDbg, row, rr.A, rr.R);
   };
   const bool nrm = h->cfg.likelihood == BNMF_NORMAL;
   if (h->rank_reg) { if (nrm) go(k_rank_sweep<true, true>); else go(k_rank_sweep<true, false>); }
@@ -840,14 +845,15 @@ static void launch_reduce(bnmf_handle* h, uint32_t t, int row, Timer& tm, bool r
   if (h->cfg.learning_rank && !rank_wrote) hipLaunchKernelGGL(k_sumA, dim3(1), dim3(64), 0, h->stream, h->dev, row, (const double*)accPn_slot(h, t), rec_at(h, t, fused_rec(h)));
   h->red_pending = true; h->red_t = t; h->red_row = row;
 }
-// ... or at once (init, end of a run): the side stream waits for everything issued on the main stream so far
+// ... or at once (init, end of a run), on the MAIN stream: behind the allocation / metrics kernel of the last iteration in
+// stream order, and behind the log-prior workgroups of that iteration on the side streams through ONE event wait (they ran
+// beside the allocation kernel and are long done).  On the side stream it took two cross-stream hops in a row (side waits
+// for main, main waits for side: ~15 us each) at the end of every bnmf_run.
 static void flush_reduce(bnmf_handle* h, Timer& tm) {
   if (!h->red_pending) return;
-  hipEventRecord(h->ev_z, h->stream);
-  hipStreamWaitEvent(h->side, h->ev_z, 0);
-  refresh_side_events(h);
-  hipStreamWaitEvent(h->side, h->ev_sideP, 0);             // k_lpe of the last iteration (side2)
-  issue_reduce(h, h->red_t, h->red_row, tm);
+  if (h->side_ev_stale) hipEventRecord(h->ev_sideP, h->side2);   // fixed-rank sweep: k_lpp / k_lpe workgroups live on side2
+  hipStreamWaitEvent(h->stream, h->ev_sideP, 0);
+  issue_reduce(h, h->red_t, h->red_row, tm, h->stream);
   h->red_pending = false;
 }
 // P and E updates of the MH models (R/sample_params.R:56-64 with sample_Pn/_En -> *_normal -> MH_*_poisson)
@@ -864,7 +870,7 @@ static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged, bool poll = 
   const bool regP = S <= MHP_W;                              // one 320-column segment per wave: the row's cells stay in registers
   const size_t ldsP = (4 * (size_t)S + 2 * N + 2 + ((regP && mhstep) ? (size_t)MH_CPL * MHP_T : 0)) * sizeof(double);
   auto goP = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(K), dim3(MHP_T), ldsP, h->stream, h->dev, t, S, (const int*)h->dNzE, h->dNzE + N, accP, h->dMhat, h->dMhat + (size_t)K * h->cfg.G,
-                                                poll ? SideWait{h->dFlags + 1, h->dFlags + 1, t, (int*)(h->dFlags + 4)} : SideWait{}); };
+                                                poll ? SideWait{h->dFlags + 1, h->dFlags + 1, t, h->dErr} : SideWait{}); };
   if (normal) { if (regP) goP(k_mh_prow<true, true, false>); else goP(k_mh_prow<true, false, false>); }
   else if (mhstep) { if (regP) goP(k_mh_prow<false, true, true>); else goP(k_mh_prow<false, false, true>); }
   else { if (regP) goP(k_mh_prow<false, true, false>); else goP(k_mh_prow<false, false, false>); }
@@ -952,7 +958,7 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
     // completion events ride on the dispatches themselves (stop events): no marker packets on the main stream
     hipExtLaunchKernelGGL(k_pdraw, dim3(h->cfg.N), dim3(PD_T), (uint32_t)(2 * (size_t)h->cfg.K * sizeof(double)), h->stream,
                           nullptr, h->ev_p, 0, h->dev, t, 0, 0, rec_pdraw(h, t, rec),
-                          poll ? SideWait{h->dFlags + 1, h->dFlags + 3, t, (int*)(h->dFlags + 4)} : SideWait{});
+                          poll ? SideWait{h->dFlags + 1, h->dFlags + 3, t, h->dErr} : SideWait{});
     if (!h->cfg.learning_rank) {
       launch_side_P(h, t + 1);
       hipExtLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, 0, 0, rec_at(h, t, rec).E);
@@ -1098,16 +1104,9 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
       d[0] = r[3]; d[1] = r[4]; d[2] = r[9]; d[3] = r[10];
     }
   }
-  {
-    int ferr = 0;
-    HIPCHK(hipMemcpy(&ferr, h->dFlags + 4, sizeof(int), hipMemcpyDeviceToHost));
-    if (ferr) return fail(BNMF_EHIP, "bnmf_run: a draw kernel timed out waiting for the hyper-parameter sweep of its iteration");
-  }
-  if (h->dRankSync) {
-    int err = 0;
-    HIPCHK(hipMemcpy(&err, h->dRankSync + 4, sizeof(int), hipMemcpyDeviceToHost));
-    if (err) return fail(BNMF_EHIP, "bnmf_run: the grid barrier of the rank sweep timed out (workgroups not co-resident?)");
-  }
+  // all three streams are idle: the time-out words (mapped host memory) are final
+  if (((volatile int*)h->hErr)[0]) return fail(BNMF_EHIP, "bnmf_run: a draw kernel timed out waiting for the hyper-parameter sweep of its iteration");
+  if (((volatile int*)h->hErr)[1]) return fail(BNMF_EHIP, "bnmf_run: the grid barrier of the rank sweep timed out (workgroups not co-resident?)");
   return 0;
 }
 int bnmf_run(bnmf_handle* h, int n_iter, int converged, double* metrics) {
