@@ -40,6 +40,9 @@ struct bnmf_handle {
   hipStream_t side2 = nullptr;         // second side stream: k_side P part (starts right after k_pdraw) and Esum
   hipEvent_t ev_draw = nullptr, ev_side = nullptr, ev_sideP = nullptr, ev_p = nullptr, ev_z = nullptr, ev_red = nullptr, ev_rank = nullptr;
   bool side_valid = false;             // k_side of iteration iter+1 has been issued
+  int gate_forced = -1;                // BNMF_GATE at bnmf_create: 0 / 1 forces the merged draw kernel off / on, else by size
+  uint32_t z_gate_next = 0;            // != 0: the allocation kernel being launched waits at its end for the hyper sweep of this iteration
+  uint32_t z_gated_for = 0;            // the last allocation kernel gated for this iteration's hyper sweep (merged draw kernel, BNMF_GATE)
   bool side_ev_stale = false;          // ev_sideP / ev_side not recorded since the last side launches (fixed-rank sweep: recorded on demand)
   bool red_on_side2 = false;           // the last k_reduce was issued on side2 (then side2 needs no event to be ordered behind it)
   double* E_alt = nullptr;             // Gibbs sweep: the other E buffer (k_edraw of t+1 does not overwrite what k_lpe of t still reads)
@@ -213,6 +216,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   HIPCHK(hipMemset(h->dZsumK, 0, N * G * sizeof(int32_t)));
   HIPCHK(hipMemset(h->dZsumG, 0, K * N * sizeof(int32_t)));
   if (cfg->save_Z) HIPCHK(hipMalloc(&h->dZ, K * N * G * sizeof(int32_t)));
+  if (const char* e = getenv("BNMF_GATE")) h->gate_forced = atoi(e) != 0 ? 1 : 0;   // diagnostics / tests
   HIPCHK(hipMalloc(&h->dFlags, 64));
   HIPCHK(hipMemset(h->dFlags, 0, 64));
   HIPCHK(hipHostMalloc((void**)&h->hErr, 64, hipHostMallocMapped));
@@ -704,7 +708,9 @@ static int launch_z(bnmf_handle* h, uint32_t t, KernelT kern, const ArgT& arg, i
 }
 static ZArgs zargs(const bnmf_handle* h) {
   const Dev& d = h->dev;
-  return ZArgs{d.K, d.G, d.N, d.maxM, d.k0, d.k1, d.M, d.P, d.E, d.A, d.ZsumK, d.ZsumG, d.Z, d.colsse, d.colll, d.colkl, d.lgfact, d.logm};
+  ZArgs za{d.K, d.G, d.N, d.maxM, d.k0, d.k1, d.M, d.P, d.E, d.A, d.ZsumK, d.ZsumG, d.Z, d.colsse, d.colll, d.colkl, d.lgfact, d.logm, nullptr, nullptr, 0u, nullptr};
+  if (h->z_gate_next) { za.gate0 = h->dFlags + 1; za.gate1 = h->dFlags + 3; za.gate_epoch = h->z_gate_next; za.gate_err = h->dErr; }
+  return za;
 }
 template <bool SZ, int ZT_, bool DIAG>
 static int launch_zreg_t(bnmf_handle* h, uint32_t t) {
@@ -928,6 +934,14 @@ static int sweep_mh(bnmf_handle* h, int row, int converged, Timer& tm) {
   launch_reduce(h, t, row, tm);
   return 0;
 }
+// Merged draw kernel + gate at the end of the allocation kernel (k_draw, zalloc_reg.h): pays when the allocation kernel is long
+// enough to cover the hyper sweep that its last lane waits for — 125.4 -> 121.3 us per iteration at K = 96, G = 10,000, but
+// 54.5 -> 57.9 us at G = 2,000, where the hyper sweep outlasts the kernel and the gate puts it on the main stream's path.
+// BNMF_GATE=0 / 1 forces it off / on (diagnostics).
+static bool gate_enabled(const bnmf_handle* h) {
+  if (h->gate_forced >= 0) return h->gate_forced != 0;
+  return (size_t)h->cfg.K * h->cfg.G >= 600000;
+}
 static int sweep(bnmf_handle* h, int row, Timer& tm) {
   h->iter += 1;
   const uint32_t t = (uint32_t)h->iter;
@@ -954,6 +968,13 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
     tm.begin(KN_PDRAW, h->stream); launch_pdraw(h, t, 0, rec); tm.end(KN_PDRAW, h->stream);
     tm.begin(KN_EDRAW, h->stream); launch_edraw(h, t, 0, rec); tm.end(KN_EDRAW, h->stream);
     launch_side(h, t + 1, tm);
+  } else if (gate_enabled(h) && !h->cfg.learning_rank && poll && h->z_reg && !h->z_tile && h->z_gated_for == t) {
+    // merged draw kernel: the allocation kernel of t-1 has waited for this iteration's hyper sweep
+    const unsigned nE = (unsigned)(((size_t)h->cfg.N * h->cfg.G + DW - 1) / DW);
+    hipExtLaunchKernelGGL(k_draw, dim3(h->cfg.N + nE), dim3(DW), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, rec_at(h, t, rec),
+                          SideDone{h->dFlags + 5, h->dFlags + 6, (unsigned)h->cfg.N, t}, SideWait{h->dFlags + 6, h->dFlags + 6, t, h->dErr});
+    launch_side_P(h, t + 1, h->ev_draw);
+    launch_side_E(h, t + 1, tm);
   } else {
     // completion events ride on the dispatches themselves (stop events): no marker packets on the main stream
     hipExtLaunchKernelGGL(k_pdraw, dim3(h->cfg.N), dim3(PD_T), (uint32_t)(2 * (size_t)h->cfg.K * sizeof(double)), h->stream,
@@ -973,7 +994,10 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
     }
   }
   if (h->cfg.learning_rank && tm.on) { tm.begin(KN_RANK, h->stream); launch_rank(h, t, nullptr, row); tm.end(KN_RANK, h->stream); }
+  const bool gate = gate_enabled(h) && !h->cfg.learning_rank && poll && h->z_reg && !h->z_tile;
+  h->z_gate_next = gate ? t + 1 : 0u;
   tm.begin(KN_ZALLOC, h->stream); if (int rc = launch_zalloc(h, t)) return rc; tm.end(KN_ZALLOC, h->stream);
+  h->z_gated_for = h->z_gate_next; h->z_gate_next = 0;
   record_Z(h, t);
   launch_reduce(h, t, row, tm, h->cfg.learning_rank != 0);
   return 0;

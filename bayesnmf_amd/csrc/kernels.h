@@ -70,6 +70,7 @@ BNMF_DEV void side_done(const SideDone& sd, int tid) {
     }
   }
 }
+template <bool FENCE = true>
 BNMF_DEV void side_wait(const SideWait& sw, int tid) {
   if (!sw.f0) return;
   if (tid == 0) {
@@ -79,11 +80,14 @@ BNMF_DEV void side_wait(const SideWait& sw, int tid) {
       __builtin_amdgcn_s_sleep(1);
       if (++spins > (1u << 24)) { __hip_atomic_store(sw.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (FENCE) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
   __syncthreads();
 }
+BNMF_DEV double ld_ag(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ---- hyper sweep of one element: R/sample_priors.R:150-200 (element-wise conditionals) ----
 template <int SIDE>
@@ -270,6 +274,80 @@ __global__ __launch_bounds__(ES_T) void k_edraw(Dev d, uint32_t t, int from_prio
   if (!with_lp) return;                                 // the log-prior is then computed off the critical path (k_lpe)
   const double r = block_tree<ES_T>(lp, buf, tid);
   if (tid == 0) d.lpE_part[blockIdx.x] = r;
+}
+
+// ---- k_draw: k_pdraw and k_edraw of the steady-state fixed-rank sweep in ONE launch (experiment switch BNMF_GATE) ----
+// Workgroups [0, N): factor n's column of P (k_pdraw's work), Psum[n] stored write-through, the last of them raises the flag pd.
+// Workgroups [N, ..): E, DW lanes each: the Gamma(shape, 1) part of the draw needs nothing from P; then the workgroup waits for
+// the flag (one lane polls; the P workgroups have the lowest indices, so they are resident before any E workgroup) and divides
+// by the rate — the same operations in the same order as rgamma(shape, rate).  The kernel waits for nothing outside itself: the
+// allocation kernel before it has waited (one lane, at its end) for the hyper sweep of this iteration.
+constexpr int DW = 1024;
+__global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, SideDone pd, SideWait pw) {
+  __shared__ double Pn[DW];
+  const int tid = threadIdx.x, N = d.N, K = d.K;
+  if ((int)blockIdx.x < N) {
+    const int n = blockIdx.x;
+    const double a_n = d.A[n];
+    const double Esum = d.Esum[n];
+    for (int k = tid; k < K; k += DW) {
+      const int e = k + K * n;
+      double x;
+      if (a_n == 0.0) x = prior_draw<0>(d, e, t);
+      else {
+        double shape, rate;
+        if (d.prior == BNMF_GAMMA) { shape = slot<0>(d, d.Alpha_p, t)[e] + (double)d.ZsumG[e]; rate = slot<0>(d, d.Beta_p, t)[e] + a_n * Esum; }
+        else { shape = 1.0 + (double)d.ZsumG[e]; rate = slot<0>(d, d.Lam_p, t)[e] + a_n * Esum; }
+        Stream s(d.k0, d.k1, BNMF_V_P, (uint32_t)e, t);
+        x = rgamma(s, shape, rate);
+      }
+      d.P[e] = x;
+      if (rec.P) rec.P[e] = x;
+      d.ZsumG[e] = 0;
+      if (k < DW) Pn[k] = x;
+    }
+    if (rec.A && tid == 0) rec.A[n] = a_n;
+    if (rec.R && tid == 0 && n == 0) *rec.R = (double)*d.R;
+    __syncthreads();
+    if (tid < 64) {
+      double acc = 0.0;
+      for (int k = tid; k < K; k += 64) acc = acc + (k < DW ? Pn[k] : d.P[k + K * n]);
+      acc = wave_tree64(acc);
+      if (tid == 0) st_wt(&d.Psum[n], acc);
+    }
+    side_done(pd, tid);
+    return;
+  }
+  const long e = (long)((int)blockIdx.x - N) * DW + tid;
+  const bool live = e < (long)d.lenE;
+  double x = 0.0, a_n = 0.0;
+  bool scaled = false;                                   // x is Gamma(shape, 1) and still has to be divided by the rate
+  double base = 0.0;                                     // the rate without its Psum term
+  int n = 0;
+  if (live) {
+    n = (int)(e % N);
+    a_n = d.A[n];
+    if (a_n == 0.0) x = prior_draw<1>(d, (int)e, t);
+    else {
+      double shape;
+      if (d.prior == BNMF_GAMMA) { shape = slot<1>(d, d.Alpha_e, t)[e] + (double)d.ZsumK[e]; base = slot<1>(d, d.Beta_e, t)[e]; }
+      else { shape = 1.0 + (double)d.ZsumK[e]; base = slot<1>(d, d.Lam_e, t)[e]; }
+      Stream s(d.k0, d.k1, BNMF_V_E, (uint32_t)e, t);
+      x = rgamma(s, shape, 1.0);
+      scaled = true;
+    }
+  }
+  side_wait<false>(pw, tid);
+  if (live) {
+    if (scaled) {
+      const double rate = base + a_n * ld_ag(&d.Psum[n]);
+      // rgamma(shape, rate) ends in `g / rate`; rgamma(shape, 1.0) returned g / 1.0 = g
+      x = x / rate;
+    }
+    d.E[e] = x;
+    if (rec.E) rec.E[e] = x;
+    if (d.zsumk_accum) d.ZsumK[e] = 0;
+  }
 }
 
 // log-prior of column n of P_t under iteration t's prior parameters: canonical W = 64 over k, as in k_pdraw

@@ -85,6 +85,9 @@ struct ZArgs {
   int32_t *ZsumK, *ZsumG, *Z;
   double *colsse, *colll, *colkl;
   const double *lgfact, *logm;
+  // gate (fixed-rank sweep, merged draw kernel): ONE lane of the launch waits, before the kernel ends, for the flags of the next
+  // iteration's hyper sweep — the draw kernel behind this one then waits for nothing outside itself
+  const unsigned *gate0, *gate1; unsigned gate_epoch; int* gate_err;
 };
 // Row geometry of the compact per-column cell list (host and device must agree: api.hip sizes the slab)
 constexpr int zreg_hdr_u4(int trc) { return (trc / 4 - 1) > 4 ? 3 : 2; }           // header 128-bit words: link + pivots
@@ -395,6 +398,14 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(ZArgs d, uint32_t t, ZGeom
     const int kk = i % K, n = i / K;
     const uint32_t v = zacc[(size_t)n * KP + kk];
     if (v && !(DIAG && (ablate & 1))) atomicAdd(&d.ZsumG[kk + (size_t)K * n], (int32_t)v);
+  }
+  if (d.gate0 && blockIdx.x == 0 && tid == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(d.gate0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < d.gate_epoch ||
+           __hip_atomic_load(d.gate1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < d.gate_epoch) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 24)) { __hip_atomic_store(d.gate_err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
   }
 }
 

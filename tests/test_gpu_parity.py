@@ -513,6 +513,43 @@ def test_fixed_rank_with_excluded_factors(prior):
     e.close()
 
 
+@pytest.mark.parametrize("gate", ["0", "1"])
+@pytest.mark.parametrize("prior,window", [("gamma", 3), ("exponential", 0)])
+def test_merged_draw_kernel_bitexact(prior, window, gate, monkeypatch):
+    """The steady-state fixed-rank sweep in its two forms: k_pdraw + k_edraw polling the hyper sweep's flags (BNMF_GATE=0), and
+    the merged draw kernel behind an allocation kernel whose last lane has waited for them (BNMF_GATE=1; the default from
+    K x G = 600,000 cells on).  Same draws: P, E, Z statistics, metrics and the recorded window bit-exact against the oracle
+    over several bnmf_run calls (the first sweep of every call and the sweeps after a set() take the two-kernel form)."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    monkeypatch.setenv("BNMF_GATE", gate)
+    M, _, _ = synth_counts(96, 900, 4, 99)
+    N = 20
+    A0 = np.ones((1, N)); A0[0, 7] = 0.0
+    o = O.Oracle(M, N, prior=prior, seed=21, nthreads=8)
+    e = Engine(M, N, prior=prior, seed=21, window=window)
+    for c in (o, e):
+        apply_hyperprior_params(c, prior, M, N)
+        c.set("A", A0)
+    o.init(); e.init()
+    for step, n_it in enumerate((1, 2, 9, 14, 5)):
+        mo, me = o.run(n_it), e.run(n_it)
+        for nm in ("P", "E", "ZsumK", "ZsumG"):
+            a, b = np.ascontiguousarray(o.get(nm), dtype=np.float64), np.ascontiguousarray(e.get(nm), dtype=np.float64)
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (nm, step)
+        assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), step
+    if window:
+        kept = []
+        for _ in range(3):
+            o.run(1); kept.append((o.get("P").copy(), o.get("E").copy()))
+        e.run(3)
+        for (po, eo), pw, ew in zip(kept, e.window("P", 3), e.window("E", 3)):
+            assert np.array_equal(po.view(np.uint64), np.ascontiguousarray(pw).view(np.uint64))
+            assert np.array_equal(eo.view(np.uint64), np.ascontiguousarray(ew).view(np.uint64))
+    e.close()
+
+
 def _match_cosine(P, Pt):
     """Best one-to-one cosine match of the columns of P to the columns of Pt (assignment problem)."""
     from scipy.optimize import linear_sum_assignment
