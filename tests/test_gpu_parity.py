@@ -143,10 +143,11 @@ def _temp_schedule(n):
     return np.concatenate([np.zeros(3), 10.0 ** np.linspace(-6, 0, 40), np.ones(max(0, n - 43))])
 
 
-@pytest.mark.parametrize("G,iters", [(2000, 4), (10000, 3)])
+@pytest.mark.parametrize("G,iters", [(2000, 4), (10000, 7)])
 def test_full_size_chain_bitexact(G, iters):
     """BASELINE config 2 (G = 2,000) and the metric configuration (G = 10,000), K = 96, N = 20, at full size:
-    every array of the sweep and the metrics rows agree bit for bit with the oracle after a few iterations."""
+    every array of the sweep and the metrics rows agree bit for bit with the oracle after a few iterations (at G = 10,000 the
+    sweeps from the third on run the merged draw kernel behind the gated allocation kernel)."""
     import oracle as O
     from bayesnmf_amd import Engine
     from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
