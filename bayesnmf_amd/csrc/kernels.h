@@ -1,11 +1,12 @@
 // bayesnmf_amd/csrc/kernels.h — hand-written gfx950 kernels of the Gibbs sweep.
 //
-// One iteration (Poisson likelihood, no MH; R/bayesNMF_sampler.R:273-285) is four launches:
-//   k_side    (side stream, overlaps k_zalloc of the previous iteration): Esum, hyper sweep
-//   k_pdraw   grid N       : P[,n] -> Psum[n], log-prior of column n
-//   k_edraw   grid NG/256  : E -> log-prior partials
-//   k_zalloc  one wave per column: thresholds -> categorical allocation of every count ->
-//                            ZsumK, ZsumG (+Z) and the per-column RMSE/KL/log-lik terms
+// One iteration (Poisson likelihood, no MH; R/bayesNMF_sampler.R:273-285), see DESIGN.md §5 for the stream structure:
+//   k_pdraw   grid N       : P[,n] -> Psum[n] (and, at init, the log-prior of column n)
+//   k_edraw   grid NG/256  : E (and, at init, the log-prior partials)
+//   k_draw    the two above in one launch (steady state of large fixed-rank problems)
+//   k_zalloc* one wave per column (zalloc_reg.h) / one workgroup per 32-row chunk (zalloc_tile.h): thresholds ->
+//                            categorical allocation of every count -> ZsumK, ZsumG (+Z), per-column RMSE/KL/log-lik terms
+//   k_side / k_side_lp (side streams, beside k_zalloc): hyper sweep of the next iteration, Esum, log-priors of this one
 //   k_reduce  grid 4       : canonical reductions; k_compose once per run -> metrics rows
 // All fp64; all cross-lane sums use the canonical orders of dmath.h so results are bitwise
 // independent of scheduling.  No MFMA: the path is sampling + reductions.
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(ES_T) void k_edraw(Dev d, uint32_t t, int from_prio
   if (tid == 0) d.lpE_part[blockIdx.x] = r;
 }
 
-// ---- k_draw: k_pdraw and k_edraw of the steady-state fixed-rank sweep in ONE launch (experiment switch BNMF_GATE) ----
+// ---- k_draw: k_pdraw and k_edraw of the steady-state fixed-rank sweep in ONE launch (large problems: api.hip gate_enabled) ----
 // Workgroups [0, N): factor n's column of P (k_pdraw's work), Psum[n] stored write-through, the last of them raises the flag pd.
 // Workgroups [N, ..): E, DW lanes each: the Gamma(shape, 1) part of the draw needs nothing from P; then the workgroup waits for
 // the flag (one lane polls; the P workgroups have the lowest indices, so they are resident before any E workgroup) and divides
