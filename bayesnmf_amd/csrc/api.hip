@@ -14,6 +14,7 @@
 #include <vector>
 #include "kernels.h"
 #include "zalloc_reg.h"
+#include "zalloc_sort.h"
 #include "zalloc_tile.h"
 #include "rank.h"
 #include "mh.h"
@@ -67,6 +68,9 @@ struct bnmf_handle {
                                        // Gibbs sweep, recorded) during iteration t, one slot ahead of the oldest kept sample
   int z_grid = 0, z_zw = 8, z_ablate = 0; bool z_reg = false; size_t z_lds = 0; ZGeom zg{};
   bool z_tile = false, z_lean = false; ZTGeom ztg{}; double* dMhatZ = nullptr;   // k_zalloc_tile (zalloc_tile.h): N > 24 / large K
+  // k_zalloc_sort (zalloc_sort.h): stats mode, N <= 24 — the static schedule built from M at bnmf_create
+  bool z_sort = false; ZSGeom zsg{}; int zs_nblk = 0, zs_w = 0; size_t zs_lds = 0;
+  uint32_t* dZsItems = nullptr; ZSBlock* dZsBlocks = nullptr; int* dZsCols = nullptr; unsigned long long* dZsProf = nullptr;
   hipEvent_t ev[2 * BNMF_NKERNEL]{};
   bool have_ev = false;
   double* dMap = nullptr; size_t map_words = 0;   // scratch of bnmf_map (grown on demand)
@@ -191,6 +195,97 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
     return rc;
   }
   *out = h;
+  return 0;
+}
+
+// Static schedule of k_zalloc_sort (zalloc_sort.h): columns dealt into blocks of equal total count (largest column first,
+// to the lightest block that still has room), the non-empty cells of a block as items sorted by their number of quads,
+// 64 items per task.  M is fixed for the life of the handle, so this runs once.
+static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
+  const bnmf_config& c = h->cfg;
+  const size_t K = c.K, G = c.G, N = c.N;
+  h->z_sort = false;
+  if (c.save_Z || !h->z_reg || N > (size_t)ZS_NMAX - 1 || K > 1024) return 0;
+  if (const char* e = getenv("BNMF_ZSORT")) if (atoi(e) == 0) return 0;          // diagnostics / tests: the register kernel
+  const int nblk = (int)((N + 4) / 5);                                             // threshold blocks per cell
+  const int KP = (K % 32 == 0) ? (int)K + 1 : (int)(K | 1);
+  size_t budget = 128 * 1024;                                                     // leaves the hyper sweep's workgroups room on the CU
+  if (const char* e = getenv("BNMF_ZSLDS")) budget = (size_t)atol(e) * 1024;
+  long nb = std::min<long>((long)G, n_cu);
+  int GBc = 0, W = 0;
+  for (int tries = 0; tries < 12; ++tries, nb = std::min<long>((long)G, nb * 2)) {
+    GBc = (int)((G + nb - 1) / nb);
+    if (GBc <= 64) {
+      const size_t sh = zsort_shared_bytes((int)K, (int)N, KP, GBc), wv = zsort_wave_bytes(nblk, (int)N);
+      W = 0;
+      for (int w : {16, 12, 8, 6, 4}) if (sh + (size_t)w * wv <= budget) { W = w; break; }
+      if (W) break;
+    }
+    if (nb >= (long)G) break;
+  }
+  if (!W || GBc > 64) return 0;
+  if (const char* e = getenv("BNMF_ZSW")) { const int w = atoi(e); if (w == 4 || w == 6 || w == 8 || w == 12 || w == 16) W = w; }
+  // columns -> blocks
+  std::vector<long> ctot(G, 0);
+  for (size_t g = 0; g < G; ++g) { long sacc = 0; for (size_t k = 0; k < K; ++k) sacc += M[k + K * g]; ctot[g] = sacc; }
+  std::vector<int> order(G);
+  for (size_t g = 0; g < G; ++g) order[g] = (int)g;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ctot[a] > ctot[b]; });
+  std::vector<std::vector<int>> bcols(nb);
+  {
+    // min-heap of (load, block) over the blocks that still have room
+    std::vector<std::pair<long, int>> heap;
+    for (int b = 0; b < nb; ++b) heap.push_back({0L, b});
+    auto cmp = [](const std::pair<long, int>& a, const std::pair<long, int>& b) { return a > b; };
+    std::make_heap(heap.begin(), heap.end(), cmp);
+    for (int g : order) {
+      std::pop_heap(heap.begin(), heap.end(), cmp);
+      auto top = heap.back(); heap.pop_back();
+      bcols[top.second].push_back(g);
+      top.first += ctot[g];
+      if ((int)bcols[top.second].size() < GBc) { heap.push_back(top); std::push_heap(heap.begin(), heap.end(), cmp); }
+    }
+  }
+  std::vector<ZSBlock> blocks(nb);
+  std::vector<int> cols;
+  std::vector<uint32_t> items;
+  std::vector<std::pair<int, uint32_t>> tmp;
+  for (int b = 0; b < nb; ++b) {
+    std::sort(bcols[b].begin(), bcols[b].end());
+    tmp.clear();
+    for (size_t gl = 0; gl < bcols[b].size(); ++gl) {
+      const size_t g = (size_t)bcols[b][gl];
+      for (size_t k = 0; k < K; ++k) {
+        const int m = M[k + K * g];
+        if (m <= 0) continue;
+        const int qt = (m + 3) >> 2;
+        for (int f = 0; f * ZS_QMAX < qt; ++f)
+          tmp.push_back({std::min(ZS_QMAX, qt - f * ZS_QMAX), (uint32_t)k | ((uint32_t)gl << 10) | ((uint32_t)f << 16)});
+      }
+    }
+    std::stable_sort(tmp.begin(), tmp.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+    ZSBlock& bk = blocks[b];
+    bk.item0 = (int)items.size(); bk.col0 = (int)cols.size(); bk.ncols = (int)bcols[b].size();
+    for (const auto& it : tmp) items.push_back(it.second);
+    while (items.size() % 64) items.push_back(0xFFFFFFFFu);
+    bk.ntask = (int)((items.size() - (size_t)bk.item0) / 64);
+    for (int g : bcols[b]) cols.push_back(g);
+  }
+  if (items.empty()) items.push_back(0xFFFFFFFFu);
+  HIPCHK(hipMalloc(&h->dZsItems, items.size() * sizeof(uint32_t)));
+  HIPCHK(hipMemcpy(h->dZsItems, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&h->dZsBlocks, blocks.size() * sizeof(ZSBlock)));
+  HIPCHK(hipMemcpy(h->dZsBlocks, blocks.data(), blocks.size() * sizeof(ZSBlock), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&h->dZsCols, cols.size() * sizeof(int)));
+  HIPCHK(hipMemcpy(h->dZsCols, cols.data(), cols.size() * sizeof(int), hipMemcpyHostToDevice));
+  h->zsg = ZSGeom{KP, GBc, (int)nb};
+  h->zs_nblk = nblk; h->zs_w = W;
+  h->zs_lds = (zsort_shared_bytes((int)K, (int)N, KP, GBc) + (size_t)W * zsort_wave_bytes(nblk, (int)N) + 15) & ~(size_t)15;
+  h->z_sort = true;
+#ifdef ZSPROF
+  HIPCHK(hipMalloc(&h->dZsProf, 8 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(h->dZsProf, 0, 8 * sizeof(unsigned long long)));
+#endif
   return 0;
 }
 
@@ -415,6 +510,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
       }
     }
     if (const char* e = getenv("BNMF_ABLATE")) h->z_ablate = atoi(e);       // diagnostics only
+    if (!h->z_tile && !h->z_ablate) if (int rc = build_zsort(h, M, prop.multiProcessorCount)) return rc;
   }
   HIPCHK(hipStreamSynchronize(h->stream));
   refresh_dev(h);
@@ -433,6 +529,7 @@ int bnmf_destroy(bnmf_handle* h) {
   hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol); if (h->dRankMhat) hipFree(h->dRankMhat); if (h->dRankSync) hipFree(h->dRankSync);
   if (h->E_alt) hipFree(h->E_alt);
   if (h->dMhatZ) hipFree(h->dMhatZ);
+  if (h->dZsItems) hipFree(h->dZsItems); if (h->dZsBlocks) hipFree(h->dZsBlocks); if (h->dZsCols) hipFree(h->dZsCols); if (h->dZsProf) hipFree(h->dZsProf);
   if (h->dMhat) hipFree(h->dMhat); if (h->dAccPn) hipFree(h->dAccPn); if (h->dAccEpart) hipFree(h->dAccEpart); if (h->dNzE) hipFree(h->dNzE);
   if (h->dEt) hipFree(h->dEt); if (h->dMt) hipFree(h->dMt); if (h->zring) hipFree(h->zring);
   if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_rank) hipEventDestroy(h->ev_rank); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); if (h->side) hipStreamDestroy(h->side); if (h->side2) hipStreamDestroy(h->side2);
@@ -531,6 +628,13 @@ int bnmf_debug_rank(bnmf_handle* h, unsigned long long* out, size_t n) {   // di
   if (!h || !h->dRankDbg) return fail(BNMF_ESTATE, "BNMF_RANKDBG not set");
   HIPCHK(hipMemcpy(out, h->dRankDbg, n * 8, hipMemcpyDeviceToHost));
   return h->rank_grid;
+}
+int bnmf_debug_zsort(bnmf_handle* h, unsigned long long* out) {   // diagnostics (-DZSPROF builds): section ticks of k_zalloc_sort, then reset
+  if (!h || !h->dZsProf) return fail(BNMF_ESTATE, "not a -DZSPROF build / kernel not in use");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(out, h->dZsProf, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(h->dZsProf, 0, 8 * sizeof(unsigned long long)));
+  return 0;
 }
 int bnmf_get_iter(bnmf_handle* h, int* iter) { if (!h || !iter) return fail(BNMF_EINVAL, "null"); *iter = h->iter; return 0; }
 
@@ -748,7 +852,36 @@ static int launch_zalloc_t(bnmf_handle* h, uint32_t t) {
   if (!h->z_reg) return launch_z(h, t, k_zalloc<SZ, ZT_>, h->dev, ZT_);
   return h->z_ablate ? launch_zreg_t<SZ, ZT_, true>(h, t) : launch_zreg_t<SZ, ZT_, false>(h, t);   // DIAG build honours BNMF_ABLATE
 }
+template <int ZT_>
+static int launch_zsort_t(bnmf_handle* h, uint32_t t) {
+  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsProf};
+  auto go = [&](auto kern) -> int {
+    if (h->z_attr_kernel != (const void*)kern) {
+      HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      h->z_attr_kernel = (const void*)kern;
+    }
+    hipLaunchKernelGGL(kern, dim3(h->zsg.nblocks), dim3(ZT_), h->zs_lds, h->stream, sa, t, h->zsg);
+    return 0;
+  };
+  switch (h->zs_nblk) {
+    case 1: return go(k_zalloc_sort<ZT_, 1>);
+    case 2: return go(k_zalloc_sort<ZT_, 2>);
+    case 3: return go(k_zalloc_sort<ZT_, 3>);
+    case 4: return go(k_zalloc_sort<ZT_, 4>);
+    default: return go(k_zalloc_sort<ZT_, 5>);
+  }
+}
+static int launch_zsort(bnmf_handle* h, uint32_t t) {
+  switch (h->zs_w) {
+    case 16: return launch_zsort_t<1024>(h, t);
+    case 12: return launch_zsort_t<768>(h, t);
+    case 8: return launch_zsort_t<512>(h, t);
+    case 6: return launch_zsort_t<384>(h, t);
+    default: return launch_zsort_t<256>(h, t);
+  }
+}
 static int launch_zalloc(bnmf_handle* h, uint32_t t) {
+  if (h->z_sort) return launch_zsort(h, t);
   const bool sz = h->cfg.save_Z != 0;
   switch (h->z_zw) {
     case 16: return sz ? launch_zalloc_t<true, 1024>(h, t) : launch_zalloc_t<false, 1024>(h, t);

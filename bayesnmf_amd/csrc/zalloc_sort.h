@@ -1,0 +1,251 @@
+// bayesnmf_amd/csrc/zalloc_sort.h — k_zalloc_sort: the Z-allocation kernel of the stats mode for N <= 25 (the metric
+// configuration: K = 96, G = 10,000, N = 20).  Same stream spec, bit-identical ZsumK / ZsumG / metric partials as
+// k_zalloc_reg and k_zalloc; different machine mapping.
+//
+// M never changes during a chain, so the work is scheduled ONCE, on the host, at bnmf_create (api.hip build_zsort):
+//   * the columns are dealt into blocks of equal total count (one workgroup per block, one block per CU);
+//   * inside a block every non-empty cell becomes an item (cells above 4*ZS_QMAX counts: several items, each a run of
+//     ZS_QMAX Philox blocks of the cell's stream); the items are sorted by their number of quads and cut into tasks of
+//     64: a task is 64 cells with (nearly) the same number of counts.
+// A wavefront takes a task at a time (LDS ticket): LANE = ITEM.  The lane builds its cell's thresholds once — the
+// pivots (every 5th threshold) stay in registers, the others go to the lane's own column of the wave's LDS slab as
+// 128-bit blocks [block][lane] (conflict-free by construction) — and then runs its quads: Philox block, pivot compares
+// in registers, ONE 128-bit LDS read, four compares, one LDS atomic into the lane's private packed 16-bit histogram.
+// No cell switch, no prefix scan, no random LDS address inside the loop.  The histogram is flushed per item into the
+// block's zG[n][k] / zK[n][column] (LDS atomics), those once per block into ZsumG (global integer atomics: exact,
+// order-independent) and ZsumK (plain stores: a column belongs to one block).  The per-column metric terms need the
+// canonical W = 64 order over the rows: they are separate small tasks (lane = row) at the end of the block's task list.
+// (sample_Zkg R/sample_params.R:253-265; metrics R/utils.R:412-471)
+#pragma once
+
+namespace bnmf {
+
+constexpr int ZS_QMAX = 32;          // quads per item (128 counts): larger cells are split
+constexpr int ZS_NMAX = 25;          // 5 blocks of 4 thresholds + 4 pivots = 24 thresholds
+
+struct ZSBlock { int item0, ntask, col0, ncols; };   // items [item0, item0 + 64 ntask), columns cols[col0 .. col0 + ncols)
+struct ZSGeom { int KP, GBc, nblocks; };              // pitch of zG rows, column capacity of a block
+struct ZSArgs {
+  ZArgs a;
+  const uint32_t* items;             // k | gl << 10 | fragment << 16; 0xFFFFFFFF = empty lane
+  const ZSBlock* blocks;
+  const int* cols;
+  unsigned long long* prof;          // -DZSPROF builds only: per-section s_memtime ticks summed over the waves (diagnostics)
+};
+// -DZSPROF: section timers.  [0] block set-up, [1] thresholds, [2] quad loops, [3] histogram flush, [4] metric tasks,
+// [5] end barrier + epilogue, [6] whole kernel, [7] waves.  Never defined in the product build.
+#ifdef ZSPROF
+#define ZSTIC(i) const uint64_t zstic_##i = __builtin_amdgcn_s_memtime()
+#define ZSTOC(i) zsprof[i] += __builtin_amdgcn_s_memtime() - zstic_##i
+#else
+#define ZSTIC(i)
+#define ZSTOC(i)
+#endif
+// host and device agree on the LDS layout through these
+#define BNMF_HD __host__ __device__ inline
+BNMF_HD size_t zsort_shared_bytes(int K, int N, int KP, int GBc) {
+  size_t w = (size_t)N * KP + (size_t)N * GBc + (size_t)K * GBc + GBc + 4;   // zG, zK, Ms, colid, ticket (32-bit words)
+  w = (w + 3) & ~(size_t)3;
+  return (w * 4 + ((size_t)K * N + (size_t)N * GBc) * 8 + 15) & ~(size_t)15;   // + Pl, ae (fp64); the waves' slabs are 16-byte aligned
+}
+BNMF_HD size_t zsort_wave_bytes(int NBLK, int N) { return (size_t)NBLK * 64 * 16 + (size_t)((N + 1) / 2) * 64 * 4; }
+
+template <int ZT, int NBLK /* threshold blocks per cell: covers N <= 5 NBLK */>
+__global__ __launch_bounds__(ZT) void k_zalloc_sort(ZSArgs s, uint32_t t, ZSGeom zg) {
+  constexpr int NPV = NBLK - 1;                           // pivots: threshold 5j + 4 closes block j
+  constexpr int NC = 5 * NBLK;                            // factors covered
+  constexpr int NMIN = NBLK == 1 ? 1 : 5 * (NBLK - 1) + 1; // smallest N routed here
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const ZArgs& d = s.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = d.K, N = d.N, KP = zg.KP, GBc = zg.GBc;
+  const int KR = (K + 63) >> 6;
+  const ZSBlock bk = s.blocks[blockIdx.x];
+  uint32_t* zG = (uint32_t*)smem;                          // [N][KP]
+  uint32_t* zK = zG + (size_t)N * KP;                      // [N][GBc]
+  int* Ms = (int*)(zK + (size_t)N * GBc);                  // [GBc][K] counts of the block's columns
+  int* colid = Ms + (size_t)K * GBc;                       // [GBc]
+  uint32_t* ticket = (uint32_t*)(colid + GBc);
+  const size_t w32 = (((size_t)N * KP + (size_t)N * GBc + (size_t)K * GBc + GBc + 4) + 3) & ~(size_t)3;
+  double* Pl = (double*)(smem + w32 * 4);                  // [N][K]
+  double* ae = Pl + (size_t)K * N;                         // [N][GBc]  A[n] E[n, column]
+  unsigned char* wbase = smem + zsort_shared_bytes(K, N, KP, GBc) + (size_t)wave * zsort_wave_bytes(NBLK, N);
+  u4* tblk = (u4*)wbase;                                   // [NBLK][64]
+  uint32_t* hist = (uint32_t*)(tblk + NBLK * 64);          // [(N+1)/2][64] packed 16-bit bucket counts of the lane's item
+  const int HW = (N + 1) >> 1;
+#ifdef ZSPROF
+  uint64_t zsprof[8] = {0, 0, 0, 0, 0, 0, 0, 1};
+#endif
+  ZSTIC(6);
+  ZSTIC(0);
+  // ---------------- block set-up
+  for (int i = tid; i < N * KP; i += ZT) zG[i] = 0;
+  for (int i = tid; i < N * GBc; i += ZT) zK[i] = 0;
+  for (int i = tid; i < bk.ncols; i += ZT) colid[i] = s.cols[bk.col0 + i];
+  if (tid == 0) *ticket = 0;
+  for (int i = tid; i < K * N; i += ZT) Pl[i] = d.P[i];
+  for (int i = lane; i < HW * 64; i += 64) hist[i] = 0;
+  for (int i = tid; i < N * bk.ncols; i += ZT) {
+    const int gl = i / N, n = i - gl * N;
+    const int g = s.cols[bk.col0 + gl];
+    ae[(size_t)n * GBc + gl] = d.A[n] * d.E[n + (size_t)N * g];
+  }
+  for (int gl = wave; gl < bk.ncols; gl += ZT / 64) {
+    const int g = s.cols[bk.col0 + gl];
+    for (int k = lane; k < K; k += 64) Ms[k + (size_t)K * gl] = d.M[k + (size_t)K * g];
+  }
+  __syncthreads();
+  ZSTOC(0);
+  const int nthr = N - 1;
+  const int ntot = bk.ntask + bk.ncols;
+  const uint32_t hlb = lds_off(hist + lane);
+  // the next task of the block: lane 0 draws a ticket, every lane reads lane 0's (readlane: whatever EXEC is)
+  auto next_task = [&]() -> int {
+    int tk = 0;
+    if (lane == 0) tk = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __builtin_amdgcn_readlane(tk, 0);
+  };
+  for (int task = next_task(); task < ntot; task = next_task()) {
+    if (task >= bk.ntask) {
+      ZSTIC(4);
+      // ---------------- metric task: one column, lane = row, canonical W = 64 sums (as phase 1 of k_zalloc_reg)
+      const int gl = task - bk.ntask, g = colid[gl];
+      double a_sse = 0.0, a_ll = 0.0, a_kl = 0.0;
+      for (int r = 0; r < KR; ++r) {
+        const int kk = (r << 6) + lane;
+        if (kk < K) {
+          const int m = Ms[kk + (size_t)K * gl];
+          const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
+          const double lgf = d.lgfact[mi], lgm = d.logm[mi];
+          double c = 0.0;
+#pragma unroll
+          for (int n = 0; n < NC; ++n) if (n < NMIN || n < N) c = c + Pl[kk + (size_t)K * n] * ae[(size_t)n * GBc + gl];
+          const double dd = c - (double)m;
+          const double mh = c < 1e-6 ? 1e-6 : c;
+          const double lmh = dlog(mh);
+          const double mt = m < 1 ? 1e-6 : (double)m;
+          a_sse = a_sse + dd * dd;
+          a_ll = a_ll + (((double)m * lmh - mh) - lgf);
+          a_kl = a_kl + mt * (lgm - lmh);
+        }
+      }
+      a_sse = wave_tree64(a_sse); a_ll = wave_tree64(a_ll); a_kl = wave_tree64(a_kl);
+      if (lane == 0) { d.colsse[g] = a_sse; d.colll[g] = a_ll; d.colkl[g] = a_kl; }
+      ZSTOC(4);
+    } else {
+    // ---------------- item task: lane = item
+    ZSTIC(1);
+    const uint32_t it = s.items[(size_t)bk.item0 + (size_t)task * 64 + lane];
+    const bool valid = it != 0xFFFFFFFFu;
+    const int k = valid ? (int)(it & 1023u) : 0, gl = valid ? (int)((it >> 10) & 63u) : 0;
+    const int q0 = valid ? (int)(it >> 16) * ZS_QMAX : 0;
+    const int m = Ms[k + (size_t)K * gl];
+    const int g = colid[gl];
+    int nq = 0, npad = 0;
+    uint32_t pv[NPV > 0 ? NPV : 1];
+    {
+      // Mhat = sum_n P[k,n] (A[n] E[n,g]) in factor order; thr_n = floor(cum_n 2^32 / Mhat) saturating at 2^32 - 1 = "never"
+      // (factors at/after the last positive one saturate by themselves, see zalloc_reg.h)
+      double pk[NC], ak[NC];
+#pragma unroll
+      for (int n = 0; n < NC; ++n) {
+        const bool on = n < NMIN || n < N;
+        pk[n] = on ? Pl[k + (size_t)K * n] : 0.0;
+        ak[n] = on ? ae[(size_t)n * GBc + gl] : 0.0;
+      }
+      double c = 0.0;
+#pragma unroll
+      for (int n = 0; n < NC; ++n) if (n < NMIN || n < N) c = c + pk[n] * ak[n];
+      if (valid && c > 0.0 && m > 0) {
+        const int qt = (m + 3) >> 2;
+        nq = min(ZS_QMAX, qt - q0);
+        npad = (q0 + nq == qt) ? ((4 - (m & 3)) & 3) : 0;
+      }
+      const double scale = 4294967296.0 / c;
+      double c2 = 0.0;
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) {
+        uint32_t tv[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          const int n = 5 * j + i;
+          tv[i] = 0xFFFFFFFFu;
+          if (n < NC - 1 && (n < NMIN - 1 || n < nthr)) { c2 = c2 + pk[n] * ak[n]; tv[i] = cvt_u32_sat(c2 * scale); }
+        }
+        tblk[j * 64 + lane] = u4{tv[0], tv[1], tv[2], tv[3]};
+        if (j < NPV) pv[j] = tv[4];
+      }
+    }
+    const uint32_t celem = (uint32_t)k + (uint32_t)K * (uint32_t)g;
+    // one quad: Philox block q of the cell's stream -> 4 words -> 4 buckets -> 4 histogram increments (inc: 1, or 0 for a pad)
+    auto quad = [&](int qidx, uint32_t inc0, uint32_t inc1, uint32_t inc2, uint32_t inc3) {
+      const u32x4 w = philox4x32_10((uint32_t)qidx, celem, t, BNMF_V_Z, d.k0, d.k1);
+      const uint32_t u0 = min(w.x, 0xFFFFFFFEu), u1 = min(w.y, 0xFFFFFFFEu), u2 = min(w.z, 0xFFFFFFFEu), u3 = min(w.w, 0xFFFFFFFEu);
+      uint32_t j0 = 0, j1 = 0, j2 = 0, j3 = 0;
+#pragma unroll
+      for (int p = 0; p < NPV; ++p) cmp_acc4(pv[p], u0, u1, u2, u3, j0, j1, j2, j3);
+      const u4 k0 = tblk[j0 * 64 + lane], k1 = tblk[j1 * 64 + lane], k2 = tblk[j2 * 64 + lane], k3 = tblk[j3 * 64 + lane];
+      const uint32_t b0 = 5 * j0 + (k0.x <= u0) + (k0.y <= u0) + (k0.z <= u0) + (k0.w <= u0);
+      const uint32_t b1 = 5 * j1 + (k1.x <= u1) + (k1.y <= u1) + (k1.z <= u1) + (k1.w <= u1);
+      const uint32_t b2 = 5 * j2 + (k2.x <= u2) + (k2.y <= u2) + (k2.z <= u2) + (k2.w <= u2);
+      const uint32_t b3 = 5 * j3 + (k3.x <= u3) + (k3.y <= u3) + (k3.z <= u3) + (k3.w <= u3);
+      lds_add(mad24(b0 >> 1, 256, hlb), inc0 << ((b0 & 1) << 4));
+      lds_add(mad24(b1 >> 1, 256, hlb), inc1 << ((b1 & 1) << 4));
+      lds_add(mad24(b2 >> 1, 256, hlb), inc2 << ((b2 & 1) << 4));
+      lds_add(mad24(b3 >> 1, 256, hlb), inc3 << ((b3 & 1) << 4));
+    };
+    wave_lds_fence();
+    ZSTOC(1);
+    ZSTIC(2);
+    // full quads, then each lane's last quad (the only one that can hold pads)
+    for (int i = 0; __builtin_amdgcn_ballot_w64(i < nq - 1) != 0; ++i)
+      if (i < nq - 1) quad(q0 + i, 1u, 1u, 1u, 1u);
+    if (nq > 0) quad(q0 + nq - 1, 1u, npad > 2 ? 0u : 1u, npad > 1 ? 0u : 1u, npad > 0 ? 0u : 1u);
+    wave_lds_fence();
+    ZSTOC(2);
+    ZSTIC(3);
+    // flush the lane's histogram into the block's tables
+    if (nq > 0) {
+      const uint32_t zgb = lds_off(zG) + ((uint32_t)k << 2), zkb = lds_off(zK) + ((uint32_t)gl << 2);
+      for (int w = 0; w < HW; ++w) {
+        const uint32_t v = hist[w * 64 + lane];
+        if (v) {
+          hist[w * 64 + lane] = 0;
+          const uint32_t lo = v & 0xFFFFu, hi = v >> 16;
+          if (lo) { lds_add(zgb + (uint32_t)(2 * w) * (uint32_t)KP * 4u, lo); lds_add(zkb + (uint32_t)(2 * w) * (uint32_t)GBc * 4u, lo); }
+          if (hi) { lds_add(zgb + (uint32_t)(2 * w + 1) * (uint32_t)KP * 4u, hi); lds_add(zkb + (uint32_t)(2 * w + 1) * (uint32_t)GBc * 4u, hi); }
+        }
+      }
+    }
+    wave_lds_fence();
+    ZSTOC(3);
+    }
+  }
+  ZSTIC(5);
+  __syncthreads();
+  // ---------------- block epilogue: ZsumK of the block's columns (plain stores), ZsumG (global integer atomics)
+  for (int i = tid; i < N * bk.ncols; i += ZT) {
+    const int gl = i / N, n = i - gl * N;
+    d.ZsumK[n + (size_t)N * colid[gl]] = (int32_t)zK[(size_t)n * GBc + gl];
+  }
+  for (int i = tid; i < K * N; i += ZT) {
+    const int kk = i % K, n = i / K;
+    const uint32_t v = zG[(size_t)n * KP + kk];
+    if (v) atomicAdd(&d.ZsumG[kk + (size_t)K * n], (int32_t)v);
+  }
+  ZSTOC(5);
+  ZSTOC(6);
+#ifdef ZSPROF
+  if (s.prof && lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&s.prof[i], (unsigned long long)zsprof[i]);
+#endif
+  if (d.gate0 && blockIdx.x == 0 && tid == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(d.gate0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < d.gate_epoch ||
+           __hip_atomic_load(d.gate1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < d.gate_epoch) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 24)) { __hip_atomic_store(d.gate_err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+}
+
+}  // namespace bnmf
