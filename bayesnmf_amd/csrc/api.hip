@@ -168,6 +168,17 @@ int bnmf_device_info(int device, char* buf, size_t buflen) {
 }
 
 static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h);
+// lgamma / digamma table of the Alpha sampler's tangent points (dsamplers.h g_alut): filled once per device
+static int ensure_alut(int device) {
+  static bool done[64] = {};
+  if (device < 0 || device >= 64) return fail(BNMF_EINVAL, "device %d out of range", device);
+  if (done[device]) return 0;
+  hipLaunchKernelGGL(k_alut_fill, dim3((ALUT_N + 255) / 256), dim3(256), 0, 0);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  done[device] = true;
+  return 0;
+}
 
 int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
   if (!cfg || !M || !out) return fail(BNMF_EINVAL, "bnmf_create: null argument");
@@ -185,6 +196,7 @@ int bnmf_create(const bnmf_config* cfg, const int32_t* M, bnmf_handle** out) {
     if (cfg->prior == BNMF_TRUNCNORMAL && !cfg->MH) return fail(BNMF_EMODEL, "truncnormal prior can only be used in a MH-within-gibbs sampler");
   } else return fail(BNMF_EMODEL, "likelihood must be one of normal, poisson");
   HIPCHK(hipSetDevice(cfg->device));
+  if (int rc = ensure_alut(cfg->device)) return rc;
   bnmf_handle* h = new bnmf_handle();
   h->cfg = *cfg;
   h->device = cfg->device;
@@ -1604,6 +1616,7 @@ int bnmf_test_math(int device, int fn, const double* in, double* out, size_t n) 
 int bnmf_test_sampler(int device, int which, uint64_t seed, uint32_t chain, uint32_t var, uint32_t elem0, uint32_t iter,
                       const double* a, const double* b, const double* c, double* out, size_t n) {
   HIPCHK(hipSetDevice(device));
+  if (int rc = ensure_alut(device)) return rc;
   double *da, *db, *dc, *dou;
   HIPCHK(hipMalloc(&da, n * sizeof(double))); HIPCHK(hipMalloc(&db, n * sizeof(double)));
   HIPCHK(hipMalloc(&dc, n * sizeof(double))); HIPCHK(hipMalloc(&dou, n * sizeof(double)));

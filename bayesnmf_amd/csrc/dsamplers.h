@@ -196,4 +196,74 @@ BNMF_DEV double ralpha(Stream& s, double c, double tau, double xprev, int* n_att
   return xs;
 }
 
+
+// ---- Gamma-shape hyper-parameter, fast path (what the hyper sweep calls; the CPU checker restates it op for op) ----
+// -lgamma is concave: its tangent at x0 gives a Gamma(c, tau + psi(x0)) envelope of f(x) ~ x^(c-1) e^(-tau x) / Gamma(x);
+// x ~ Gamma(c, r) by Marsaglia-Tsang, kept with probability exp(lgamma(x0) + psi(x0)(x - x0) - lgamma(x)); one uniform for
+// both acceptance tests, one Philox block per attempt.  x0 = grid point (doubles with 6 mantissa bits; lgamma / digamma
+// tabulated once per device in g_alut) below two Newton steps from the previous value.  c <= 1, r <= 0 or 64 rejections in
+// a row: the general 3-tangent sampler ralpha, on the same stream.
+constexpr int ALUT_I0 = 1013 << 6;     // 2^-10 <= 1e-3
+constexpr int ALUT_N = 24 * 64;        // up to 2^14 > 1e4
+__device__ double g_alut[2 * ALUT_N];
+BNMF_DEV double alut_x(int i) { return __longlong_as_double((long long)((uint64_t)((uint32_t)(i + ALUT_I0) << 14) << 32)); }
+BNMF_DEV int alut_idx(double x) {
+  const int i = (int)((uint32_t)((uint64_t)__double_as_longlong(x) >> 32) >> 14) - ALUT_I0;
+  return i < 0 ? 0 : (i > ALUT_N - 1 ? ALUT_N - 1 : i);
+}
+__global__ void k_alut_fill() {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ALUT_N) { double lg, dg; lgamma_digamma<true>(alut_x(i), lg, dg); g_alut[2 * i] = lg; g_alut[2 * i + 1] = dg; }
+}
+constexpr int FAST_ATTEMPTS = 64;
+BNMF_DEV double ralpha_fast(Stream& s, double c, double tau, double xprev, int* n_attempts = nullptr) {
+  const double L = 1e-3, U = 1e4;
+  if (!(c > 1.0)) return ralpha(s, c, tau, xprev, n_attempts);
+  double x = xprev;
+  if (!(x >= L)) x = L;
+  if (x > U) x = U;
+  const double cm1 = c - 1.0;
+  for (int it = 0; it < 12; ++it) {    // H(x) = (c-1)/x - tau - psi(x), psi from the table, psi'(x) ~ 1/x + 1/x^2
+    const int i = alut_idx(x);
+    const double xg = alut_x(i), psi = g_alut[2 * i + 1];
+    const double inv = 1.0 / xg;
+    const double H = (cm1 * inv - tau) - psi;
+    const double dH = -cm1 * (inv * inv) - (inv + inv * inv);
+    double xn = xg - H / dH;
+    if (!(xn > 0.1 * xg)) xn = 0.1 * xg;
+    if (xn > 10.0 * xg) xn = 10.0 * xg;
+    if (xn < L) xn = L;
+    if (xn > U) xn = U;
+    const double dx = dabs(xn - xg);
+    x = xn;
+    if (dx <= 0.03 * xg) break;
+  }
+  const int i0 = alut_idx(x);
+  const double x0 = alut_x(i0), lg0 = g_alut[2 * i0], psi0 = g_alut[2 * i0 + 1];
+  const double r = tau + psi0;
+  // expected acceptance ~ 1 / sqrt(1 + rho), rho = psi'(x0) var(x): a broad or skewed target (small c) goes to the general sampler
+  const double i0v = 1.0 / x0, tri = i0v + i0v * i0v;
+  const double rho = tri / (cm1 * (i0v * i0v) + tri);
+  if (!(r > 0.0) || !(rho < 0.35)) return ralpha(s, c, tau, xprev, n_attempts);
+  const double d = c - 0.333333333333333333333;
+  const double cc = 1.0 / dsqrt(9.0 * d);
+  const double b0 = lg0 - psi0 * x0;
+  for (int it = 0; it < FAST_ATTEMPTS; ++it) {
+    const u32x4 w = s.next();
+    const double z = dqnorm(u52(w.x, w.y));
+    const double u = u52(w.z, w.w);
+    double v = 1.0 + cc * z;
+    if (v <= 0.0) continue;
+    v = v * v * v;
+    const double xs = (d * v) / r;
+    if (!(xs >= L && xs <= U)) continue;
+    const double rhs = (0.5 * (z * z) + d * ((1.0 - v) + dlog(v))) + ((b0 + psi0 * xs) - dlgamma(xs));
+    if (dlog(u) < rhs) { if (n_attempts) *n_attempts = it + 1; return xs; }
+  }
+  int na = 0;
+  const double xs = ralpha(s, c, tau, xprev, &na);
+  if (n_attempts) *n_attempts = FAST_ATTEMPTS + na;
+  return xs;
+}
+
 }  // namespace bnmf

@@ -105,7 +105,7 @@ BNMF_DEV void hyper_elem(const Dev& d, int e, uint32_t t, double v, double* rec0
     if (rec1) rec1[e] = b;
     const double tau = (hy(hD, e) - dlog(clamp_tiny(b))) - dlog(clamp_tiny(v));
     Stream s2(d.k0, d.k1, SIDE ? BNMF_V_ALPHA_E : BNMF_V_ALPHA_P, (uint32_t)e, t);
-    const double al = ralpha(s2, hy(hC, e), tau, al_old);                   // sample_Alpha_* :356-397
+    const double al = ralpha_fast(s2, hy(hC, e), tau, al_old);              // sample_Alpha_* :356-397
     st_wt(&slot<SIDE>(d, Al, t)[e], al);
     if (rec0) rec0[e] = al;
   } else if (d.prior == BNMF_EXPONENTIAL) {
@@ -867,6 +867,7 @@ __global__ void k_test_sampler(int which, uint32_t k0, uint32_t k1, uint32_t var
     case 1: r = rtnorm0(s, a[i], b[i]); break;
     case 2: r = rnorm_std(s); break;
     case 3: r = ralpha(s, a[i], b[i], c[i]); break;
+    case 6: r = ralpha_fast(s, a[i], b[i], c[i]); break;
     case 4: r = runif(s); break;
     case 5: r = rexp(s, a[i]); break;
     default: r = BNMF_NAN;

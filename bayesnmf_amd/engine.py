@@ -26,7 +26,7 @@ LIKELIHOOD = dict(poisson=0, normal=1)
 PRIOR = dict(truncnormal=0, exponential=1, gamma=2)
 RANK_METHOD = dict(SBFI=0, BFI=1)
 MATH_FN = dict(log=0, exp=1, lgamma=2, digamma=3, qnorm=4, log_pnorm=5, sqrt=6, recip=7)
-SAMPLER = dict(rgamma=0, rtnorm0=1, rnorm=2, ralpha=3, runif=4, rexp=5)
+SAMPLER = dict(rgamma=0, rtnorm0=1, rnorm=2, ralpha=3, runif=4, rexp=5, ralpha_fast=6)
 
 
 class BnmfError(RuntimeError):

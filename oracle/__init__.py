@@ -76,6 +76,7 @@ def lib():
         L.orc_t_rtnorm0.argtypes = hdr + [dp, dp, dp, C.c_long]
         L.orc_t_rnorm.argtypes = hdr + [dp, C.c_long]
         L.orc_t_ralpha.argtypes = hdr + [dp, dp, dp, dp, ip, C.c_long]
+        L.orc_t_ralpha_fast.argtypes = hdr + [dp, dp, dp, dp, ip, C.c_long]
         L.orc_t_alpha_h.argtypes = [C.c_double, C.c_double, C.c_double, dp, dp]
         _LIB = L
     return _LIB
@@ -129,14 +130,15 @@ def rnorm(n, seed=1, chain=0, var=8, elem0=0, it=1):
     return out
 
 
-def ralpha(c, tau, xprev, seed=1, chain=0, var=5, elem0=0, it=1):
+def ralpha(c, tau, xprev, seed=1, chain=0, var=5, elem0=0, it=1, fast=False):
+    """fast=False: the general 3-tangent sampler; fast=True: the Gamma-envelope sampler the sweep uses (falls back to the general one)."""
     c = np.ascontiguousarray(c, dtype=np.float64)
     tau = np.ascontiguousarray(np.broadcast_to(tau, c.shape), dtype=np.float64)
     xprev = np.ascontiguousarray(np.broadcast_to(xprev, c.shape), dtype=np.float64)
     out = np.empty_like(c)
     att = np.empty(c.size, dtype=np.int32)
-    lib().orc_t_ralpha(seed, chain, var, elem0, it, _dp(c), _dp(tau), _dp(xprev), _dp(out),
-                       att.ctypes.data_as(C.POINTER(C.c_int32)), c.size)
+    (lib().orc_t_ralpha_fast if fast else lib().orc_t_ralpha)(seed, chain, var, elem0, it, _dp(c), _dp(tau), _dp(xprev), _dp(out),
+                                                               att.ctypes.data_as(C.POINTER(C.c_int32)), c.size)
     return out, att
 
 

@@ -190,7 +190,7 @@ static void hyper_elem(orc_handle* o, int side /*0=p,1=e*/, long e, uint32_t t) 
     /* sample_Alpha_Pkn / _Eng  R/sample_priors.R:356-397 */
     double tau = (HY(idD, e) - orc_log(clamp_tiny(b))) - orc_log(clamp_tiny(v));
     orc_stream s2 = ST(o, side ? V_ALPHA_E : V_ALPHA_P, (uint32_t)e, t);
-    Al[e] = orc_ralpha(&s2, HY(idC, e), tau, Al[e], NULL);
+    Al[e] = orc_ralpha_fast(&s2, HY(idC, e), tau, Al[e], NULL);
   } else if (pr == PRIOR_EXPONENTIAL) {
     /* sample_Lambda_Pn / _En  R/sample_priors.R:284-308 */
     int idA = side ? ID_HA_E : ID_HA_P, idB = side ? ID_HB_E : ID_HB_P;
@@ -947,5 +947,9 @@ void orc_t_rnorm(uint64_t seed, uint32_t chain, uint32_t var, uint32_t elem0, ui
 void orc_t_ralpha(uint64_t seed, uint32_t chain, uint32_t var, uint32_t elem0, uint32_t iter,
                   const double* c, const double* tau, const double* xprev, double* out, int32_t* attempts, long n) {
   for (long e = 0; e < n; ++e) { orc_stream s = orc_stream_make(seed, chain, var, elem0 + (uint32_t)e, iter); int na; out[e] = orc_ralpha(&s, c[e], tau[e], xprev[e], &na); if (attempts) attempts[e] = na; }
+}
+void orc_t_ralpha_fast(uint64_t seed, uint32_t chain, uint32_t var, uint32_t elem0, uint32_t iter,
+                       const double* c, const double* tau, const double* xprev, double* out, int32_t* attempts, long n) {
+  for (long e = 0; e < n; ++e) { orc_stream s = orc_stream_make(seed, chain, var, elem0 + (uint32_t)e, iter); int na; out[e] = orc_ralpha_fast(&s, c[e], tau[e], xprev[e], &na); if (attempts) attempts[e] = na; }
 }
 void orc_t_alpha_h(double x, double c, double tau, double* h, double* hp) { orc_alpha_h(x, c, tau, h, hp); }

@@ -46,5 +46,6 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "math_kat.npz"), x=x, log=O.vec("log", x), exp=O.vec("exp", np.log(x)), xin_exp=np.log(x),
                         lgamma=O.vec("lgamma", x), digamma=O.vec("digamma", x), p=p, qnorm=O.vec("qnorm", p),
                         rgamma=O.rgamma(np.full(16, 6.5), 10.0, var=2, it=3), rtnorm0=O.rtnorm0(np.linspace(-3, 3, 16), 1.0, var=3, it=4),
-                        ralpha=O.ralpha(np.full(16, 65.0), 6.0, 6.5, var=5, it=5)[0])
+                        ralpha=O.ralpha(np.full(16, 65.0), 6.0, 6.5, var=5, it=5)[0],
+                        ralpha_fast=O.ralpha(np.full(16, 65.0), 6.0, 6.5, var=5, it=5, fast=True)[0])
     print("golden fixtures written to", HERE)

@@ -80,6 +80,11 @@ def test_samplers_bitexact_vs_oracle(oracle_lib):
     a = E.test_sampler("ralpha", c, tau, xp, var=5, it=7)
     b, _ = O.ralpha(c, tau, xp, var=5, it=7)
     assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    # the Gamma-envelope sampler of the sweep, on the wide grid and in the regime of the default hyper-parameters
+    for cc, tt, xx in ((c, tau, xp), (rng.uniform(20, 200, n), rng.uniform(0.5, 12, n), rng.uniform(1, 30, n))):
+        a = E.test_sampler("ralpha_fast", cc, tt, xx, var=7, it=8)
+        b, _ = O.ralpha(cc, tt, xx, var=7, it=8, fast=True)
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
 
 
 @pytest.mark.parametrize("prior", ["gamma", "exponential"])

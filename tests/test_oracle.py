@@ -77,24 +77,44 @@ def test_rtnorm_law(oracle_lib, mu, sd):   # truncnorm::rtruncnorm(a = 0, b = In
 
 @pytest.mark.parametrize("c,tau,xp", [(65.0, 6.0, 6.5), (65.0, 6.0, 5000.0), (1.0, 0.5, 1.0), (0.3, 2.0, 1.0),
                                       (200.0, -1.0, 10.0), (65.0, -8.5, 100.0), (2.0, 700.0, 1.0), (3000.0, 0.1, 1.0)])
-def test_ralpha_law(oracle_lib, c, tau, xp):
-    """The armspp::arms target of R/sample_priors.R:356-397 on [1e-3, 1e4], against its numerical CDF."""
-    x, att = oracle_lib.ralpha(np.full(20000, c), tau, xp, it=5)
+@pytest.mark.parametrize("fast", [False, True])
+def test_ralpha_law(oracle_lib, c, tau, xp, fast):
+    """The armspp::arms target of R/sample_priors.R:356-397 on [1e-3, 1e4], against its numerical CDF: the general
+    3-tangent sampler and the Gamma-envelope sampler the sweep uses (which falls back to the general one)."""
+    x, att = oracle_lib.ralpha(np.full(20000, c), tau, xp, it=5, fast=fast)
     xs = np.concatenate([np.linspace(1e-3, 1, 100001), np.linspace(1, 50, 200001)[1:], np.linspace(50, 1e4, 400001)[1:]])
     h = (c - 1) * np.log(xs) - tau * xs - sp.gammaln(xs)
     f = np.exp(h - h.max())
     cdf = np.concatenate([[0], np.cumsum(0.5 * (f[1:] + f[:-1]) * np.diff(xs))])
     cdf /= cdf[-1]
     assert st.kstest(x, lambda v: np.interp(v, xs, cdf)).pvalue > 1e-3
-    assert att.mean() < 1.4 and att.max() < 40     # 3-tangent hull: acceptance ~ 0.886
+    assert att.mean() < 1.4 and att.max() < 40     # 3-tangent hull: acceptance ~ 0.886; Gamma envelope ~ 0.94 at the defaults
+
+
+@pytest.mark.parametrize("c,tau,xp", [(65.0, 9.0, 6.5), (65.0, 3.0, 7.0), (10.0, 0.5, 3.0), (20.0, 4.0, 1e-3), (4.0, 2.0, 1.0), (120.0, 14.0, 2.0)])
+def test_ralpha_fast_law(oracle_lib, c, tau, xp):
+    """More of the Gamma-envelope sampler: the regime of the default hyper-parameters (c = 10 sqrt(mean M), d = 10), far
+    starting points, small shapes."""
+    x, att = oracle_lib.ralpha(np.full(40000, c), tau, xp, it=9, fast=True)
+    xs = np.concatenate([np.linspace(1e-3, 1, 100001), np.linspace(1, 50, 200001)[1:], np.linspace(50, 1e4, 400001)[1:]])
+    h = (c - 1) * np.log(xs) - tau * xs - sp.gammaln(xs)
+    f = np.exp(h - h.max())
+    cdf = np.concatenate([[0], np.cumsum(0.5 * (f[1:] + f[:-1]) * np.diff(xs))])
+    cdf /= cdf[-1]
+    assert st.kstest(x, lambda v: np.interp(v, xs, cdf)).pvalue > 1e-3
+    assert att.mean() < 2.0
 
 
 def test_ralpha_robust_grid(oracle_lib):
     rng = np.random.default_rng(1)
     n = 20000
-    x, att = oracle_lib.ralpha(10 ** rng.uniform(-2, 3.5, n), rng.uniform(-9, 50, n), 10 ** rng.uniform(-3, 4, n), it=6)
+    c, tau, xp = 10 ** rng.uniform(-2, 3.5, n), rng.uniform(-9, 50, n), 10 ** rng.uniform(-3, 4, n)
+    x, att = oracle_lib.ralpha(c, tau, xp, it=6)
     assert np.isfinite(x).all() and (x >= 1e-3).all() and (x <= 1e4).all()
     assert att.max() < 60
+    x, att = oracle_lib.ralpha(c, tau, xp, it=6, fast=True)       # <= 64 fast attempts, then the general sampler
+    assert np.isfinite(x).all() and (x >= 1e-3).all() and (x <= 1e4).all()
+    assert att.max() < 64 + 60
 
 
 def _chain(oracle_lib, prior, **kw):
@@ -203,3 +223,4 @@ def test_golden_math_kat(oracle_lib):
     assert np.array_equal(O.rgamma(np.full(16, 6.5), 10.0, var=2, it=3), g["rgamma"])
     assert np.array_equal(O.rtnorm0(np.linspace(-3, 3, 16), 1.0, var=3, it=4), g["rtnorm0"])
     assert np.array_equal(O.ralpha(np.full(16, 65.0), 6.0, 6.5, var=5, it=5)[0], g["ralpha"])
+    assert np.array_equal(O.ralpha(np.full(16, 65.0), 6.0, 6.5, var=5, it=5, fast=True)[0], g["ralpha_fast"])
