@@ -42,6 +42,7 @@ struct bnmf_handle {
   hipEvent_t ev_draw = nullptr, ev_side = nullptr, ev_sideP = nullptr, ev_p = nullptr, ev_z = nullptr, ev_red = nullptr, ev_rank = nullptr;
   bool side_valid = false;             // k_side of iteration iter+1 has been issued
   int gate_forced = -1;                // BNMF_GATE at bnmf_create: 0 / 1 forces the merged draw kernel off / on, else by size
+  int gate_f0 = 1;                     // flag the gate waits for beside [3]: [1] E-side sweep (k_side), [9] P-side sweep on its own stream (merged draw path)
   uint32_t z_gate_next = 0;            // != 0: the allocation kernel being launched waits at its end for the hyper sweep of this iteration
   uint32_t z_gated_for = 0;            // the last allocation kernel gated for this iteration's hyper sweep (merged draw kernel, BNMF_GATE)
   bool side_ev_stale = false;          // ev_sideP / ev_side not recorded since the last side launches (fixed-rank sweep: recorded on demand)
@@ -69,7 +70,7 @@ struct bnmf_handle {
   int z_grid = 0, z_zw = 8, z_ablate = 0; bool z_reg = false; size_t z_lds = 0; ZGeom zg{};
   bool z_tile = false, z_lean = false; ZTGeom ztg{}; double* dMhatZ = nullptr;   // k_zalloc_tile (zalloc_tile.h): N > 24 / large K
   // k_zalloc_sort (zalloc_sort.h): stats mode, N <= 24 — the static schedule built from M at bnmf_create
-  bool z_sort = false; ZSGeom zsg{}; int zs_nblk = 0, zs_w = 0; size_t zs_lds = 0;
+  bool z_sort = false, zs_pk = false; ZSGeom zsg{}; int zs_nblk = 0, zs_w = 0; size_t zs_lds = 0; int32_t* dZsM = nullptr;
   uint32_t* dZsItems = nullptr; ZSBlock* dZsBlocks = nullptr; int* dZsCols = nullptr; unsigned long long* dZsProf = nullptr;
   hipEvent_t ev[2 * BNMF_NKERNEL]{};
   bool have_ev = false;
@@ -228,7 +229,7 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   for (int tries = 0; tries < 12; ++tries, nb = std::min<long>((long)G, nb * 2)) {
     GBc = (int)((G + nb - 1) / nb);
     if (GBc <= 64) {
-      const size_t sh = zsort_shared_bytes((int)K, (int)N, KP, GBc), wv = zsort_wave_bytes(nblk, (int)N);
+      const size_t sh = zsort_shared_bytes((int)K, (int)N, KP, GBc, false), wv = zsort_wave_bytes(nblk, (int)N);
       W = 0;
       for (int w : {16, 12, 8, 6, 4}) if (sh + (size_t)w * wv <= budget) { W = w; break; }
       if (W) break;
@@ -262,6 +263,13 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   std::vector<int> cols;
   std::vector<uint32_t> items;
   std::vector<std::pair<int, uint32_t>> tmp;
+  // two factors per word in the block's zG / zK tables (16-bit halves): only if no half can overflow, i.e. every column total
+  // (bound of a ZsumK entry) and every row total over a block's columns (bound of the block's share of a ZsumG entry) < 2^16
+  bool pk = ctot[order[0]] < 65536;
+  for (int b = 0; b < nb && pk; ++b)
+    for (size_t k = 0; k < K && pk; ++k) { long r = 0; for (int g : bcols[b]) r += M[k + K * (size_t)g]; if (r >= 65536) pk = false; }
+  if (const char* e = getenv("BNMF_ZSPK")) pk = pk && atoi(e) != 0;                 // diagnostics / tests: 0 = one factor per word
+  std::vector<int32_t> Mblk(K * G);
   for (int b = 0; b < nb; ++b) {
     std::sort(bcols[b].begin(), bcols[b].end());
     tmp.clear();
@@ -281,7 +289,7 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
     for (const auto& it : tmp) items.push_back(it.second);
     while (items.size() % 64) items.push_back(0xFFFFFFFFu);
     bk.ntask = (int)((items.size() - (size_t)bk.item0) / 64);
-    for (int g : bcols[b]) cols.push_back(g);
+    for (int g : bcols[b]) { memcpy(Mblk.data() + K * cols.size(), M + K * (size_t)g, K * sizeof(int32_t)); cols.push_back(g); }
   }
   if (items.empty()) items.push_back(0xFFFFFFFFu);
   HIPCHK(hipMalloc(&h->dZsItems, items.size() * sizeof(uint32_t)));
@@ -290,9 +298,11 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   HIPCHK(hipMemcpy(h->dZsBlocks, blocks.data(), blocks.size() * sizeof(ZSBlock), hipMemcpyHostToDevice));
   HIPCHK(hipMalloc(&h->dZsCols, cols.size() * sizeof(int)));
   HIPCHK(hipMemcpy(h->dZsCols, cols.data(), cols.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&h->dZsM, Mblk.size() * sizeof(int32_t)));
+  HIPCHK(hipMemcpy(h->dZsM, Mblk.data(), Mblk.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   h->zsg = ZSGeom{KP, GBc, (int)nb};
-  h->zs_nblk = nblk; h->zs_w = W;
-  h->zs_lds = (zsort_shared_bytes((int)K, (int)N, KP, GBc) + (size_t)W * zsort_wave_bytes(nblk, (int)N) + 15) & ~(size_t)15;
+  h->zs_nblk = nblk; h->zs_w = W; h->zs_pk = pk;
+  h->zs_lds = (zsort_shared_bytes((int)K, (int)N, KP, GBc, pk) + (size_t)W * zsort_wave_bytes(nblk, (int)N) + 15) & ~(size_t)15;
   h->z_sort = true;
 #ifdef ZSPROF
   HIPCHK(hipMalloc(&h->dZsProf, 8 * sizeof(unsigned long long)));
@@ -541,7 +551,7 @@ int bnmf_destroy(bnmf_handle* h) {
   hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol); if (h->dRankMhat) hipFree(h->dRankMhat); if (h->dRankSync) hipFree(h->dRankSync);
   if (h->E_alt) hipFree(h->E_alt);
   if (h->dMhatZ) hipFree(h->dMhatZ);
-  if (h->dZsItems) hipFree(h->dZsItems); if (h->dZsBlocks) hipFree(h->dZsBlocks); if (h->dZsCols) hipFree(h->dZsCols); if (h->dZsProf) hipFree(h->dZsProf);
+  if (h->dZsItems) hipFree(h->dZsItems); if (h->dZsBlocks) hipFree(h->dZsBlocks); if (h->dZsCols) hipFree(h->dZsCols); if (h->dZsProf) hipFree(h->dZsProf); if (h->dZsM) hipFree(h->dZsM);
   if (h->dMhat) hipFree(h->dMhat); if (h->dAccPn) hipFree(h->dAccPn); if (h->dAccEpart) hipFree(h->dAccEpart); if (h->dNzE) hipFree(h->dNzE);
   if (h->dEt) hipFree(h->dEt); if (h->dMt) hipFree(h->dMt); if (h->zring) hipFree(h->zring);
   if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_rank) hipEventDestroy(h->ev_rank); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); if (h->side) hipStreamDestroy(h->side); if (h->side2) hipStreamDestroy(h->side2);
@@ -761,27 +771,48 @@ static void launch_side_P(bnmf_handle* h, uint32_t t, hipEvent_t after = nullptr
   if (h->red_issued && !h->red_on_side2) hipStreamWaitEvent(h->side2, h->ev_red, 0);
   // ... and the log-prior of the P just drawn (k_lpp's work, iteration t-1) in the same launch
   hipLaunchKernelGGL(k_side_lp, dim3(nbP + h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, h->cfg.N, rec_at(h, t, fused_rec(h)), SideDone{},
-                     SideExtra{nbP, h->cfg.N, 0, t - 1, nullptr});
+                     SideExtra{nbP, h->cfg.N, 0, t - 1, nullptr, 0});
 }
-static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm) {   // ev_draw = completion of k_edraw(t-1)
+static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm, bool e_done = false) {   // ev_draw = completion of k_edraw(t-1); e_done: k_draw ran the E-side sweep
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
   const int nbE = (int)(((size_t)h->cfg.N * h->cfg.G + RT - 1) / RT);
   hipStreamWaitEvent(h->side2, h->ev_draw, 0);
   // Esum closes the side2 work the next k_pdraw needs (the P part ran before it on the same stream): it publishes flag [3]
   // ... and, in the same launch, the log-prior of the E just drawn (k_lpe's work; iteration t-1, whose slot pointers h->dev
   // still holds): off the critical path
-  hipLaunchKernelGGL(k_side_lp, dim3(h->cfg.N + h->nblkE), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)h->cfg.N, t},
-                     SideExtra{h->cfg.N, 0, h->nblkE, t - 1, lpe_src(h, t - 1)});
+  hipLaunchKernelGGL(k_side_lp, dim3(h->cfg.N + h->nblkE), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)(h->cfg.N + h->nblkE), t},
+                     SideExtra{h->cfg.N, 0, h->nblkE, t - 1, lpe_src(h, t - 1), 1});
   // k_reduce of the PREVIOUS iteration here, behind the kernels that produce its inputs on this stream (k_lpp, k_lpe) and
   // behind ev_draw (k_zalloc of that iteration): on the E part's stream it sat in front of the next E-side sweep, and the
   // P part waited for its event
   if (h->red_pending) { issue_reduce(h, h->red_t, h->red_row, tm, h->side2); h->red_pending = false; }
-  hipStreamWaitEvent(h->side, h->ev_draw, 0);
-  hipLaunchKernelGGL(k_side, dim3(nbE), dim3(RT), 0, h->side, h->dev, t, nbP, h->cfg.N + nbP, rec_at(h, t, fused_rec(h)), SideDone{h->dFlags, h->dFlags + 1, (unsigned)nbE, t});
+  if (!e_done) {
+    hipStreamWaitEvent(h->side, h->ev_draw, 0);
+    hipLaunchKernelGGL(k_side, dim3(nbE), dim3(RT), 0, h->side, h->dev, t, nbP, h->cfg.N + nbP, rec_at(h, t, fused_rec(h)), SideDone{h->dFlags, h->dFlags + 1, (unsigned)nbE, t});
+  }
   h->flags_valid = true;
   // ev_side (the E part AND the P part / Esum / log-priors done) for a main-stream wait: on demand, see refresh_side_events
   h->side_ev_stale = true;
   h->side_valid = true;
+}
+// Behind the merged draw kernel (which runs the E-side sweep itself): the P-side hyper sweep of iteration t on `side`, with a
+// flag of its own ([9]); Esum(t) and the log-priors of iteration t-1 in ONE launch on side2 (flag [3] counts all its
+// workgroups), k_reduce behind it.  The two no longer share a stream: the P-side sweep is a few long per-lane chains and
+// held Esum's flag back.
+static void launch_side_merged(bnmf_handle* h, uint32_t t, Timer& tm) {
+  const int N = h->cfg.N;
+  const int nbP = (int)(((size_t)h->cfg.K * N + RT - 1) / RT);
+  hipStreamWaitEvent(h->side, h->ev_draw, 0);
+  hipLaunchKernelGGL(k_side, dim3(nbP), dim3(RT), 0, h->side, h->dev, t, nbP, N, rec_at(h, t, fused_rec(h)), SideDone{h->dFlags + 8, h->dFlags + 9, (unsigned)nbP, t});
+  hipStreamWaitEvent(h->side2, h->ev_draw, 0);
+  if (h->red_issued && !h->red_on_side2) hipStreamWaitEvent(h->side2, h->ev_red, 0);   // lpPn slot reuse, see launch_side_P
+  hipLaunchKernelGGL(k_side_lp, dim3(2 * N + h->nblkE), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)(2 * N + h->nblkE), t},
+                     SideExtra{N, N, h->nblkE, t - 1, lpe_src(h, t - 1), 1});
+  if (h->red_pending) { issue_reduce(h, h->red_t, h->red_row, tm, h->side2); h->red_pending = false; }
+  h->flags_valid = true;
+  h->side_ev_stale = true;
+  h->side_valid = true;
+  h->gate_f0 = 9;
 }
 // Rank learning: the hyper sweep of t+1 in two parts.  Early (released by k_edraw): the k_side kernels.  They hold 64+ VGPRs
 // and cannot be scheduled on a CU whose SIMDs carry two waves of the rank sweep (230 VGPRs each): they run on the ~100 CUs
@@ -825,7 +856,7 @@ static int launch_z(bnmf_handle* h, uint32_t t, KernelT kern, const ArgT& arg, i
 static ZArgs zargs(const bnmf_handle* h) {
   const Dev& d = h->dev;
   ZArgs za{d.K, d.G, d.N, d.maxM, d.k0, d.k1, d.M, d.P, d.E, d.A, d.ZsumK, d.ZsumG, d.Z, d.colsse, d.colll, d.colkl, d.lgfact, d.logm, nullptr, nullptr, 0u, nullptr};
-  if (h->z_gate_next) { za.gate0 = h->dFlags + 1; za.gate1 = h->dFlags + 3; za.gate_epoch = h->z_gate_next; za.gate_err = h->dErr; }
+  if (h->z_gate_next) { za.gate0 = h->dFlags + h->gate_f0; za.gate1 = h->dFlags + 3; za.gate_epoch = h->z_gate_next; za.gate_err = h->dErr; }
   return za;
 }
 template <bool SZ, int ZT_, bool DIAG>
@@ -866,7 +897,7 @@ static int launch_zalloc_t(bnmf_handle* h, uint32_t t) {
 }
 template <int ZT_>
 static int launch_zsort_t(bnmf_handle* h, uint32_t t) {
-  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsProf};
+  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->dZsProf};
   auto go = [&](auto kern) -> int {
     if (h->z_attr_kernel != (const void*)kern) {
       HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -875,12 +906,19 @@ static int launch_zsort_t(bnmf_handle* h, uint32_t t) {
     hipLaunchKernelGGL(kern, dim3(h->zsg.nblocks), dim3(ZT_), h->zs_lds, h->stream, sa, t, h->zsg);
     return 0;
   };
+  if (h->zs_pk) switch (h->zs_nblk) {
+    case 1: return go(k_zalloc_sort<ZT_, 1, true>);
+    case 2: return go(k_zalloc_sort<ZT_, 2, true>);
+    case 3: return go(k_zalloc_sort<ZT_, 3, true>);
+    case 4: return go(k_zalloc_sort<ZT_, 4, true>);
+    default: return go(k_zalloc_sort<ZT_, 5, true>);
+  }
   switch (h->zs_nblk) {
-    case 1: return go(k_zalloc_sort<ZT_, 1>);
-    case 2: return go(k_zalloc_sort<ZT_, 2>);
-    case 3: return go(k_zalloc_sort<ZT_, 3>);
-    case 4: return go(k_zalloc_sort<ZT_, 4>);
-    default: return go(k_zalloc_sort<ZT_, 5>);
+    case 1: return go(k_zalloc_sort<ZT_, 1, false>);
+    case 2: return go(k_zalloc_sort<ZT_, 2, false>);
+    case 3: return go(k_zalloc_sort<ZT_, 3, false>);
+    case 4: return go(k_zalloc_sort<ZT_, 4, false>);
+    default: return go(k_zalloc_sort<ZT_, 5, false>);
   }
 }
 static int launch_zsort(bnmf_handle* h, uint32_t t) {
@@ -1117,14 +1155,15 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
     // merged draw kernel: the allocation kernel of t-1 has waited for this iteration's hyper sweep
     const unsigned nE = (unsigned)(((size_t)h->cfg.N * h->cfg.G + DW - 1) / DW);
     hipExtLaunchKernelGGL(k_draw, dim3(h->cfg.N + nE), dim3(DW), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, rec_at(h, t, rec),
-                          SideDone{h->dFlags + 5, h->dFlags + 6, (unsigned)h->cfg.N, t}, SideWait{h->dFlags + 6, h->dFlags + 6, t, h->dErr});
-    launch_side_P(h, t + 1, h->ev_draw);
-    launch_side_E(h, t + 1, tm);
+                          SideDone{h->dFlags + 5, h->dFlags + 6, (unsigned)h->cfg.N, t}, SideWait{h->dFlags + 6, h->dFlags + 6, t, h->dErr},
+                          rec_at(h, t + 1, rec), SideDone{h->dFlags, h->dFlags + 1, nE, t + 1});
+    launch_side_merged(h, t + 1, tm);
   } else {
     // completion events ride on the dispatches themselves (stop events): no marker packets on the main stream
     hipExtLaunchKernelGGL(k_pdraw, dim3(h->cfg.N), dim3(PD_T), (uint32_t)(2 * (size_t)h->cfg.K * sizeof(double)), h->stream,
                           nullptr, h->ev_p, 0, h->dev, t, 0, 0, rec_pdraw(h, t, rec),
                           poll ? SideWait{h->dFlags + 1, h->dFlags + 3, t, h->dErr} : SideWait{});
+    h->gate_f0 = 1;
     if (!h->cfg.learning_rank) {
       launch_side_P(h, t + 1);
       hipExtLaunchKernelGGL(k_edraw, dim3(h->nblkE), dim3(ES_T), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, 0, 0, rec_at(h, t, rec).E);

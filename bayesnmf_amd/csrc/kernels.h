@@ -284,7 +284,11 @@ __global__ __launch_bounds__(ES_T) void k_edraw(Dev d, uint32_t t, int from_prio
 // by the rate — the same operations in the same order as rgamma(shape, rate).  The kernel waits for nothing outside itself: the
 // allocation kernel before it has waited (one lane, at its end) for the hyper sweep of this iteration.
 constexpr int DW = 1024;
-__global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, SideDone pd, SideWait pw) {
+// The E workgroups also run the E-side hyper sweep of iteration t + 1 (hyper_elem<1>: element-wise, it needs nothing but the
+// element's own E_t): beside the allocation kernel that sweep got one wave per SIMD and the leftover issue slots (85 us for
+// ~20 us of work, and the allocation kernel's gate waited for it); here it runs at full occupancy.  rec_next: ring slots of
+// t + 1 for the prior parameters; ed: the E-side flag of the hand-off protocol (k_side raises it when it does this work).
+__global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, SideDone pd, SideWait pw, RecDst rec_next, SideDone ed) {
   __shared__ double Pn[DW];
   const int tid = threadIdx.x, N = d.N, K = d.K;
   if ((int)blockIdx.x < N) {
@@ -348,7 +352,9 @@ __global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, Side
     d.E[e] = x;
     if (rec.E) rec.E[e] = x;
     if (d.zsumk_accum) d.ZsumK[e] = 0;
+    hyper_elem<1>(d, (int)e, t + 1, x, rec_next.pp[2], rec_next.pp[3]);
   }
+  side_done(ed, tid);
 }
 
 // log-prior of column n of P_t under iteration t's prior parameters: canonical W = 64 over k, as in k_pdraw
@@ -379,14 +385,17 @@ __global__ __launch_bounds__(ES_T) void k_lpe(Dev d, uint32_t t, const double* E
 // per iteration — small problems are bound by the host's enqueue rate).  Workgroups [0, first): k_side's (blk0 as there);
 // then n_lpp workgroups with k_lpp's work (one wave each), then n_lpe with k_lpe's.  The two kinds are independent of each
 // other; side_done counts the k_side workgroups only.
-struct SideExtra { int first, n_lpp, n_lpe; uint32_t t_lp; const double* Esrc; };
+struct SideExtra { int first, n_lpp, n_lpe; uint32_t t_lp; const double* Esrc; int count_all; };   // count_all: the log-prior workgroups count towards sd too
 static_assert(ES_T == RT, "k_side_lp: one block size for both kinds of workgroup");
 __global__ __launch_bounds__(RT, 4) void k_side_lp(Dev d, uint32_t t, int nbP, int blk0, RecDst rec, SideDone sd, SideExtra ex) {
   __shared__ double buf[RT];
   const int j = (int)blockIdx.x - ex.first;
-  if (j < 0) side_body(d, t, nbP, blockIdx.x + blk0, ex.first, rec, sd, buf, threadIdx.x);
-  else if (j < ex.n_lpp) { if (threadIdx.x < 64) lpp_body(d, ex.t_lp, j, threadIdx.x); }
+  if (j < 0) { side_body(d, t, nbP, blockIdx.x + blk0, ex.first, rec, sd, buf, threadIdx.x); return; }
+  if (j < ex.n_lpp) { if (threadIdx.x < 64) lpp_body(d, ex.t_lp, j, threadIdx.x); }
   else lpe_body(d, ex.t_lp, j - ex.n_lpp, ex.Esrc, buf, threadIdx.x);
+  // the prior parameters these workgroups read (slot t_lp & 1) are overwritten two iterations on: where the writer is released
+  // by sd's flag (the merged draw kernel, which runs the E-side sweep itself), the flag has to cover these reads
+  if (ex.count_all) side_done(sd, threadIdx.x);
 }
 
 // ---- k_zalloc: the general Z-allocation kernel (any N, any K); the metric configuration runs k_zalloc_reg ----

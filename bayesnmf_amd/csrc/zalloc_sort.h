@@ -30,6 +30,7 @@ struct ZSArgs {
   const uint32_t* items;             // k | gl << 10 | fragment << 16; 0xFFFFFFFF = empty lane
   const ZSBlock* blocks;
   const int* cols;
+  const int32_t* Mblk;               // M with its columns in block order: column col0 + gl of Mblk = column cols[col0 + gl] of M
   unsigned long long* prof;          // -DZSPROF builds only: per-section s_memtime ticks summed over the waves (diagnostics)
 };
 // -DZSPROF: section timers.  [0] block set-up, [1] thresholds, [2] quad loops, [3] histogram flush, [4] metric tasks,
@@ -41,17 +42,23 @@ struct ZSArgs {
 #define ZSTIC(i)
 #define ZSTOC(i)
 #endif
-// host and device agree on the LDS layout through these
+constexpr int ZS_MCOL = 2;           // columns per metric task (independent chains in flight: the task is latency-bound)
+// host and device agree on the LDS layout through these.  PK: zG / zK hold two factors per word (16-bit halves, as the
+// lanes' histograms do), chosen at bnmf_create when no half can overflow
 #define BNMF_HD __host__ __device__ inline
-BNMF_HD size_t zsort_shared_bytes(int K, int N, int KP, int GBc) {
-  size_t w = (size_t)N * KP + (size_t)N * GBc + (size_t)K * GBc + GBc + 4;   // zG, zK, Ms, colid, ticket (32-bit words)
+BNMF_HD int zsort_zrows(int N, bool pk) { return pk ? (N + 1) / 2 : N; }
+BNMF_HD size_t zsort_shared_bytes(int K, int N, int KP, int GBc, bool pk) {
+  size_t w = (size_t)zsort_zrows(N, pk) * (KP + GBc) + (size_t)K * GBc + GBc + 4;   // zG, zK, Ms, colid, ticket (32-bit words)
   w = (w + 3) & ~(size_t)3;
   return (w * 4 + ((size_t)K * N + (size_t)N * GBc) * 8 + 15) & ~(size_t)15;   // + Pl, ae (fp64); the waves' slabs are 16-byte aligned
 }
 BNMF_HD size_t zsort_wave_bytes(int NBLK, int N) { return (size_t)NBLK * 64 * 16 + (size_t)((N + 1) / 2) * 64 * 4; }
 
-template <int ZT, int NBLK /* threshold blocks per cell: covers N <= 5 NBLK */>
-__global__ __launch_bounds__(ZT) void k_zalloc_sort(ZSArgs s, uint32_t t, ZSGeom zg) {
+// <= 128 VGPRs (4 waves per SIMD by registers): three waves per SIMD of this kernel then leave the side streams' kernels
+// (128 VGPRs) a wave slot on every SIMD — at 133 VGPRs they could not start before the first workgroups here had ended
+template <int ZT, int NBLK /* threshold blocks per cell: covers N <= 5 NBLK */, bool PK>
+__global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_zalloc_sort(ZSArgs s, uint32_t t, ZSGeom zg) {
+  constexpr int ZW = ZT / 64;
   constexpr int NPV = NBLK - 1;                           // pivots: threshold 5j + 4 closes block j
   constexpr int NC = 5 * NBLK;                            // factors covered
   constexpr int NMIN = NBLK == 1 ? 1 : 5 * (NBLK - 1) + 1; // smallest N routed here
@@ -60,44 +67,58 @@ __global__ __launch_bounds__(ZT) void k_zalloc_sort(ZSArgs s, uint32_t t, ZSGeom
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = d.K, N = d.N, KP = zg.KP, GBc = zg.GBc;
   const int KR = (K + 63) >> 6;
+  const int HW = (N + 1) >> 1;
+  const int ZR = PK ? HW : N;                              // rows of zG / zK
   const ZSBlock bk = s.blocks[blockIdx.x];
-  uint32_t* zG = (uint32_t*)smem;                          // [N][KP]
-  uint32_t* zK = zG + (size_t)N * KP;                      // [N][GBc]
-  int* Ms = (int*)(zK + (size_t)N * GBc);                  // [GBc][K] counts of the block's columns
+  uint32_t* zG = (uint32_t*)smem;                          // [ZR][KP]
+  uint32_t* zK = zG + (size_t)ZR * KP;                     // [ZR][GBc]
+  int* Ms = (int*)(zK + (size_t)ZR * GBc);                 // [GBc][K] counts of the block's columns
   int* colid = Ms + (size_t)K * GBc;                       // [GBc]
   uint32_t* ticket = (uint32_t*)(colid + GBc);
-  const size_t w32 = (((size_t)N * KP + (size_t)N * GBc + (size_t)K * GBc + GBc + 4) + 3) & ~(size_t)3;
+  const size_t w32 = (((size_t)ZR * (KP + GBc) + (size_t)K * GBc + GBc + 4) + 3) & ~(size_t)3;
   double* Pl = (double*)(smem + w32 * 4);                  // [N][K]
   double* ae = Pl + (size_t)K * N;                         // [N][GBc]  A[n] E[n, column]
-  unsigned char* wbase = smem + zsort_shared_bytes(K, N, KP, GBc) + (size_t)wave * zsort_wave_bytes(NBLK, N);
+  unsigned char* wbase = smem + zsort_shared_bytes(K, N, KP, GBc, PK) + (size_t)wave * zsort_wave_bytes(NBLK, N);
   u4* tblk = (u4*)wbase;                                   // [NBLK][64]
   uint32_t* hist = (uint32_t*)(tblk + NBLK * 64);          // [(N+1)/2][64] packed 16-bit bucket counts of the lane's item
-  const int HW = (N + 1) >> 1;
 #ifdef ZSPROF
   uint64_t zsprof[8] = {0, 0, 0, 0, 0, 0, 0, 1};
 #endif
   ZSTIC(6);
   ZSTIC(0);
-  // ---------------- block set-up
-  for (int i = tid; i < N * KP; i += ZT) zG[i] = 0;
-  for (int i = tid; i < N * GBc; i += ZT) zK[i] = 0;
-  for (int i = tid; i < bk.ncols; i += ZT) colid[i] = s.cols[bk.col0 + i];
-  if (tid == 0) *ticket = 0;
-  for (int i = tid; i < K * N; i += ZT) Pl[i] = d.P[i];
+  // ---------------- block set-up.  Three independent global-memory chains (P; the block's slab of M; column ids -> E) go
+  // to different waves, so that their latencies overlap instead of adding up
   for (int i = lane; i < HW * 64; i += 64) hist[i] = 0;
-  for (int i = tid; i < N * bk.ncols; i += ZT) {
-    const int gl = i / N, n = i - gl * N;
-    const int g = s.cols[bk.col0 + gl];
-    ae[(size_t)n * GBc + gl] = d.A[n] * d.E[n + (size_t)N * g];
-  }
-  for (int gl = wave; gl < bk.ncols; gl += ZT / 64) {
-    const int g = s.cols[bk.col0 + gl];
-    for (int k = lane; k < K; k += 64) Ms[k + (size_t)K * gl] = d.M[k + (size_t)K * g];
+  {
+    const int job = wave % 3, jw = wave / 3, nj = (ZW - job + 2) / 3;   // waves job, job + 3, ... do this job
+    const int jt = jw * 64 + lane, jn = nj * 64;
+    if (job == 0 || ZW < 3) {
+      const int jt0 = ZW < 3 ? tid : jt, jn0 = ZW < 3 ? ZT : jn;
+      for (int i = jt0; i < K * N; i += jn0) Pl[i] = d.P[i];
+    }
+    if (job == 1 || ZW < 3) {
+      const int jt0 = ZW < 3 ? tid : jt, jn0 = ZW < 3 ? ZT : jn;
+      const int32_t* Mb = s.Mblk + (size_t)K * bk.col0;
+      for (int i = jt0; i < K * bk.ncols; i += jn0) Ms[i] = Mb[i];
+      for (int i = jt0; i < ZR * KP; i += jn0) zG[i] = 0;
+    }
+    if (job == 2 || ZW < 3) {
+      const int jt0 = ZW < 3 ? tid : jt, jn0 = ZW < 3 ? ZT : jn;
+      for (int i = jt0; i < N * bk.ncols; i += jn0) {
+        const int gl = i / N, n = i - gl * N;
+        const int g = s.cols[bk.col0 + gl];
+        ae[(size_t)n * GBc + gl] = d.A[n] * d.E[n + (size_t)N * g];
+      }
+      for (int i = jt0; i < bk.ncols; i += jn0) colid[i] = s.cols[bk.col0 + i];
+      for (int i = jt0; i < ZR * GBc; i += jn0) zK[i] = 0;
+      if (jt0 == 0) *ticket = 0;
+    }
   }
   __syncthreads();
   ZSTOC(0);
   const int nthr = N - 1;
-  const int ntot = bk.ntask + bk.ncols;
+  const int nmt = (bk.ncols + ZS_MCOL - 1) / ZS_MCOL;      // metric tasks
+  const int ntot = bk.ntask + nmt;
   const uint32_t hlb = lds_off(hist + lane);
   // the next task of the block: lane 0 draws a ticket, every lane reads lane 0's (readlane: whatever EXEC is)
   auto next_task = [&]() -> int {
@@ -105,32 +126,54 @@ __global__ __launch_bounds__(ZT) void k_zalloc_sort(ZSArgs s, uint32_t t, ZSGeom
     if (lane == 0) tk = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return __builtin_amdgcn_readlane(tk, 0);
   };
-  for (int task = next_task(); task < ntot; task = next_task()) {
-    if (task >= bk.ntask) {
+  // tickets [0, nmt): metric tasks (uniform size), then the item tasks in descending size: the block's tail is made of its
+  // smallest tasks
+  for (int tk = next_task(); tk < ntot; tk = next_task()) {
+    const int task = tk - nmt;
+    if (task < 0) {
       ZSTIC(4);
-      // ---------------- metric task: one column, lane = row, canonical W = 64 sums (as phase 1 of k_zalloc_reg)
-      const int gl = task - bk.ntask, g = colid[gl];
-      double a_sse = 0.0, a_ll = 0.0, a_kl = 0.0;
+      // ---------------- metric task: ZS_MCOL columns, lane = row, canonical W = 64 sums per column (as phase 1 of
+      // k_zalloc_reg); the columns' chains are independent and interleave
+      const int gl0 = tk * ZS_MCOL;
+      double a_sse[ZS_MCOL], a_ll[ZS_MCOL], a_kl[ZS_MCOL];
+#pragma unroll
+      for (int j = 0; j < ZS_MCOL; ++j) { a_sse[j] = 0.0; a_ll[j] = 0.0; a_kl[j] = 0.0; }
       for (int r = 0; r < KR; ++r) {
         const int kk = (r << 6) + lane;
         if (kk < K) {
-          const int m = Ms[kk + (size_t)K * gl];
-          const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
-          const double lgf = d.lgfact[mi], lgm = d.logm[mi];
-          double c = 0.0;
+          int m[ZS_MCOL];
+          double lgf[ZS_MCOL], lgm[ZS_MCOL], c[ZS_MCOL];
 #pragma unroll
-          for (int n = 0; n < NC; ++n) if (n < NMIN || n < N) c = c + Pl[kk + (size_t)K * n] * ae[(size_t)n * GBc + gl];
-          const double dd = c - (double)m;
-          const double mh = c < 1e-6 ? 1e-6 : c;
-          const double lmh = dlog(mh);
-          const double mt = m < 1 ? 1e-6 : (double)m;
-          a_sse = a_sse + dd * dd;
-          a_ll = a_ll + (((double)m * lmh - mh) - lgf);
-          a_kl = a_kl + mt * (lgm - lmh);
+          for (int j = 0; j < ZS_MCOL; ++j) {
+            const int gl = min(gl0 + j, bk.ncols - 1);
+            m[j] = Ms[kk + (size_t)K * gl];
+            const int mi = m[j] < 0 ? 0 : (m[j] > d.maxM ? d.maxM : m[j]);
+            lgf[j] = d.lgfact[mi]; lgm[j] = d.logm[mi];
+            c[j] = 0.0;
+          }
+#pragma unroll
+          for (int n = 0; n < NC; ++n) if (n < NMIN || n < N) {
+            const double pkn = Pl[kk + (size_t)K * n];
+#pragma unroll
+            for (int j = 0; j < ZS_MCOL; ++j) c[j] = c[j] + pkn * ae[(size_t)n * GBc + min(gl0 + j, bk.ncols - 1)];
+          }
+#pragma unroll
+          for (int j = 0; j < ZS_MCOL; ++j) {
+            const double dd = c[j] - (double)m[j];
+            const double mh = c[j] < 1e-6 ? 1e-6 : c[j];
+            const double lmh = dlog(mh);
+            const double mt = m[j] < 1 ? 1e-6 : (double)m[j];
+            a_sse[j] = a_sse[j] + dd * dd;
+            a_ll[j] = a_ll[j] + (((double)m[j] * lmh - mh) - lgf[j]);
+            a_kl[j] = a_kl[j] + mt * (lgm[j] - lmh);
+          }
         }
       }
-      a_sse = wave_tree64(a_sse); a_ll = wave_tree64(a_ll); a_kl = wave_tree64(a_kl);
-      if (lane == 0) { d.colsse[g] = a_sse; d.colll[g] = a_ll; d.colkl[g] = a_kl; }
+#pragma unroll
+      for (int j = 0; j < ZS_MCOL; ++j) {
+        const double r0 = wave_tree64(a_sse[j]), r1 = wave_tree64(a_ll[j]), r2 = wave_tree64(a_kl[j]);
+        if (lane == 0 && gl0 + j < bk.ncols) { const int g = colid[gl0 + j]; d.colsse[g] = r0; d.colll[g] = r1; d.colkl[g] = r2; }
+      }
       ZSTOC(4);
     } else {
     // ---------------- item task: lane = item
@@ -146,23 +189,20 @@ __global__ __launch_bounds__(ZT) void k_zalloc_sort(ZSArgs s, uint32_t t, ZSGeom
     {
       // Mhat = sum_n P[k,n] (A[n] E[n,g]) in factor order; thr_n = floor(cum_n 2^32 / Mhat) saturating at 2^32 - 1 = "never"
       // (factors at/after the last positive one saturate by themselves, see zalloc_reg.h)
-      double pk[NC], ak[NC];
-#pragma unroll
-      for (int n = 0; n < NC; ++n) {
-        const bool on = n < NMIN || n < N;
-        pk[n] = on ? Pl[k + (size_t)K * n] : 0.0;
-        ak[n] = on ? ae[(size_t)n * GBc + gl] : 0.0;
-      }
+      // the running sums cum_n are kept (NC - 1 fp64 registers) between the pass that forms Mhat and the thresholds: the same
+      // additions in the same order as a second accumulation from zero, without reading the row of P and the column of A E again
+      const double* Pk = Pl + k;
+      const double* ag = ae + gl;
+      double cs[NC];
       double c = 0.0;
 #pragma unroll
-      for (int n = 0; n < NC; ++n) if (n < NMIN || n < N) c = c + pk[n] * ak[n];
+      for (int n = 0; n < NC; ++n) { if (n < NMIN || n < N) c = c + Pk[(size_t)K * n] * ag[(size_t)n * GBc]; cs[n] = c; }
       if (valid && c > 0.0 && m > 0) {
         const int qt = (m + 3) >> 2;
         nq = min(ZS_QMAX, qt - q0);
         npad = (q0 + nq == qt) ? ((4 - (m & 3)) & 3) : 0;
       }
       const double scale = 4294967296.0 / c;
-      double c2 = 0.0;
 #pragma unroll
       for (int j = 0; j < NBLK; ++j) {
         uint32_t tv[5];
@@ -170,7 +210,7 @@ __global__ __launch_bounds__(ZT) void k_zalloc_sort(ZSArgs s, uint32_t t, ZSGeom
         for (int i = 0; i < 5; ++i) {
           const int n = 5 * j + i;
           tv[i] = 0xFFFFFFFFu;
-          if (n < NC - 1 && (n < NMIN - 1 || n < nthr)) { c2 = c2 + pk[n] * ak[n]; tv[i] = cvt_u32_sat(c2 * scale); }
+          if (n < NC - 1 && (n < NMIN - 1 || n < nthr)) tv[i] = cvt_u32_sat(cs[n] * scale);
         }
         tblk[j * 64 + lane] = u4{tv[0], tv[1], tv[2], tv[3]};
         if (j < NPV) pv[j] = tv[4];
@@ -211,9 +251,13 @@ __global__ __launch_bounds__(ZT) void k_zalloc_sort(ZSArgs s, uint32_t t, ZSGeom
         const uint32_t v = hist[w * 64 + lane];
         if (v) {
           hist[w * 64 + lane] = 0;
-          const uint32_t lo = v & 0xFFFFu, hi = v >> 16;
-          if (lo) { lds_add(zgb + (uint32_t)(2 * w) * (uint32_t)KP * 4u, lo); lds_add(zkb + (uint32_t)(2 * w) * (uint32_t)GBc * 4u, lo); }
-          if (hi) { lds_add(zgb + (uint32_t)(2 * w + 1) * (uint32_t)KP * 4u, hi); lds_add(zkb + (uint32_t)(2 * w + 1) * (uint32_t)GBc * 4u, hi); }
+          if (PK) {                      // the pair of factors 2w, 2w + 1 in one add (no half can overflow: checked at bnmf_create)
+            lds_add(zgb + (uint32_t)w * (uint32_t)KP * 4u, v); lds_add(zkb + (uint32_t)w * (uint32_t)GBc * 4u, v);
+          } else {
+            const uint32_t lo = v & 0xFFFFu, hi = v >> 16;
+            if (lo) { lds_add(zgb + (uint32_t)(2 * w) * (uint32_t)KP * 4u, lo); lds_add(zkb + (uint32_t)(2 * w) * (uint32_t)GBc * 4u, lo); }
+            if (hi) { lds_add(zgb + (uint32_t)(2 * w + 1) * (uint32_t)KP * 4u, hi); lds_add(zkb + (uint32_t)(2 * w + 1) * (uint32_t)GBc * 4u, hi); }
+          }
         }
       }
     }
@@ -226,11 +270,12 @@ __global__ __launch_bounds__(ZT) void k_zalloc_sort(ZSArgs s, uint32_t t, ZSGeom
   // ---------------- block epilogue: ZsumK of the block's columns (plain stores), ZsumG (global integer atomics)
   for (int i = tid; i < N * bk.ncols; i += ZT) {
     const int gl = i / N, n = i - gl * N;
-    d.ZsumK[n + (size_t)N * colid[gl]] = (int32_t)zK[(size_t)n * GBc + gl];
+    const uint32_t v = PK ? (zK[(size_t)(n >> 1) * GBc + gl] >> ((n & 1) << 4)) & 0xFFFFu : zK[(size_t)n * GBc + gl];
+    d.ZsumK[n + (size_t)N * colid[gl]] = (int32_t)v;
   }
   for (int i = tid; i < K * N; i += ZT) {
     const int kk = i % K, n = i / K;
-    const uint32_t v = zG[(size_t)n * KP + kk];
+    const uint32_t v = PK ? (zG[(size_t)(n >> 1) * KP + kk] >> ((n & 1) << 4)) & 0xFFFFu : zG[(size_t)n * KP + kk];
     if (v) atomicAdd(&d.ZsumG[kk + (size_t)K * n], (int32_t)v);
   }
   ZSTOC(5);

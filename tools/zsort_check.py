@@ -9,6 +9,7 @@ from bayesnmf_amd.setup import apply_hyperprior_params, synth_counts  # noqa: E4
 
 def mk(M, N, zs, **kw):
     os.environ["BNMF_ZSORT"] = str(zs)
+    os.environ["BNMF_ZSPK"] = os.environ.get("ZSPK", "1")
     e = Engine(M, N, prior="gamma", seed=5, **kw)
     apply_hyperprior_params(e, "gamma", M, N)
     return e
