@@ -79,6 +79,9 @@ struct bnmf_handle {
   int* hErr = nullptr; int* dErr = nullptr;       // time-out words of the bounded in-kernel waits, in mapped host memory (read without a copy):
                                                   // [0] a draw kernel waiting for the hyper sweep, [1] the rank sweep's exchange
   bool flags_valid = false;                       // the side work of the next iteration publishes its flags
+  bool serial = false;                            // no kernel may wait for a kernel of another stream (serialised dispatch: counter
+                                                  // collection, AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING; or BNMF_SERIAL=1): stream waits only
+  bool poisoned = false;                          // a bounded in-kernel wait timed out: the state is no longer the chain's, every call fails
   std::vector<double> hist;                       // [wcap][4]: loglikelihood, logposterior, P / E mean acceptance of the last iterations
   std::vector<double> temp_host;                  // temperature schedule (host copy, for the convergence rule)
 };
@@ -334,6 +337,14 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   HIPCHK(hipMemset(h->dZsumG, 0, K * N * sizeof(int32_t)));
   if (cfg->save_Z) HIPCHK(hipMalloc(&h->dZ, K * N * G * sizeof(int32_t)));
   if (const char* e = getenv("BNMF_GATE")) h->gate_forced = atoi(e) != 0 ? 1 : 0;   // diagnostics / tests
+  {
+    // A lane that polls inside a main-stream kernel for a side-stream kernel deadlocks (until its bound) when dispatches cannot
+    // overlap: the waited-for kernel only starts once the waiting one has ended.  Where the process is known to serialise its
+    // dispatches, every hand-off is a stream wait on an event instead (the structure profile mode has always used).
+    auto on = [](const char* name) { const char* e = getenv(name); return e && *e && strcmp(e, "0") != 0; };
+    h->serial = on("AMD_SERIALIZE_KERNEL") || on("HIP_LAUNCH_BLOCKING") || on("ROCPROF_COUNTER_COLLECTION") || getenv("ROCPROF_COUNTERS") != nullptr;
+    if (const char* e = getenv("BNMF_SERIAL")) h->serial = atoi(e) != 0;
+  }
   HIPCHK(hipMalloc(&h->dFlags, 64));
   HIPCHK(hipMemset(h->dFlags, 0, 64));
   HIPCHK(hipHostMalloc((void**)&h->hErr, 64, hipHostMallocMapped));
@@ -611,6 +622,7 @@ int bnmf_set_array(bnmf_handle* h, int id, const double* x, size_t n) {
 
 int bnmf_get_array(bnmf_handle* h, int id, double* out, size_t n) {
   if (!h || !out) return fail(BNMF_EINVAL, "bnmf_get_array: null argument");
+  if (h->poisoned) return fail(BNMF_ESTATE, "bnmf_get_array: the handle timed out inside a kernel; its state is invalid");
   const size_t len = id_len(h, id);
   if (len == 0 || n != len) return fail(BNMF_ESIZE, "bnmf_get_array: id %d expects %zu values, got %zu", id, len, n);
   HIPCHK(hipSetDevice(h->device));
@@ -656,6 +668,11 @@ int bnmf_debug_zsort(bnmf_handle* h, unsigned long long* out) {   // diagnostics
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipMemcpy(out, h->dZsProf, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   HIPCHK(hipMemset(h->dZsProf, 0, 8 * sizeof(unsigned long long)));
+  return 0;
+}
+int bnmf_debug_set_timeout(bnmf_handle* h, int word) {   // tests: what a bounded in-kernel wait does when it gives up
+  if (!h || word < 0 || word > 1) return fail(BNMF_EINVAL, "bnmf_debug_set_timeout: bad argument");
+  ((volatile int*)h->hErr)[word] = 2;
   return 0;
 }
 int bnmf_get_iter(bnmf_handle* h, int* iter) { if (!h || !iter) return fail(BNMF_EINVAL, "null"); *iter = h->iter; return 0; }
@@ -1107,7 +1124,7 @@ static int sweep_mh(bnmf_handle* h, int row, int converged, Timer& tm) {
   if (!h->side_valid) launch_side(h, t, tm);
   // prior parameters of iteration t: in the steady state the P-row kernel polls the flag k_side publishes (a stream wait is a
   // barrier packet: ~16 us of bubble per iteration here); after init / set_array / in profile mode a stream wait
-  const bool poll = h->flags_valid && !tm.on;
+  const bool poll = h->flags_valid && !tm.on && !h->serial;
   if (!poll) { refresh_side_events(h); hipStreamWaitEvent(h->stream, h->ev_side, 0); hipStreamWaitEvent(h->stream, h->ev_sideP, 0); }
   tm.begin(KN_MH, h->stream); launch_mh_PE(h, t, converged, poll); tm.end(KN_MH, h->stream);
   launch_side(h, t + 1, tm, !tm.on);
@@ -1145,7 +1162,7 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   }
   // prior parameters + Esum of iteration t: in the steady state k_pdraw polls the flags their kernels publish (no barrier
   // packet on the main stream); after init / set_array / in profile mode a stream wait
-  const bool poll = h->flags_valid && !tm.on;
+  const bool poll = h->flags_valid && !tm.on && !h->serial;
   if (!poll) { refresh_side_events(h); hipStreamWaitEvent(h->stream, h->ev_side, 0); }
   if (tm.on) {                                             // profile mode: one kernel at a time
     tm.begin(KN_PDRAW, h->stream); launch_pdraw(h, t, 0, rec); tm.end(KN_PDRAW, h->stream);
@@ -1192,6 +1209,24 @@ extern "C" {
 int bnmf_init(bnmf_handle* h, double* metrics_row1) {
   if (!h) return fail(BNMF_EINVAL, "bnmf_init: null handle");
   HIPCHK(hipSetDevice(h->device));
+  if (h->poisoned) return fail(BNMF_ESTATE, "bnmf_init: the handle timed out inside a kernel; destroy it");
+  if (h->inited) {
+    // Re-initialisation restarts the iteration counter at 1, and with it every epoch the kernels compare their sync words
+    // against (flags < epoch, the rank sweep's granule tags): stale words from the first life of the handle would satisfy
+    // those waits at once.  Drain the streams and clear the words and the host-side pipeline state.
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->side));
+    HIPCHK(hipStreamSynchronize(h->side2));
+    HIPCHK(hipMemset(h->dFlags, 0, 64));
+    memset(h->hErr, 0, 64);
+    if (h->dRankSync) HIPCHK(hipMemset(h->dRankSync, 0, 32));
+    if (h->dRankCol) HIPCHK(hipMemset(h->dRankCol, 0, 4 * 2 * (((size_t)h->cfg.G + RK_MAXC - 1) / RK_MAXC) * sizeof(double)));
+    HIPCHK(hipMemset(h->dZsumK, 0, (size_t)h->cfg.N * h->cfg.G * sizeof(int32_t)));
+    HIPCHK(hipMemset(h->dZsumG, 0, (size_t)h->cfg.K * h->cfg.N * sizeof(int32_t)));
+    h->side_valid = false; h->flags_valid = false; h->z_gate_next = 0; h->z_gated_for = 0; h->gate_f0 = 1;
+    h->side_ev_stale = false; h->red_on_side2 = false; h->red_pending = false; h->red_issued = false; h->mh_prep_valid = false;
+    h->inited = false;
+  }
   const bnmf_config& c = h->cfg;
   const int N = c.N;
   const long KN = (long)c.K * N, NG = (long)N * c.G;
@@ -1285,6 +1320,7 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
 static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, Timer& tm) {
   if (!h) return fail(BNMF_EINVAL, "bnmf_run: null handle");
   if (!h->inited) return fail(BNMF_ESTATE, "bnmf_run: call bnmf_init first");
+  if (h->poisoned) return fail(BNMF_ESTATE, "bnmf_run: an earlier call timed out inside a kernel; the handle's state is invalid, destroy it");
   if (n_iter < 0) return fail(BNMF_EINVAL, "bnmf_run: n_iter < 0");
   if (n_iter == 0) return 0;
   HIPCHK(hipSetDevice(h->device));
@@ -1293,6 +1329,9 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
   for (int i = 0; i < n_iter; ++i) {
     if (int rc = ((h->cfg.MH || h->cfg.likelihood == BNMF_NORMAL) ? sweep_mh(h, i, h->cfg.MH ? converged : 0, tm) : sweep(h, i, tm))) return rc;
     HIPCHK(hipGetLastError());                               // a refused launch of this iteration (bad geometry, LDS size)
+    // a bounded in-kernel wait that timed out has set its word (mapped host memory): issue nothing more, so that one stuck
+    // hand-off costs one spin bound and not one per remaining launch
+    if (((volatile int*)h->hErr)[0] | ((volatile int*)h->hErr)[1]) break;
   }
   flush_reduce(h, tm);
   hipEventRecord(h->ev_z, h->side); hipStreamWaitEvent(h->stream, h->ev_z, 0);   // last k_reduce done
@@ -1313,8 +1352,17 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
     }
   }
   // all three streams are idle: the time-out words (mapped host memory) are final
-  if (((volatile int*)h->hErr)[0]) return fail(BNMF_EHIP, "bnmf_run: a draw kernel timed out waiting for the hyper-parameter sweep of its iteration");
-  if (((volatile int*)h->hErr)[1]) return fail(BNMF_EHIP, "bnmf_run: the grid barrier of the rank sweep timed out (workgroups not co-resident?)");
+  if (((volatile int*)h->hErr)[0] | ((volatile int*)h->hErr)[1]) {
+    // the kernels behind the time-out ran on inputs that were never published: P, E, the rings and the metric rows of this call
+    // are not the chain's.  The handle stays poisoned (every later call fails with BNMF_ESTATE) until it is destroyed.
+    h->poisoned = true;
+    unsigned fl[16] = {};
+    hipMemcpy(fl, h->dFlags, sizeof fl, hipMemcpyDeviceToHost);
+    if (((volatile int*)h->hErr)[0])
+      return fail(BNMF_EHIP, "bnmf_run: a kernel timed out waiting for the hyper-parameter sweep of its iteration (iteration %d; flags E-side %u, Esum %u, P-side %u, draw %u; "
+                  "serialised dispatch? set BNMF_SERIAL=1); the handle is now invalid", h->iter, fl[1], fl[3], fl[9], fl[6]);
+    return fail(BNMF_EHIP, "bnmf_run: the grid barrier of the rank sweep timed out at iteration %d (workgroups not co-resident?); the handle is now invalid", h->iter);
+  }
   return 0;
 }
 int bnmf_run(bnmf_handle* h, int n_iter, int converged, double* metrics) {
@@ -1333,6 +1381,7 @@ int bnmf_profile(bnmf_handle* h, int n_iter, int converged, double* out_ms) {
 int bnmf_window(bnmf_handle* h, int id, int last_n, double* out) {
   if (!h || !out) return fail(BNMF_EINVAL, "bnmf_window: null argument");
   const int W = h->cfg.window;
+  if (h->poisoned) return fail(BNMF_ESTATE, "bnmf_window: the handle timed out inside a kernel; its state is invalid");
   if (W <= 0) return fail(BNMF_ESTATE, "bnmf_window: the handle was created with window = 0");
   if (last_n < 1 || last_n > W || last_n > h->iter) return fail(BNMF_ESIZE, "bnmf_window: last_n = %d but only min(window = %d, iter = %d) samples are kept", last_n, W, h->iter);
   if (id < 0 || id >= BNMF_ID_MAX) return fail(BNMF_EINVAL, "bnmf_window: unknown id %d", id);
@@ -1377,6 +1426,7 @@ int bnmf_map(bnmf_handle* h, int last_n, double ci, double* P_mean, double* E_me
              double* P_lower, double* P_upper, double* E_lower, double* E_upper, int32_t* used, bnmf_map_info* info) {
   if (!h || !A_mode || !info) return fail(BNMF_EINVAL, "bnmf_map: null argument");
   const int W = h->cfg.window;
+  if (h->poisoned) return fail(BNMF_ESTATE, "bnmf_map: the handle timed out inside a kernel; its state is invalid");
   if (W <= 0) return fail(BNMF_ESTATE, "bnmf_map: the handle was created with window = 0");
   if (last_n < 1 || last_n > W || last_n > h->iter) return fail(BNMF_ESIZE, "bnmf_map: last_n = %d but only min(window = %d, iter = %d) samples are kept", last_n, W, h->iter);
   if (ci >= 1.0) return fail(BNMF_EINVAL, "bnmf_map: credible_interval must be below 1");
@@ -1570,6 +1620,7 @@ int bnmf_assign(bnmf_handle* h, int last_n, const int32_t* used, const double* r
                 double ci, double* votes, int32_t* assigned, double* MAP_cosine, double* lower, double* upper) {
   if (!h || !ref || !votes || !assigned) return fail(BNMF_EINVAL, "bnmf_assign: null argument");
   const int W = h->cfg.window;
+  if (h->poisoned) return fail(BNMF_ESTATE, "bnmf_assign: the handle timed out inside a kernel; its state is invalid");
   if (W <= 0 || !h->arr[BNMF_P].ring) return fail(BNMF_ESTATE, "bnmf_assign: no recorded samples (window = 0)");
   if (last_n < 1 || last_n > W || last_n > h->iter) return fail(BNMF_ESIZE, "bnmf_assign: last_n = %d but only min(window = %d, iter = %d) samples are kept", last_n, W, h->iter);
   if (R < 1) return fail(BNMF_EINVAL, "bnmf_assign: empty reference");

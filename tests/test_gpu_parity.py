@@ -582,3 +582,126 @@ def test_reference_example_data_known_answer(rank, tmp_path):
     cos = _match_cosine(np.asarray(s.MAP["P"])[:, keep], Pt)
     assert cos.min() >= 0.95, cos
     s.close()
+
+
+@pytest.mark.parametrize("model", ["gamma_gate", "gamma_small", "mh", "rank"])
+def test_serial_mode_bitexact(model, monkeypatch):
+    """BNMF_SERIAL=1 (chosen automatically under counter collection, AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING): no kernel
+    polls for a kernel of another stream, every hand-off is a stream wait on an event.  Same chain, bit for bit, as the oracle —
+    for the gated fixed-rank sweep (BNMF_GATE=1 forced: the gate must stay off), the small fixed-rank sweep, an MH model and
+    rank learning."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    monkeypatch.setenv("BNMF_SERIAL", "1")
+    kw, prior, N = {}, "gamma", 12
+    if model == "gamma_gate":
+        monkeypatch.setenv("BNMF_GATE", "1")
+    elif model == "mh":
+        kw, prior = dict(MH=True), "truncnormal"
+    elif model == "rank":
+        kw = dict(learning_rank=True, temperature=np.concatenate([np.zeros(3), 10.0 ** np.linspace(-6, 0, 20), np.ones(60)]))
+    M, _, _ = synth_counts(96, 700, 4, 77)
+    o = O.Oracle(M, N, prior=prior, seed=31, nthreads=8, **kw)
+    e = Engine(M, N, prior=prior, seed=31, window=4, **kw)
+    for c in (o, e):
+        apply_hyperprior_params(c, prior, M, N)
+    o.init(); e.init()
+    for step, n_it in enumerate((1, 3, 11, 6)):
+        mo, me = o.run(n_it), e.run(n_it)
+        for nm in ("P", "E", "A"):
+            a, b = np.ascontiguousarray(o.get(nm), dtype=np.float64), np.ascontiguousarray(e.get(nm), dtype=np.float64)
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (nm, step)
+        assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), step
+    e.close()
+
+
+@pytest.mark.parametrize("model", ["gamma_gate", "mh", "rank"])
+def test_reinit_matches_fresh_handle(model, monkeypatch):
+    """bnmf_init on a handle that has already run restarts the chain: the device-side sync words (flag epochs, granule tags of
+    the rank sweep) and the host-side pipeline state are cleared, so init, run(n), init, run(n) ends where a fresh handle's
+    init, run(n) does — bit for bit."""
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    kw, prior, N = {}, "gamma", 10
+    if model == "gamma_gate":
+        monkeypatch.setenv("BNMF_GATE", "1")
+    elif model == "mh":
+        kw, prior = dict(MH=True), "exponential"
+    else:
+        kw = dict(learning_rank=True, temperature=np.concatenate([np.zeros(2), 10.0 ** np.linspace(-5, 0, 12), np.ones(60)]))
+    M, _, _ = synth_counts(96, 8200, 4, 5)          # G >= 8,000: several column blocks in the rank sweep, a long allocation kernel
+
+    def fresh():
+        e = Engine(M, N, prior=prior, seed=3, window=5, **kw)
+        apply_hyperprior_params(e, prior, M, N)
+        return e
+    a, b = fresh(), fresh()
+    a.init(); a.run(17); a.run(4)
+    r0 = a.init(); ma = a.run(23)
+    r1 = b.init(); mb = b.run(23)
+    assert np.array_equal(r0[:9].view(np.uint64), r1[:9].view(np.uint64))
+    assert np.array_equal(ma[:, :9].view(np.uint64), mb[:, :9].view(np.uint64))
+    for nm in ("P", "E", "A"):
+        assert np.array_equal(a.get(nm).view(np.uint64), b.get(nm).view(np.uint64)), nm
+    for x, y in zip(a.window("E", 5), b.window("E", 5)):
+        assert np.array_equal(np.ascontiguousarray(x).view(np.uint64), np.ascontiguousarray(y).view(np.uint64))
+    a.close(); b.close()
+
+
+def test_timeout_poisons_the_handle():
+    """A bounded in-kernel wait that gives up sets its word in mapped host memory: bnmf_run stops issuing, reports BNMF_EHIP with
+    the flag epochs, and the handle then refuses every call (its state is no longer the chain's) until it is destroyed."""
+    import ctypes as C
+    from bayesnmf_amd import Engine, engine as E
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    M, _, _ = synth_counts(96, 200, 4, 5)
+    e = Engine(M, 6, prior="gamma", seed=3, window=3)
+    apply_hyperprior_params(e, "gamma", M, 6)
+    e.init(); e.run(5)
+    L = E.lib()
+    L.bnmf_debug_set_timeout.argtypes = [C.c_void_p, C.c_int]
+    assert L.bnmf_debug_set_timeout(e._h, 0) == 0
+    it0 = e.iter
+    with pytest.raises(E.BnmfError) as ei:
+        e.run(50)
+    assert ei.value.code == -5 and "timed out" in str(ei.value) and "flags" in str(ei.value)
+    assert e.iter - it0 <= 2, "the run went on issuing iterations after the time-out"
+    for call in (lambda: e.run(1), lambda: e.get("P"), lambda: e.window("P", 2), lambda: e.map(2), lambda: e.init()):
+        with pytest.raises(E.BnmfError) as ei:
+            call()
+        assert ei.value.code == -7
+    e.close()
+
+
+@pytest.mark.parametrize("K,G,N", [(96, 3000, 20), (200, 130, 7), (96, 64, 24), (33, 700, 3)])
+@pytest.mark.parametrize("packed", ["1", "0"])
+def test_sorted_schedule_kernel_matches_register_kernel(K, G, N, packed, monkeypatch):
+    """k_zalloc_sort (static count-sorted schedule, stats mode) against k_zalloc_reg (BNMF_ZSORT=0) on the same chain: ZsumK,
+    ZsumG, metrics, P, E bit for bit; both layouts of the block tables (two factors per word / one), cells above 128 counts
+    (several items per cell), N at both ends of the template range."""
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import apply_hyperprior_params
+    rng = np.random.default_rng(K + G)
+    M = rng.poisson(rng.gamma(0.7, 60.0, size=(K, G))).astype(np.int32)
+    M[rng.uniform(size=M.shape) < 0.05] = 0
+    M[0, 0] = 3000
+
+    def mk(zs):
+        monkeypatch.setenv("BNMF_ZSORT", zs)
+        monkeypatch.setenv("BNMF_ZSPK", packed)
+        e = Engine(M, N, prior="gamma", seed=5)
+        apply_hyperprior_params(e, "gamma", M, N)
+        return e
+    e0, e1 = mk("0"), mk("1")
+    r0, r1 = e0.init(), e1.init()
+    assert np.array_equal(r0[:9].view(np.uint64), r1[:9].view(np.uint64))
+    for it in range(4):
+        m0, m1 = e0.run(2), e1.run(2)
+        assert np.array_equal(m0[:, :9].view(np.uint64), m1[:, :9].view(np.uint64)), it
+        for nm in ("ZsumK", "ZsumG"):
+            assert np.array_equal(e0.get(nm), e1.get(nm)), (nm, it)
+        for nm in ("P", "E"):
+            assert np.array_equal(e0.get(nm).view(np.uint64), e1.get(nm).view(np.uint64)), (nm, it)
+    assert (e1.get("ZsumK").sum(0) == M.sum(0)).all()
+    e0.close(); e1.close()
