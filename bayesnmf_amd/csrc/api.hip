@@ -289,6 +289,10 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
     std::stable_sort(tmp.begin(), tmp.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
     ZSBlock& bk = blocks[b];
     bk.item0 = (int)items.size(); bk.col0 = (int)cols.size(); bk.ncols = (int)bcols[b].size();
+    // inside a task (64 consecutive items) the order is free: ascending row, so that neighbouring lanes read neighbouring
+    // rows of the LDS copy of P and add to neighbouring words of the block's ZsumG table (few bank conflicts)
+    for (size_t i0 = 0; i0 < tmp.size(); i0 += 64)
+      std::sort(tmp.begin() + i0, tmp.begin() + std::min(tmp.size(), i0 + 64), [](const auto& a, const auto& b) { return (a.second & 1023u) < (b.second & 1023u); });
     for (const auto& it : tmp) items.push_back(it.second);
     while (items.size() % 64) items.push_back(0xFFFFFFFFu);
     bk.ntask = (int)((items.size() - (size_t)bk.item0) / 64);
@@ -1168,8 +1172,9 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
     tm.begin(KN_PDRAW, h->stream); launch_pdraw(h, t, 0, rec); tm.end(KN_PDRAW, h->stream);
     tm.begin(KN_EDRAW, h->stream); launch_edraw(h, t, 0, rec); tm.end(KN_EDRAW, h->stream);
     launch_side(h, t + 1, tm);
-  } else if (gate_enabled(h) && !h->cfg.learning_rank && poll && h->z_reg && !h->z_tile && h->z_gated_for == t) {
-    // merged draw kernel: the allocation kernel of t-1 has waited for this iteration's hyper sweep
+  } else if (gate_enabled(h) && !h->cfg.learning_rank && h->z_reg && !h->z_tile && (!poll || h->z_gated_for == t)) {
+    // merged draw kernel: the allocation kernel of t-1 has waited for this iteration's hyper sweep (its gate), or the main
+    // stream has (the event wait above: first sweep after init / set_array, serial mode)
     const unsigned nE = (unsigned)(((size_t)h->cfg.N * h->cfg.G + DW - 1) / DW);
     hipExtLaunchKernelGGL(k_draw, dim3(h->cfg.N + nE), dim3(DW), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, rec_at(h, t, rec),
                           SideDone{h->dFlags + 5, h->dFlags + 6, (unsigned)h->cfg.N, t}, SideWait{h->dFlags + 6, h->dFlags + 6, t, h->dErr},
