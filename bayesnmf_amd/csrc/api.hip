@@ -10,6 +10,7 @@
 #include <cstring>
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "kernels.h"
@@ -1322,7 +1323,14 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
   return 0;
 }
 
+// Two handles that learn the rank must not run on one device at the same time: each persistent rank sweep sizes its grid
+// as if it owned the device (one workgroup per CU, every workgroup waits for all others), and two half-resident grids
+// would wait for each other until their bounded spins give up.  Their calls take turns (a call is at most one block of
+// iterations between MAP checks).
+static std::mutex g_rank_turn[64];
 static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, Timer& tm) {
+  std::unique_lock<std::mutex> turn;
+  if (h && h->cfg.learning_rank && h->device >= 0 && h->device < 64) turn = std::unique_lock<std::mutex>(g_rank_turn[h->device]);
   if (!h) return fail(BNMF_EINVAL, "bnmf_run: null handle");
   if (!h->inited) return fail(BNMF_ESTATE, "bnmf_run: call bnmf_init first");
   if (h->poisoned) return fail(BNMF_ESTATE, "bnmf_run: an earlier call timed out inside a kernel; the handle's state is invalid, destroy it");
@@ -1514,6 +1522,52 @@ int bnmf_map(bnmf_handle* h, int last_n, double ci, double* P_mean, double* E_me
   return 0;
 }
 
+// One MAP check (R/bayesNMF_sampler.R:297-321): get_MAP_ over the last min(MAP_over, iter) samples on the device, the
+// state$MAP_metrics row (update_MAP_metrics_, R/utils.R:356-397) and check_convergence_ (R/convergence.R:60-154) into mr.
+static int map_check(bnmf_handle* h, const bnmf_convergence_control* cc, bnmf_convergence_state* st, const double* lastrow, double* mr,
+                     std::vector<double>& Am, std::vector<int32_t>& used) {
+  const int K = h->cfg.K, G = h->cfg.G, N = h->cfg.N;
+  const int it = h->iter;
+  const int win = it < cc->MAP_over ? it : cc->MAP_over;
+  bnmf_map_info info;
+  if (int rc = bnmf_map(h, win, 0.0, nullptr, nullptr, Am.data(), nullptr, nullptr, nullptr, nullptr, nullptr, used.data(), &info)) return rc;
+  // update_MAP_metrics_: loglikelihood / logposterior are means of the per-sample values over the whole window
+  double ll = 0.0, lp = 0.0, mt = 0.0, sumA = 0.0;
+  for (int i = it - win + 1; i <= it; ++i) {
+    const double* hrow = h->hist.data() + (size_t)((i - 1) % h->wcap) * 4;
+    ll += hrow[0]; lp += hrow[1];
+    mt += h->temp_host.empty() ? 1.0 : h->temp_host[std::min<size_t>((size_t)i - 1, h->temp_host.size() - 1)];
+  }
+  ll /= win; lp /= win; mt /= win;
+  for (int j = 0; j < N; ++j) sumA += Am[j];
+  const double n_params = sumA * (double)(G + K);
+  mr[0] = it; mr[1] = info.rmse; mr[2] = info.kl; mr[3] = ll; mr[4] = lp; mr[5] = n_params;
+  mr[6] = -2.0 * ll + n_params * std::log((double)G); mr[7] = sumA; mr[8] = info.top_counts[0]; mr[9] = mt;
+  mr[10] = lastrow[9]; mr[11] = lastrow[10];            // compute_metrics_ uses the CURRENT acceptance matrices
+  // check_convergence_
+  static const int col_of[5] = {3, 4, 1, 2, 6};
+  double m = mr[col_of[cc->metric]];
+  if (cc->metric <= 1) m = -m;
+  if (!st->have_prev) { st->prev_MAP_metric = m + 1.0; st->best_MAP_metric = m + 1.0; st->inarow_na = st->inarow_no_change = st->inarow_no_best = 0; st->have_prev = 1; }
+  const double pc = (m - st->prev_MAP_metric) / st->prev_MAP_metric;
+  st->prev_percent_change = pc; st->prev_MAP_metric = m;
+  if (pc != pc) { st->inarow_no_change = 0; st->inarow_no_best = 0; st->inarow_na += 1; }
+  else if (std::fabs(pc) < cc->tol) { st->inarow_no_change += 1; st->inarow_na = 0; }
+  else { st->inarow_no_change = 0; st->inarow_na = 0; }
+  bool temps_one = true;                                  // temperature_schedule[(iter - MAP_over):iter] == 1 (R drops index 0)
+  for (int i = std::max(it - cc->MAP_over, 1); i <= it && temps_one; ++i)
+    temps_one = h->temp_host.empty() || h->temp_host[std::min<size_t>((size_t)i - 1, h->temp_host.size() - 1)] == 1.0;
+  if (temps_one && it >= cc->miniters) {
+    if (m < st->best_MAP_metric) { st->best_MAP_metric = m; st->best_iter = it; st->inarow_no_best = 0; }
+    else st->inarow_no_best += 1;
+    if (st->inarow_no_change >= cc->Ninarow_nochange) { st->converged = 1; st->why = 1; }
+    else if (st->inarow_no_best >= cc->Ninarow_nobest) { st->converged = 1; st->why = 2; }
+    else if (it >= cc->maxiters) { st->converged = 1; st->why = 3; }
+  }
+  mr[12] = pc; mr[13] = st->inarow_no_change; mr[14] = st->inarow_no_best; mr[15] = st->inarow_na; mr[16] = st->converged;
+  return 0;
+}
+
 // The sampling loop up to convergence as ONE call: blocks of iterations up to the next MAP check, get_MAP_ on the device,
 // update_MAP_metrics_ (R/utils.R:356-397) and check_convergence_ (R/convergence.R:60-154) here on the host side of the ABI.
 int bnmf_run_until(bnmf_handle* h, const bnmf_convergence_control* cc, bnmf_convergence_state* st, double* metrics, int cap_rows,
@@ -1522,7 +1576,7 @@ int bnmf_run_until(bnmf_handle* h, const bnmf_convergence_control* cc, bnmf_conv
   if (!h->inited) return fail(BNMF_ESTATE, "bnmf_run_until: call bnmf_init first");
   if (h->cfg.window < cc->MAP_over) return fail(BNMF_ESTATE, "bnmf_run_until: the handle keeps %d samples, MAP_over = %d", h->cfg.window, cc->MAP_over);
   if (cc->MAP_every < 1 || cc->MAP_over < 1 || cc->metric < 0 || cc->metric > 4) return fail(BNMF_EINVAL, "bnmf_run_until: bad convergence control");
-  const int K = h->cfg.K, G = h->cfg.G, N = h->cfg.N;
+  const int N = h->cfg.N;
   *n_rows = 0; *n_checks = 0;
   std::vector<double> Am(N);
   std::vector<int32_t> used(cc->MAP_over);
@@ -1540,44 +1594,37 @@ int bnmf_run_until(bnmf_handle* h, const bnmf_convergence_control* cc, bnmf_conv
     const int over = cc->MAP_over > cc->MAP_every ? cc->MAP_over : cc->MAP_every;
     if (!((it % cc->MAP_every == 0 && it >= over) || it >= cc->maxiters)) continue;      // :288-296
     if (*n_checks >= cap_checks) return fail(BNMF_ESIZE, "bnmf_run_until: MAP-metrics buffer too small (%d rows)", cap_checks);
-    const int win = it < cc->MAP_over ? it : cc->MAP_over;
-    bnmf_map_info info;
-    if (int rc = bnmf_map(h, win, 0.0, nullptr, nullptr, Am.data(), nullptr, nullptr, nullptr, nullptr, nullptr, used.data(), &info)) return rc;
-    // update_MAP_metrics_: loglikelihood / logposterior are means of the per-sample values over the whole window
-    double ll = 0.0, lp = 0.0, mt = 0.0, sumA = 0.0;
-    for (int i = it - win + 1; i <= it; ++i) {
-      const double* hrow = h->hist.data() + (size_t)((i - 1) % h->wcap) * 4;
-      ll += hrow[0]; lp += hrow[1];
-      mt += h->temp_host.empty() ? 1.0 : h->temp_host[std::min<size_t>((size_t)i - 1, h->temp_host.size() - 1)];
-    }
-    ll /= win; lp /= win; mt /= win;
-    for (int j = 0; j < N; ++j) sumA += Am[j];
-    const double n_params = sumA * (double)(G + K);
-    double* mr = map_rows + (size_t)*n_checks * BNMF_NMAPROW;
-    mr[0] = it; mr[1] = info.rmse; mr[2] = info.kl; mr[3] = ll; mr[4] = lp; mr[5] = n_params;
-    mr[6] = -2.0 * ll + n_params * std::log((double)G); mr[7] = sumA; mr[8] = info.top_counts[0]; mr[9] = mt;
-    mr[10] = lastrow[9]; mr[11] = lastrow[10];            // compute_metrics_ uses the CURRENT acceptance matrices
-    // check_convergence_
-    static const int col_of[5] = {3, 4, 1, 2, 6};
-    double m = mr[col_of[cc->metric]];
-    if (cc->metric <= 1) m = -m;
-    if (!st->have_prev) { st->prev_MAP_metric = m + 1.0; st->best_MAP_metric = m + 1.0; st->inarow_na = st->inarow_no_change = st->inarow_no_best = 0; st->have_prev = 1; }
-    const double pc = (m - st->prev_MAP_metric) / st->prev_MAP_metric;
-    st->prev_percent_change = pc; st->prev_MAP_metric = m;
-    if (pc != pc) { st->inarow_no_change = 0; st->inarow_no_best = 0; st->inarow_na += 1; }
-    else if (std::fabs(pc) < cc->tol) { st->inarow_no_change += 1; st->inarow_na = 0; }
-    else { st->inarow_no_change = 0; st->inarow_na = 0; }
-    bool temps_one = true;                                  // temperature_schedule[(iter - MAP_over):iter] == 1 (R drops index 0)
-    for (int i = std::max(it - cc->MAP_over, 1); i <= it && temps_one; ++i)
-      temps_one = h->temp_host.empty() || h->temp_host[std::min<size_t>((size_t)i - 1, h->temp_host.size() - 1)] == 1.0;
-    if (temps_one && it >= cc->miniters) {
-      if (m < st->best_MAP_metric) { st->best_MAP_metric = m; st->best_iter = it; st->inarow_no_best = 0; }
-      else st->inarow_no_best += 1;
-      if (st->inarow_no_change >= cc->Ninarow_nochange) { st->converged = 1; st->why = 1; }
-      else if (st->inarow_no_best >= cc->Ninarow_nobest) { st->converged = 1; st->why = 2; }
-      else if (it >= cc->maxiters) { st->converged = 1; st->why = 3; }
-    }
-    mr[12] = pc; mr[13] = st->inarow_no_change; mr[14] = st->inarow_no_best; mr[15] = st->inarow_na; mr[16] = st->converged;
+    if (int rc = map_check(h, cc, st, lastrow, map_rows + (size_t)*n_checks * BNMF_NMAPROW, Am, used)) return rc;
+    *n_checks += 1; st->n_checks += 1;
+  }
+  return 0;
+}
+
+// The post-warm-up tail of the MH models as ONE call (R/bayesNMF_sampler.R:332-384): post_warmup more iterations with
+// state$converged = TRUE (true accept / reject), a MAP check whenever iter is a multiple of MAP_every and after the last one.
+int bnmf_run_post_warmup(bnmf_handle* h, const bnmf_convergence_control* cc, bnmf_convergence_state* st, int post_warmup,
+                         double* metrics, int cap_rows, int* n_rows, double* map_rows, int cap_checks, int* n_checks) {
+  if (!h || !cc || !st || !metrics || !n_rows || !map_rows || !n_checks) return fail(BNMF_EINVAL, "bnmf_run_post_warmup: null argument");
+  if (!h->inited) return fail(BNMF_ESTATE, "bnmf_run_post_warmup: call bnmf_init first");
+  if (post_warmup < 0) return fail(BNMF_EINVAL, "bnmf_run_post_warmup: post_warmup < 0");
+  if (h->cfg.window < cc->MAP_over) return fail(BNMF_ESTATE, "bnmf_run_post_warmup: the handle keeps %d samples, MAP_over = %d", h->cfg.window, cc->MAP_over);
+  if (cc->MAP_every < 1 || cc->MAP_over < 1 || cc->metric < 0 || cc->metric > 4) return fail(BNMF_EINVAL, "bnmf_run_post_warmup: bad convergence control");
+  *n_rows = 0; *n_checks = 0;
+  std::vector<double> Am(h->cfg.N);
+  std::vector<int32_t> used(cc->MAP_over);
+  Timer tm{h, false};
+  int done = 0;
+  while (done < post_warmup) {
+    const int it0 = h->iter;
+    const int nxt = (it0 / cc->MAP_every + 1) * cc->MAP_every;
+    const int n = std::min(nxt - it0, post_warmup - done);
+    if (*n_rows + n > cap_rows) return fail(BNMF_ESIZE, "bnmf_run_post_warmup: metrics buffer too small (%d rows)", cap_rows);
+    if (int rc = run_impl(h, n, 1, metrics + (size_t)*n_rows * BNMF_NMETRIC, tm)) return rc;
+    const double* lastrow = metrics + (size_t)(*n_rows + n - 1) * BNMF_NMETRIC;
+    *n_rows += n; done += n;
+    if (!(h->iter % cc->MAP_every == 0 || done == post_warmup)) continue;
+    if (*n_checks >= cap_checks) return fail(BNMF_ESIZE, "bnmf_run_post_warmup: MAP-metrics buffer too small (%d rows)", cap_checks);
+    if (int rc = map_check(h, cc, st, lastrow, map_rows + (size_t)*n_checks * BNMF_NMAPROW, Am, used)) return rc;
     *n_checks += 1; st->n_checks += 1;
   }
   return 0;

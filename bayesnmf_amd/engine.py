@@ -66,7 +66,7 @@ CC_METRICS = ["loglikelihood", "logposterior", "RMSE", "KL", "BIC"]
 WHY = {0: None, 1: "no change", 2: "no best", 3: "max iters"}
 
 ABI_SYMBOLS = ["bnmf_create", "bnmf_destroy", "bnmf_set_array", "bnmf_get_array", "bnmf_get_array_i32",
-               "bnmf_init", "bnmf_run", "bnmf_window", "bnmf_map", "bnmf_run_until", "bnmf_assign", "bnmf_get_iter", "bnmf_profile",
+               "bnmf_init", "bnmf_run", "bnmf_window", "bnmf_map", "bnmf_run_until", "bnmf_run_post_warmup", "bnmf_assign", "bnmf_get_iter", "bnmf_profile",
                "bnmf_kernel_name", "bnmf_test_math", "bnmf_test_sampler", "bnmf_test_philox",
                "bnmf_device_info", "bnmf_device_count", "bnmf_last_error", "bnmf_version"]
 
@@ -90,6 +90,8 @@ def lib():
         L.bnmf_map.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, dp, dp, dp, dp, dp, dp, dp, ip, C.POINTER(BnmfMapInfo)]
         L.bnmf_run_until.argtypes = [C.c_void_p, C.POINTER(BnmfConvergenceControl), C.POINTER(BnmfConvergenceState), dp, C.c_int,
                                      C.POINTER(C.c_int), dp, C.c_int, C.POINTER(C.c_int)]
+        L.bnmf_run_post_warmup.argtypes = [C.c_void_p, C.POINTER(BnmfConvergenceControl), C.POINTER(BnmfConvergenceState), C.c_int, dp, C.c_int,
+                                           C.POINTER(C.c_int), dp, C.c_int, C.POINTER(C.c_int)]
         L.bnmf_assign.argtypes = [C.c_void_p, C.c_int, ip, dp, C.c_int, ip, dp, C.c_double, dp, ip, dp, dp, dp]
         L.bnmf_get_iter.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.bnmf_profile.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
@@ -253,6 +255,18 @@ class Engine:
         nr, nc = C.c_int(), C.c_int()
         _chk(lib().bnmf_run_until(self._h, C.byref(c), C.byref(st), _dp(rows), cap_rows, C.byref(nr), _dp(maps), cap_checks, C.byref(nc)))
         return rows[:nr.value].copy(), maps[:nc.value].copy(), st
+
+    def run_post_warmup(self, cc, state, post_warmup):
+        """The MH models' post-warm-up tail in one C-ABI call.  Returns (metrics rows, MAP rows, state)."""
+        c = BnmfConvergenceControl(cc["MAP_over"], cc["MAP_every"], cc["Ninarow_nochange"], cc["Ninarow_nobest"], cc["miniters"],
+                                   cc["maxiters"], CC_METRICS.index(cc["metric"]), 0, cc["tol"])
+        cap_rows = int(post_warmup) + 1
+        cap_checks = cap_rows // cc["MAP_every"] + 3
+        rows, maps = np.empty((cap_rows, NMETRIC)), np.empty((cap_checks, NMAPROW))
+        nr, nc = C.c_int(), C.c_int()
+        _chk(lib().bnmf_run_post_warmup(self._h, C.byref(c), C.byref(state), int(post_warmup), _dp(rows), cap_rows, C.byref(nr), _dp(maps),
+                                        cap_checks, C.byref(nc)))
+        return rows[:nr.value].copy(), maps[:nc.value].copy(), state
 
     def assign(self, last_n, reference_P, used=None, keep=None, MAP_P=None, credible_interval=0.95):
         """assign_signatures_ensemble_ over recorded samples: votes (N x R), assigned reference per signature (-1 = not

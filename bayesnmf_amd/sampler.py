@@ -370,6 +370,10 @@ class bayesNMF_sampler:
             pw = self.specs["post_warmup"]
             self.log(f"Warmup done, sampling {pw} with MH for inference", verbosity=1)
             done = 0
+            if (hasattr(self._chain, "run_post_warmup") and self._block_hook is None and not self.specs["periodic_save"]
+                    and not self.specs["save_all_samples"] and self.specs.get("engine_side_convergence", True) and pw > 0):
+                self._post_warmup_on_engine(cc, pw)      # the tail as one engine call (bnmf_run_post_warmup)
+                done = pw
             while done < pw:
                 it = self.state["iter"]
                 nxt = (it // cc["MAP_every"] + 1) * cc["MAP_every"]
@@ -398,14 +402,23 @@ class bayesNMF_sampler:
         self.save_object()
         return self
 
-    def _run_until_on_engine(self, cc):
-        """The warm-up loop (blocks, MAP, MAP metrics, convergence bookkeeping) as one engine call (SURVEY.md 8 f2);
-        the R6-style state, both metric tables and the log lines are rebuilt from what it returns."""
-        from .engine import WHY
-        rows, maps, st = self._chain.run_until(cc)
-        if len(rows):
-            self._append_metrics(rows)
-            self.state["iter"] = int(rows[-1, 0])
+    def _cc_state(self):
+        """state$prev_MAP_metric ... as the C-ABI's bnmf_convergence_state."""
+        from .engine import BnmfConvergenceState, WHY
+        st = BnmfConvergenceState()
+        have = "prev_MAP_metric" in self.state
+        st.have_prev = 1 if have else 0
+        if have:
+            st.prev_MAP_metric = self.state["prev_MAP_metric"]; st.best_MAP_metric = self.state["best_MAP_metric"]
+            st.prev_percent_change = self.state.get("prev_percent_change", float("nan"))
+            st.inarow_na = int(self.state.get("inarow_na", 0)); st.inarow_no_change = int(self.state.get("inarow_no_change", 0))
+            st.inarow_no_best = int(self.state.get("inarow_no_best", 0)); st.best_iter = int(self.state.get("best_iter", 0) or 0)
+        st.converged = 1 if self.state["converged"] else 0
+        st.why = {v: k for k, v in WHY.items()}.get(self.state.get("why"), 0)
+        return st
+
+    def _absorb_map_rows(self, maps, cc):
+        """state$MAP_metrics rows and the log lines of the MAP checks an engine-side loop has made."""
         names = ["iter", "RMSE", "KL", "loglikelihood", "logposterior", "n_params", "BIC", "rank", "MAP_A_counts", "mean_temp",
                  "P_mean_acceptance_rate", "E_mean_acceptance_rate"]
         flip = -1 if cc["metric"] in ("loglikelihood", "logposterior") else 1
@@ -423,12 +436,36 @@ class bayesNMF_sampler:
             self.log("Checking convergence", verbosity=1)
             self.log(f"{cc['metric']} = {round(m, 2)} | {pcs}% change | {int(r[13])} no change | {int(r[14])} no best | {int(r[15])} NA", verbosity=1)
             self.state["indent"] = 1
+
+    def _absorb_cc_state(self, st):
         if st.have_prev:
             self.state.update(prev_MAP_metric=st.prev_MAP_metric, best_MAP_metric=st.best_MAP_metric,
                               prev_percent_change=st.prev_percent_change, inarow_na=st.inarow_na,
                               inarow_no_change=st.inarow_no_change, inarow_no_best=st.inarow_no_best)
             if st.best_iter:
                 self.state["best_iter"] = st.best_iter
+
+    def _post_warmup_on_engine(self, cc, pw):
+        """The MH models' post-warm-up iterations (R/bayesNMF_sampler.R:332-384) as one engine call; the final MAP (kept
+        signatures, credible intervals) is then taken from the device window as after the reference's last check."""
+        rows, maps, st = self._chain.run_post_warmup(cc, self._cc_state(), pw)
+        if len(rows):
+            self._append_metrics(rows)
+            self.state["iter"] = int(rows[-1, 0])
+        self._absorb_map_rows(maps, cc)
+        self._absorb_cc_state(st)
+        self.get_MAP(final=True)
+
+    def _run_until_on_engine(self, cc):
+        """The warm-up loop (blocks, MAP, MAP metrics, convergence bookkeeping) as one engine call (SURVEY.md 8 f2);
+        the R6-style state, both metric tables and the log lines are rebuilt from what it returns."""
+        from .engine import WHY
+        rows, maps, st = self._chain.run_until(cc)
+        if len(rows):
+            self._append_metrics(rows)
+            self.state["iter"] = int(rows[-1, 0])
+        self._absorb_map_rows(maps, cc)
+        self._absorb_cc_state(st)
         if st.converged:
             self.state["converged"] = True
             self.state["why"] = WHY[st.why]

@@ -204,6 +204,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the timings of BASELINE configs 2-5")
     ap.add_argument("--save-z", action="store_true", help="full mode: materialise Z every iteration")
     ap.add_argument("--G", type=int, default=G_)
+    ap.add_argument("--force-dist", action="store_true", help="initialise the nccl (RCCL) process group and run the gather / all-reduce "
+                                                               "legs even with one rank (exercises the collectives on a one-GPU box)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -220,9 +222,13 @@ def main():
         local_rank = 0
     tdev = "cpu" if rehearse else "cuda"
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1])); sk.close()
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         if rehearse:
             dist.init_process_group(backend="gloo")

@@ -144,6 +144,13 @@ int bnmf_run_until(bnmf_handle* h, const bnmf_convergence_control* cc, bnmf_conv
                    double* metrics_rowmajor, int cap_rows, int* n_rows, double* map_rows, int cap_checks,
                    int* n_checks);
 
+/* The post-warm-up tail of the MH models as ONE call (R/bayesNMF_sampler.R:332-384): post_warmup more iterations with
+ * state$converged = TRUE, i.e. true accept / reject in MH_Pn_poisson / MH_En_poisson (R/sample_Pn.R:199-248), a MAP check
+ * (rows as in bnmf_run_until) whenever iter is a multiple of MAP_every and after the last iteration. */
+int bnmf_run_post_warmup(bnmf_handle* h, const bnmf_convergence_control* cc, bnmf_convergence_state* st,
+                         int post_warmup, double* metrics_rowmajor, int cap_rows, int* n_rows, double* map_rows,
+                         int cap_checks, int* n_checks);
+
 /* Posterior reference assignment (assign_signatures_ensemble_, R/postprocessing.R:175-341; hungarian_assignment,
  * pairwise_sim, R/helpers.R:218-398) over the recorded samples flagged in used[last_n] (MAP$idx; NULL = all):
  * cosine similarities of every sample's included signatures (keep[N] flags; NULL = all) with the reference catalogue

@@ -6,9 +6,10 @@
 # Everything else (get_MAP, check_convergence, logging, save_object, summary/plot) is the reference's
 # own code operating on fields that are refreshed from the device at block boundaries.
 # EXPERIMENTAL: not runnable in this repository's container (no R).  The Python mirror bayesnmf_amd/sampler.py is
-# the tested equivalent and performs the same C-ABI call sequence; keep this file logic-free.  Faster paths that the
-# mirror uses and an R maintainer can bind the same way: bnmf_map (get_MAP on the device), bnmf_run_until (warm-up to
-# convergence in one call), bnmf_assign (assign_signatures_ensemble_): see INTEGRATION.md.
+# the tested equivalent and performs the same C-ABI call sequence; keep this file logic-free.  The MAP checks use
+# bnmf_map (get_MAP_ on the device: no window copy), the warm-up loop and the MH tail one call each (bnmf_run_until,
+# bnmf_run_post_warmup) unless periodic_save asks for the block-by-block loop; the recorded samples are materialised
+# into self$samples ONCE, at the end; assign_signatures_ensemble goes through bnmf_assign.  See INTEGRATION.md.
 
 .bnmf_ids <- c(P = 0L, E = 1L, A = 2L, R = 3L, Z = 4L, sigmasq = 7L,
                Alpha_p = 10L, Beta_p = 11L, Alpha_e = 12L, Beta_e = 13L, Mu_p = 14L, Sigmasq_p = 15L,
@@ -30,29 +31,73 @@ bayesNMF_sampler_hip <- R6::R6Class(
     run_gibbs_sampler = function() {
       cc <- self$specs$convergence_control
       start_time <- Sys.time()
-      while (!self$state$converged & self$state$iter < cc$maxiters) {
+      if (!self$specs$periodic_save) {
+        private$absorb(.Call("C_bnmf_run_until", self$handle, private$cc_int(), as.double(cc$tol), private$cc_state()), cc)
+      }
+      while (!self$state$converged & self$state$iter < cc$maxiters) {        # block-by-block (periodic_save)
         nxt <- (self$state$iter %/% cc$MAP_every + 1) * cc$MAP_every
         private$run_block(min(nxt, cc$maxiters) - self$state$iter, converged = FALSE)
         it <- self$state$iter
         if ((it %% cc$MAP_every == 0 & it >= max(cc$MAP_over, cc$MAP_every)) | it >= cc$maxiters) {
-          private$pull_window()
           self$get_MAP()
           msg <- private$check_convergence(); self$log(msg, verbosity = 1)
           if (self$specs$periodic_save) self$save_object()
         }
       }
       if (self$specs$MH) {
-        done <- 0
-        while (done < self$specs$post_warmup) {
-          n <- min(cc$MAP_every, self$specs$post_warmup - done)
-          private$run_block(n, converged = TRUE); done <- done + n
-          private$pull_window(); self$get_MAP(final = done == self$specs$post_warmup)
-          private$check_convergence(final = done == self$specs$post_warmup)
+        if (!self$specs$periodic_save) {
+          private$absorb(.Call("C_bnmf_run_post_warmup", self$handle, private$cc_int(), as.double(cc$tol), private$cc_state(),
+                               as.integer(self$specs$post_warmup)), cc)
+          self$get_MAP(final = TRUE)
+        } else {
+          done <- 0
+          while (done < self$specs$post_warmup) {
+            nxt <- (self$state$iter %/% cc$MAP_every + 1) * cc$MAP_every
+            n <- min(nxt - self$state$iter, self$specs$post_warmup - done)
+            private$run_block(n, converged = TRUE); done <- done + n
+            if (self$state$iter %% cc$MAP_every == 0 | done == self$specs$post_warmup) {
+              self$get_MAP(final = done == self$specs$post_warmup)
+              private$check_convergence(final = done == self$specs$post_warmup)
+              self$save_object()
+            }
+          }
         }
-      } else { private$pull_window(); self$get_MAP(final = TRUE) }
+      } else self$get_MAP(final = TRUE)
+      private$pull_state(); private$pull_window()      # self$params / self$samples for summary(), plot(), saveRDS: once
       self$time$total <- difftime(Sys.time(), start_time, units = "mins")
       self$time$per_iter <- self$time$total / self$state$iter
       self$save_object()
+    },
+    # get_MAP_ (R/utils.R:194-288) on the device: mode of A, renormalised means, 95 % bounds at the final MAP
+    get_MAP = function(final = FALSE, credible_interval = 0.95) {
+      n <- min(self$specs$convergence_control$MAP_over, self$state$iter)
+      r <- .Call("C_bnmf_map", self$handle, as.integer(n), as.double(if (final) credible_interval else 0),
+                 c(self$dims$K, self$dims$G, self$dims$N))
+      keep <- if (final) which(r$A[1, ] == 1) else seq_len(self$dims$N)
+      first <- self$state$iter - n + 1
+      pats <- apply(r$top_A[seq_len(min(5, r$n_patterns)), , drop = FALSE], 1, paste, collapse = "")
+      self$MAP <- list(P = r$P[, keep, drop = FALSE], A = r$A[, keep, drop = FALSE], E = r$E[keep, , drop = FALSE],
+                       idx = first + which(r$used) - 1, A_counts = stats::setNames(r$top_counts[seq_along(pats)], pats),
+                       keep_sigs = keep, RMSE = r$rmse, KL = r$kl)
+      if (final) self$credible_intervals <- list(P = list(lower = r$P_lower[, keep, drop = FALSE], upper = r$P_upper[, keep, drop = FALSE]),
+                                                 E = list(lower = r$E_lower[keep, , drop = FALSE], upper = r$E_upper[keep, , drop = FALSE]))
+      invisible(self$MAP)
+    },
+    # assign_signatures_ensemble_ (R/postprocessing.R:175-341) on the recorded window: cosine matrices on the device
+    assign_signatures_ensemble = function(reference_P, credible_interval = 0.95) {
+      n <- min(self$specs$convergence_control$MAP_over, self$state$iter)
+      used <- rep(FALSE, n); used[self$MAP$idx - (self$state$iter - n)] <- TRUE
+      keep <- rep(FALSE, self$dims$N); keep[self$MAP$keep_sigs] <- TRUE
+      Pfull <- matrix(0, self$dims$K, self$dims$N); Pfull[, self$MAP$keep_sigs] <- self$MAP$P
+      r <- .Call("C_bnmf_assign", self$handle, as.integer(n), used, as.matrix(reference_P), keep, Pfull, as.double(credible_interval),
+                 c(self$dims$K, self$dims$G, self$dims$N))
+      self$reference_comparison$reference_P <- reference_P
+      self$reference_comparison$votes <- r$votes[self$MAP$keep_sigs, , drop = FALSE]
+      self$reference_comparison$assignments <- data.frame(sig = self$MAP$keep_sigs, ref = colnames(reference_P)[r$assigned[self$MAP$keep_sigs]],
+                                                          cos_sim = r$MAP_cosine[self$MAP$keep_sigs], lower = r$lower[self$MAP$keep_sigs],
+                                                          upper = r$upper[self$MAP$keep_sigs])
+      self$reference_comparison$idxs <- self$MAP$idx
+      invisible(self$reference_comparison)
     }
   ),
   private = list(
@@ -81,6 +126,38 @@ bayesNMF_sampler_hip <- R6::R6Class(
       for (nm in skip) if (nm %in% names(.bnmf_ids)) .Call("C_bnmf_set_array", self$handle, .bnmf_ids[[nm]], as.double(self$params[[nm]]))
       row <- .Call("C_bnmf_init", self$handle)
       private$pull_state(); private$bind_metrics(matrix(row, ncol = 1))
+    },
+    cc_int = function() {
+      cc <- self$specs$convergence_control
+      as.integer(c(cc$MAP_over, cc$MAP_every, cc$Ninarow_nochange, cc$Ninarow_nobest, cc$miniters, cc$maxiters,
+                   match(cc$metric, c("loglikelihood", "logposterior", "RMSE", "KL", "BIC")) - 1L))
+    },
+    cc_state = function() {
+      st <- self$state; have <- !is.null(st$prev_MAP_metric)
+      nz <- function(x) if (is.null(x)) 0 else x
+      as.double(c(isTRUE(st$converged), match(nz(st$why), c("no change", "no best", "max iters"), nomatch = 0), nz(st$best_iter),
+                  nz(st$inarow_na), nz(st$inarow_no_change), nz(st$inarow_no_best), have, 0,
+                  if (have) st$prev_MAP_metric else 0, if (have) st$best_MAP_metric else 0, nz(st$prev_percent_change)))
+    },
+    # what an engine-side loop returns -> state$sample_metrics, state$MAP_metrics, the convergence counters
+    absorb = function(res, cc) {
+      if (ncol(res$metrics) > 0) { private$bind_metrics(res$metrics); self$state$iter <- res$metrics[1, ncol(res$metrics)] }
+      mm_names <- c("iter", "RMSE", "KL", "loglikelihood", "logposterior", "n_params", "BIC", "rank", "MAP_A_counts", "mean_temp",
+                    "P_mean_acceptance_rate", "E_mean_acceptance_rate")
+      for (j in seq_len(ncol(res$map_rows))) {
+        row <- as.data.frame(t(res$map_rows[1:12, j])); names(row) <- mm_names
+        self$state$MAP_metrics <- rbind(self$state$MAP_metrics, row[, names(self$state$MAP_metrics)])
+      }
+      st <- res$state
+      if (st[7] == 1) {
+        self$state$prev_MAP_metric <- st[9]; self$state$best_MAP_metric <- st[10]; self$state$prev_percent_change <- st[11]
+        self$state$inarow_na <- st[4]; self$state$inarow_no_change <- st[5]; self$state$inarow_no_best <- st[6]
+        if (st[3] > 0) self$state$best_iter <- st[3]
+      }
+      if (st[1] == 1 && !isTRUE(self$state$converged)) {
+        self$state$converged <- TRUE; self$state$why <- c("no change", "no best", "max iters")[st[2]]
+        self$state$converged_iter <- self$state$iter
+      }
     },
     record_sample = function() invisible(NULL),          # recorded on the device (bnmf_window)
     update_sample_metrics = function(update_trace = FALSE) invisible(NULL),

@@ -344,3 +344,95 @@ def test_randomised_parity_sweep():
     env = dict(os.environ, FUZZ_N="60", FUZZ_SEED="77")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _solo_metrics(M, rank, cc, out, **kw):
+    from bayesnmf_amd.sampler import bayesNMF
+    s = bayesNMF(M, rank, convergence_control=cc, output_dir=out, periodic_save=False, save_all_samples=False, **kw)
+    sm = s.state["sample_metrics"].to_numpy().copy()
+    s.close()
+    return sm
+
+
+def test_bic_sweep_runs_concurrent_handles_on_one_device(tmp_path):
+    """bayesNMF(rank_method = "BIC") (R/bayesNMF.R:66-126): one fixed-rank chain per rank, here as concurrent handles (one
+    host thread each) on ONE device.  Every chain is bit-identical to the same chain run alone."""
+    from bayesnmf_amd.sampler import bayesNMF
+    from bayesnmf_amd.convergence import new_convergence_control
+    from bayesnmf_amd.setup import synth_counts
+    M, _, _ = synth_counts(96, 1500, 3, 33)
+    cc = new_convergence_control(MAP_over=40, MAP_every=20, miniters=40, maxiters=120)
+    res = bayesNMF(M, [2, 3, 4, 5], rank_method="BIC", prior="gamma", convergence_control=cc, output_dir=str(tmp_path / "bic"),
+                   periodic_save=False, save_all_samples=False, seed=9, devices=[0])
+    assert sorted(res["results"]["rank"].tolist()) == [2, 3, 4, 5] and res["best_rank"] in (2, 3, 4, 5)
+    import glob
+    import pickle
+    for k in (2, 3, 4, 5):
+        solo = _solo_metrics(M, k, cc, str(tmp_path / f"solo{k}"), prior="gamma", seed=9)
+        with open(glob.glob(str(tmp_path / "bic" / f"rank_{k}" / "sampler.pkl"))[0], "rb") as f:
+            conc = pickle.load(f)["state"]["sample_metrics"].to_numpy()
+        assert conc.shape == solo.shape and np.array_equal(np.nan_to_num(conc), np.nan_to_num(solo)), k
+
+
+def test_run_chains_with_rank_learning_chains_sharing_a_device(tmp_path):
+    """run_chains with n_chains = 3 on one device where every chain learns the rank (G >= 8,000: each persistent rank sweep
+    wants a workgroup on most CUs, so two of them may not be co-resident — their calls take turns inside the library).
+    No time-out, every chain bit-identical to its solo run."""
+    from bayesnmf_amd.multichain import run_chains
+    from bayesnmf_amd.sampler import bayesNMF_sampler
+    from bayesnmf_amd.convergence import new_convergence_control
+    from bayesnmf_amd.setup import synth_counts
+    M, _, _ = synth_counts(96, 8200, 4, 41)
+    cc = new_convergence_control(MAP_over=20, MAP_every=10, miniters=20, maxiters=50)
+    kw = dict(prior="gamma", convergence_control=cc, periodic_save=False, save_all_samples=False, seed=4, prop_temp=0.4)
+    chains = run_chains(M, range(1, 9), n_chains=3, devices=[0], output_dir=str(tmp_path / "mc"), **kw)
+    for c, s in enumerate(chains):
+        solo = bayesNMF_sampler(M, range(1, 9), chain_id=c, device=0, output_dir=str(tmp_path / f"solo{c}"), **kw)
+        solo.run_gibbs_sampler()
+        a, b = s.state["sample_metrics"].to_numpy(), solo.state["sample_metrics"].to_numpy()
+        assert a.shape == b.shape and np.array_equal(np.nan_to_num(a), np.nan_to_num(b)), c
+        assert np.array_equal(s.params["A"], solo.params["A"])
+        solo.close(); s.close()
+
+
+def test_four_different_chains_at_once_match_their_solo_runs():
+    """Four handles of four different sweep types (gated fixed rank, rank learning, MH, exponential prior with K > 128) driven
+    from four host threads on one device: same bits as each chain alone (tools/concurrent_check.py in the suite)."""
+    import threading
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    cases = [dict(K=96, G=8000, N=20, kw=dict(prior="gamma"), window=30),
+             dict(K=96, G=900, N=8, kw=dict(prior="gamma", learning_rank=True, temperature=np.linspace(0.2, 1, 40)), window=0),
+             dict(K=96, G=1200, N=6, kw=dict(prior="truncnormal", MH=True), window=10),
+             dict(K=200, G=700, N=24, kw=dict(prior="exponential"), window=5)]
+
+    def make(c, cid):
+        M, _, _ = synth_counts(c["K"], c["G"], 4, 77 + cid)
+        e = Engine(M, c["N"], seed=5, chain_id=cid, window=c["window"], **c["kw"])
+        apply_hyperprior_params(e, c["kw"]["prior"], M, c["N"])
+        e.init()
+        return e
+    n = 60
+    alone = []
+    for cid, c in enumerate(cases):
+        e = make(c, cid)
+        m = np.concatenate([e.run(n // 2, converged=True), e.run(n - n // 2, converged=True)])
+        alone.append((m, e.get("P").copy(), e.get("E").copy()))
+        e.close()
+    es = [make(c, cid) for cid, c in enumerate(cases)]
+    out, err = [None] * len(es), [None] * len(es)
+
+    def work(i):
+        try:
+            out[i] = np.concatenate([es[i].run(n // 2, converged=True), es[i].run(n - n // 2, converged=True)])
+        except BaseException as ex:  # noqa: BLE001
+            err[i] = ex
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(es))]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert all(x is None for x in err), err
+    for i, e in enumerate(es):
+        assert np.array_equal(out[i][:, :9].view(np.uint64), alone[i][0][:, :9].view(np.uint64)), i
+        assert np.array_equal(e.get("P").view(np.uint64), alone[i][1].view(np.uint64)), i
+        assert np.array_equal(e.get("E").view(np.uint64), alone[i][2].view(np.uint64)), i
+        e.close()

@@ -1,0 +1,47 @@
+"""The RCCL path on hardware: `torch.distributed` backend "nccl" IS RCCL on ROCm.  A one-GPU box can only form a
+world of one rank, which still executes the real collectives (ncclAllGather / ncclAllReduce on the device, through the RCCL
+communicator) that the multi-GPU launcher uses at block boundaries.  Run in a child process: the process group is global."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_run_rank_over_a_world_of_one_nccl_rank(tmp_path):
+    code = textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 1000), RANK="0", WORLD_SIZE="1",
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import numpy as np, torch, torch.distributed as dist
+        from bayesnmf_amd.multichain import run_rank, gather_rows, all_converged
+        from bayesnmf_amd.convergence import new_convergence_control
+        from bayesnmf_amd.setup import synth_counts
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        assert dist.get_backend() == "nccl"
+        M, _, _ = synth_counts(96, 400, 3, 8)
+        cc = new_convergence_control(MAP_over=40, MAP_every=20, miniters=40, maxiters=100)
+        s, sync = run_rank(M, 3, dist, device=0, tensor_device="cuda", prior="gamma", convergence_control=cc,
+                           output_dir={str(tmp_path / 'o')!r}, periodic_save=False, save_all_samples=False, seed=2)
+        own = s.state["sample_metrics"].to_numpy()[1:, :9]
+        got = sync.metrics(0)[:, :9]
+        assert got.shape == own.shape and np.array_equal(np.nan_to_num(got), np.nan_to_num(own)), "rows gathered over RCCL differ from the chain's own"
+        assert sync.n_collectives >= 5 and sync.done == [True]
+        g = gather_rows(np.arange(6.0).reshape(2, 3), dist, device="cuda")
+        assert g.shape == (1, 2, 3) and np.array_equal(g[0], np.arange(6.0).reshape(2, 3))
+        t = torch.tensor([3.5], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t.item()) == 3.5 and all_converged(True, dist, device="cuda")
+        dist.barrier()
+        dist.destroy_process_group()
+        s.close()
+        print("RCCL_OK", sync.n_collectives)
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

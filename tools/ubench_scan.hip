@@ -10,6 +10,11 @@
 #include "../bayesnmf_amd/csrc/dmath.h"
 using namespace bnmf;
 
+__device__ __forceinline__ uint32_t gt1(uint32_t a, uint32_t u) {   // 1 if a > u else 0, without the condition-code path
+  uint32_t r;
+  asm("v_sub_u32_e64 %0, %1, %2 clamp\n\tv_min_u32_e32 %0, 1, %0" : "=v"(r) : "v"(a), "v"(u));
+  return r;
+}
 template <int MODE, int NT>
 __global__ __launch_bounds__(256) void kb(uint32_t* out, int quads, uint32_t seed) {
   __shared__ uint4 blk[8 * 256];        // MODE 2: [block][lane] threshold blocks (conflict-free 128-bit reads)
@@ -18,7 +23,7 @@ __global__ __launch_bounds__(256) void kb(uint32_t* out, int quads, uint32_t see
   uint32_t thr[NT], c[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) { thr[n] = (uint32_t)(((uint64_t)(n + 1) << 32) / (NT + 1)) + gid * 7u; c[n] = 0; }
-  if (MODE == 2) {
+  if (MODE == 2 || MODE == 4) {
     for (int j = 0; j < 8; ++j) blk[j * 256 + tid] = uint4{thr[(4 * j) % NT], thr[(4 * j + 1) % NT], thr[(4 * j + 2) % NT], thr[(4 * j + 3) % NT]};
     for (int j = 0; j < 32; ++j) hist[j * 256 + tid] = 0;
     __syncthreads();
@@ -37,6 +42,22 @@ __global__ __launch_bounds__(256) void kb(uint32_t* out, int quads, uint32_t see
       }
     } else if (MODE == 1) {
       c[0] += u0 ^ u1 ^ u2 ^ u3;
+    } else if (MODE == 4) {   // as MODE 2 with the saturating-subtract compare form
+      constexpr int NPV = (NT + 3) / 4 - 1;
+      uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+#pragma unroll
+      for (int p = 0; p < NPV; ++p) {
+        const uint32_t pv = thr[4 * p + 3];
+        g0 += gt1(pv, u0); g1 += gt1(pv, u1); g2 += gt1(pv, u2); g3 += gt1(pv, u3);
+      }
+      const uint32_t j0 = NPV - g0, j1 = NPV - g1, j2 = NPV - g2, j3 = NPV - g3;
+      const uint4 k0 = blk[j0 * 256 + tid], k1 = blk[j1 * 256 + tid], k2 = blk[j2 * 256 + tid], k3 = blk[j3 * 256 + tid];
+      const uint32_t b0 = 4 * j0 + 3 - (gt1(k0.x, u0) + gt1(k0.y, u0) + gt1(k0.z, u0));
+      const uint32_t b1 = 4 * j1 + 3 - (gt1(k1.x, u1) + gt1(k1.y, u1) + gt1(k1.z, u1));
+      const uint32_t b2 = 4 * j2 + 3 - (gt1(k2.x, u2) + gt1(k2.y, u2) + gt1(k2.z, u2));
+      const uint32_t b3 = 4 * j3 + 3 - (gt1(k3.x, u3) + gt1(k3.y, u3) + gt1(k3.z, u3));
+      atomicAdd(&hist[b0 * 256 + tid], 1u); atomicAdd(&hist[b1 * 256 + tid], 1u);
+      atomicAdd(&hist[b2 * 256 + tid], 1u); atomicAdd(&hist[b3 * 256 + tid], 1u);
     } else {
       constexpr int NPV = (NT + 3) / 4 - 1;
       uint32_t j0 = 0, j1 = 0, j2 = 0, j3 = 0;
@@ -57,7 +78,7 @@ __global__ __launch_bounds__(256) void kb(uint32_t* out, int quads, uint32_t see
   uint32_t s = lcg;
 #pragma unroll
   for (int n = 0; n < NT; ++n) s += c[n] * (n + 1);
-  if (MODE == 2) for (int j = 0; j < 32; ++j) s += hist[j * 256 + tid];
+  if (MODE == 2 || MODE == 4) for (int j = 0; j < 32; ++j) s += hist[j * 256 + tid];
   out[gid] = s;
 }
 template <int MODE, int NT>
@@ -75,13 +96,10 @@ void run(const char* name, int wavesPerSimd) {
   hipFree(d);
 }
 int main() {
-  for (int w : {1, 2, 4, 6, 8}) {
+  for (int w : {1, 2, 3, 4}) {
     run<1, 19>("philox only", w);
-    run<3, 19>("scan only (LCG words)", w);
-    run<0, 19>("philox + linear scan", w);
-    if (w <= 4) run<2, 19>("philox + pivots + LDS block + LDS hist", w);
-    run<0, 49>("philox + linear scan", w);
-    if (w <= 2) run<0, 99>("philox + linear scan", w);
+    run<2, 19>("philox + pivots + LDS block + LDS hist", w);
+    run<4, 19>("same, saturating-subtract compares", w);
   }
   return 0;
 }
