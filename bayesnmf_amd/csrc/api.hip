@@ -1742,6 +1742,57 @@ int bnmf_assign(bnmf_handle* h, int last_n, const int32_t* used, const double* r
   return 0;
 }
 
+// ---- measured ceilings for bench.py's roofline: Philox4x32-10 words per second with nothing else in the loop (the floor of
+// any allocation kernel: one word per count), and the device-to-device copy bandwidth ----
+__global__ __launch_bounds__(256) void k_ubench_philox(uint32_t* out, int blocks_per_lane, uint32_t seed) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t acc = 0;
+  for (int q = 0; q < blocks_per_lane; ++q) {
+    const u32x4 w = philox4x32_10((uint32_t)q, gid, seed, 5u, 17u, 29u);
+    acc += w.x ^ w.y ^ w.z ^ w.w;
+  }
+  out[gid] = acc;
+}
+int bnmf_ubench(int device, double* philox_words_per_s, double* copy_gbs) {
+  if (!philox_words_per_s || !copy_gbs) return fail(BNMF_EINVAL, "bnmf_ubench: null argument");
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  {
+    const int wgs = prop.multiProcessorCount * 8, nq = 4000;                 // 8 waves per SIMD
+    uint32_t* d = nullptr;
+    HIPCHK(hipMalloc(&d, (size_t)wgs * 256 * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_ubench_philox, dim3(wgs), dim3(256), 0, 0, d, 200, 1u);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_ubench_philox, dim3(wgs), dim3(256), 0, 0, d, nq, 1u);
+    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *philox_words_per_s = 4.0 * nq * (double)wgs * 256.0 / (ms * 1e-3);
+    hipFree(d);
+  }
+  {
+    const size_t bytes = (size_t)1 << 30;
+    char *a = nullptr, *b = nullptr;
+    HIPCHK(hipMalloc(&a, bytes)); HIPCHK(hipMalloc(&b, bytes));
+    HIPCHK(hipMemset(a, 1, bytes));
+    HIPCHK(hipMemcpy(b, a, bytes, hipMemcpyDeviceToDevice));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipEventRecord(e0, 0));
+    for (int r = 0; r < 4; ++r) HIPCHK(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0));
+    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *copy_gbs = 4.0 * 2.0 * (double)bytes / (ms * 1e-3) / 1e9;               // read + write
+    hipFree(a); hipFree(b);
+  }
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  return 0;
+}
+
 // ---- device-side probes for the parity tests ----
 int bnmf_test_math(int device, int fn, const double* in, double* out, size_t n) {
   HIPCHK(hipSetDevice(device));

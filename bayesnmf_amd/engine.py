@@ -67,7 +67,7 @@ WHY = {0: None, 1: "no change", 2: "no best", 3: "max iters"}
 
 ABI_SYMBOLS = ["bnmf_create", "bnmf_destroy", "bnmf_set_array", "bnmf_get_array", "bnmf_get_array_i32",
                "bnmf_init", "bnmf_run", "bnmf_window", "bnmf_map", "bnmf_run_until", "bnmf_run_post_warmup", "bnmf_assign", "bnmf_get_iter", "bnmf_profile",
-               "bnmf_kernel_name", "bnmf_test_math", "bnmf_test_sampler", "bnmf_test_philox",
+               "bnmf_kernel_name", "bnmf_ubench", "bnmf_test_math", "bnmf_test_sampler", "bnmf_test_philox",
                "bnmf_device_info", "bnmf_device_count", "bnmf_last_error", "bnmf_version"]
 
 
@@ -97,6 +97,7 @@ def lib():
         L.bnmf_profile.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
         L.bnmf_kernel_name.restype = C.c_char_p
         L.bnmf_kernel_name.argtypes = [C.c_int]
+        L.bnmf_ubench.argtypes = [C.c_int, dp, dp]
         L.bnmf_test_math.argtypes = [C.c_int, C.c_int, dp, dp, C.c_size_t]
         L.bnmf_test_sampler.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.c_uint32, dp, dp, dp, dp, C.c_size_t]
@@ -120,6 +121,13 @@ def _dp(a):
 
 def device_count():
     return lib().bnmf_device_count()
+
+
+def ubench(device=0):
+    """Measured ceilings: (Philox4x32-10 words/s with nothing else in the loop, device-to-device copy GB/s)."""
+    a, b = C.c_double(), C.c_double()
+    _chk(lib().bnmf_ubench(device, C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 def device_info(device=0):

@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 K_, G_, N_, R_TRUE, DATA_SEED = 96, 10000, 20, 8, 20250218
 MAP_OVER = 1000                # new_convergence_control() default: depth of the record_sample ring
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 
 def z_bytes(K, G, N, save_Z):
@@ -55,15 +55,37 @@ def pmc_traffic(save_Z):
     return None
 
 
-def roofline_of(chain, K, G, N, save_Z, total_counts, n_iter, kernel="k_zalloc_reg"):
+_CEILINGS = {}
+
+
+def ceilings(device):
+    """Measured ceilings of this box: Philox4x32-10 words/s with nothing else in the loop (one word per
+    allocated count is the floor of any allocation kernel) and the device-to-device copy bandwidth, next to the nominal 8 TB/s."""
+    if device not in _CEILINGS:
+        from bayesnmf_amd.engine import ubench
+        _CEILINGS[device] = ubench(device)
+    return _CEILINGS[device]
+
+
+def roofline_of(chain, K, G, N, save_Z, total_counts, n_iter, kernel=None, device=0):
     prof = chain.profile(n_iter)
     zb = z_bytes(K, G, N, save_Z)
     z_ms = prof["k_zalloc"]
     achieved = zb / (z_ms * 1e-3) / 1e9 if z_ms > 0 else 0.0
-    return prof, {"bound": "hbm", "kernel": kernel + ("<save_Z>" if save_Z else ""), "achieved": achieved,
+    philox_peak, copy_gbs = ceilings(device)
+    draws = total_counts / (z_ms * 1e-3) if z_ms > 0 else 0.0
+    if kernel is None:
+        kernel = "k_zalloc_reg<save_Z>" if save_Z else "k_zalloc_sort"
+    return prof, {"bound": "hbm", "kernel": kernel, "achieved": achieved,
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(save_Z),
+                  "peak_measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs > 0 else None,
                   "algorithmic_bytes_per_launch": zb, "avg_launch_ms": z_ms,
-                  "draws_per_s": total_counts / (z_ms * 1e-3) if z_ms > 0 else 0.0,
+                  "draws_per_s": draws,
+                  # the bound that actually binds in stats mode: one Philox word per allocated count
+                  "alu": {"achieved_philox_words_per_s": draws, "peak_philox_words_per_s": philox_peak,
+                          "frac": draws / philox_peak if philox_peak > 0 else None,
+                          "note": "peak = Philox4x32-10 alone at 8 waves/SIMD, measured on this box (bnmf_ubench); the kernel also "
+                                  "searches 19 thresholds and updates two tables per word"},
                   "note": "stats mode moves 6.3 MB per 40 M categorical draws: the kernel is VALU/Philox-bound, not HBM-bound (DESIGN.md 5)"
                           if not save_Z else "full mode: Z (K x N x G int32) written every iteration"}
 
@@ -157,16 +179,26 @@ def secondary_configs(device, quick=False):
                                "frac": zb / (zms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             rec["kernel_ms"] = prof
         else:
-            # sequential-in-n Normal-approximation sweeps: every factor update reads M (int32) and Mhat-sized data once
-            b = N * 2 * (4 * K * G + 8 * N * G)
-            rec["roofline"] = {"bound": "hbm", "kernel": "k_mh_*", "algorithmic_bytes_per_iteration": b,
-                               "achieved": b * rec["it_per_s"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": b * rec["it_per_s"] / 1e9 / HBM_PEAK_GBS}
+            # 2N sequential factor steps per iteration on data that stays in L2 (M, Mhat, E: a few MB): latency-bound, not an
+            # HBM stream.  What is reported is the time per factor step and the CUs the P side can use (one workgroup per row).
+            prof = c.profile(max(3, iters // 10))
+            rec["kernel_ms"] = prof
+            rec["roofline"] = {"bound": "latency (sequential-in-n sweeps on L2-resident data; no HBM or MFMA roofline applies)",
+                               "kernel": "k_mh_prow + k_mh_ecol16", "us_per_factor_step": 1e6 / (rec["it_per_s"] * 2 * N),
+                               "us_per_factor_step_after_convergence": 1e6 / (rec["it_per_s_after_convergence"] * 2 * N),
+                               "P_side_workgroups": K, "CUs": 256}
+        if kw.get("learning_rank") and "kernel_ms" in rec:
+            # the persistent rank sweep: N sequential decisions, each one alternative Poisson log-likelihood per cell (fp64 log)
+            rk_ms = rec["kernel_ms"].get("k_rank", 0.0)
+            rec["roofline_k_rank_sweep"] = {"bound": "fp64 VALU (software log) + per-factor exchange", "avg_launch_ms": rk_ms,
+                                            "log_evaluations_per_launch": N * K * G,
+                                            "achieved_log_per_s": N * K * G / (rk_ms * 1e-3) if rk_ms > 0 else None,
+                                            "us_per_factor": 1e3 * rk_ms / N}
         rec["setup_s"] = time.perf_counter() - t0
         c.close()
         out.append(rec)
 
-    run("2: Poisson-Gamma fixed rank N=20, K=96 x G=2,000", 96, 2000, 20, "gamma", 1000, 8, 2, "k_zalloc_reg")
+    run("2: Poisson-Gamma fixed rank N=20, K=96 x G=2,000", 96, 2000, 20, "gamma", 1000, 8, 2, "k_zalloc_sort")
     run("3: Poisson-TruncNormal+MH fixed rank N=20, K=96 x G=5,000", 96, 5000, 20, "truncnormal", 60, 8, 3, "k_mh", MH=True)
     run("4: Poisson-Gamma SBFI learned rank 1:50, K=96 x G=10,000", 96, 10000, 50, "gamma", 60, 12, 4, "k_zalloc_tile (+ memset, k_colmetrics)",
         learning_rank=True, rank_method="SBFI", temperature=np.ones(8000))
@@ -230,10 +262,22 @@ def main():
             sk = socket.socket(); sk.bind(("127.0.0.1", 0)); os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1])); sk.close()
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        if rehearse:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on STDOUT when its first communicator is created: keep the contract (rank 0 prints ONE
+        # JSON line) by pointing fd 1 at stderr while the group is set up and the first collective runs
+        sys.stdout.flush()
+        keep_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if rehearse:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep_fd, 1)
+            os.close(keep_fd)
     else:
         torch.cuda.set_device(local_rank)
 
@@ -250,7 +294,7 @@ def main():
     chain.run(args.warmup, metrics=False)
     # roofline of the dominant kernel (k_zalloc): HIP events on the chain's own stream, one kernel at a time.
     # Done before the timed region (it advances the chain like any other iterations and keeps the clocks up).
-    prof, roof = roofline_of(chain, K_, args.G, N_, args.save_z, total_counts, min(200, max(20, args.steps // 10)))
+    prof, roof = roofline_of(chain, K_, args.G, N_, args.save_z, total_counts, min(200, max(20, args.steps // 10)), device=local_rank)
     chain.run(max(args.warmup, 20), metrics=False)   # refill the two-stream pipeline after the serialised profile pass
 
     rep_dt = []
@@ -296,10 +340,11 @@ def main():
             # the same kernel in full mode (Z materialised): the only mode in which HBM traffic is substantial
             cz = make_chain(M, N_, seed=1, chain_id=0, device=local_rank, save_Z=True, window=0)
             cz.run(50, metrics=False)
-            _, out["roofline_save_Z"] = roofline_of(cz, K_, args.G, N_, True, total_counts, 100)
+            _, out["roofline_save_Z"] = roofline_of(cz, K_, args.G, N_, True, total_counts, 100, device=local_rank)
             cz.close()
         if gathered is not None:
             out["chains_final_logposterior"] = [float(g[0][4]) for g in gathered]
+            out["collectives"] = {"backend": "gloo" if rehearse else "nccl (RCCL)", "world": world, "forced_on_one_rank": bool(args.force_dist and world == 1)}
     chain.close()
     if rank == 0:
         if world == 1 and not args.no_secondary:

@@ -171,6 +171,11 @@ int bnmf_get_iter(bnmf_handle* h, int* iter);
 int bnmf_profile(bnmf_handle* h, int n_iter, int converged, double* out_ms);
 const char* bnmf_kernel_name(int i);
 
+/* measured ceilings of the device for bench.py's roofline: Philox4x32-10 words per second with nothing else in the loop
+ * (one word per allocated count: the floor of sample_Zkg, R/sample_params.R:253-265) and the device-to-device copy
+ * bandwidth in GB/s (read + write), next to the nominal 8 TB/s */
+int bnmf_ubench(int device, double* philox_words_per_s, double* copy_gbs);
+
 /* device-side unit probes used by the parity tests (tests/test_gpu_*.py) */
 int bnmf_test_math(int device, int fn, const double* in, double* out, size_t n);
 int bnmf_test_sampler(int device, int which, uint64_t seed, uint32_t chain, uint32_t var,
