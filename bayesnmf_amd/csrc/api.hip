@@ -43,6 +43,7 @@ struct bnmf_handle {
   hipEvent_t ev_draw = nullptr, ev_side = nullptr, ev_sideP = nullptr, ev_p = nullptr, ev_z = nullptr, ev_red = nullptr, ev_rank = nullptr;
   bool side_valid = false;             // k_side of iteration iter+1 has been issued
   int gate_forced = -1;                // BNMF_GATE at bnmf_create: 0 / 1 forces the merged draw kernel off / on, else by size
+  int draw_bw = 0;                     // lanes per workgroup of the merged draw kernel (chosen at the first launch)
   int gate_f0 = 1;                     // flag the gate waits for beside [3]: [1] E-side sweep (k_side), [9] P-side sweep on its own stream (merged draw path)
   uint32_t z_gate_next = 0;            // != 0: the allocation kernel being launched waits at its end for the hyper sweep of this iteration
   uint32_t z_gated_for = 0;            // the last allocation kernel gated for this iteration's hyper sweep (merged draw kernel, BNMF_GATE)
@@ -178,7 +179,8 @@ static int ensure_alut(int device) {
   static bool done[64] = {};
   if (device < 0 || device >= 64) return fail(BNMF_EINVAL, "device %d out of range", device);
   if (done[device]) return 0;
-  hipLaunchKernelGGL(k_alut_fill, dim3((ALUT_N + 255) / 256), dim3(256), 0, 0);
+  hipLaunchKernelGGL(k_alut_fill, dim3((ALUT_N + 255) / 256), dim3(256), 0, 0, 0);
+  hipLaunchKernelGGL(k_alut_fill, dim3((ALUT_N + 255) / 256), dim3(256), 0, 0, 1);
   HIPCHK(hipGetLastError());
   HIPCHK(hipDeviceSynchronize());
   done[device] = true;
@@ -1176,8 +1178,19 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   } else if (gate_enabled(h) && !h->cfg.learning_rank && h->z_reg && !h->z_tile && (!poll || h->z_gated_for == t)) {
     // merged draw kernel: the allocation kernel of t-1 has waited for this iteration's hyper sweep (its gate), or the main
     // stream has (the event wait above: first sweep after init / set_array, serial mode)
-    const unsigned nE = (unsigned)(((size_t)h->cfg.N * h->cfg.G + DW - 1) / DW);
-    hipExtLaunchKernelGGL(k_draw, dim3(h->cfg.N + nE), dim3(DW), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, rec_at(h, t, rec),
+    // workgroup width: the E elements spread over (almost) all CUs in ONE round of workgroups — 1,024-lane workgroups left
+    // 60 of 256 CUs idle at N G = 200,000 — while the workgroup count stays small (the gap to the next kernel grows with it)
+    if (!h->draw_bw) {
+      hipDeviceProp_t pr;
+      HIPCHK(hipGetDeviceProperties(&pr, h->device));
+      const size_t per_cu = ((size_t)h->cfg.N * h->cfg.G + pr.multiProcessorCount - 1) / pr.multiProcessorCount;
+      size_t bw = ((per_cu + 63) / 64) * 64 + 64;        // one wave of slack: a few CUs take two small workgroups rather than one a second round
+      h->draw_bw = (int)std::min<size_t>(DW, std::max<size_t>(256, bw));
+      if (const char* e = getenv("BNMF_DRAWBW")) { const int v = atoi(e); if (v >= 64 && v <= DW && v % 64 == 0) h->draw_bw = v; }   // diagnostics
+    }
+    const unsigned bw = (unsigned)h->draw_bw;
+    const unsigned nE = (unsigned)(((size_t)h->cfg.N * h->cfg.G + bw - 1) / bw);
+    hipExtLaunchKernelGGL(k_draw, dim3(h->cfg.N + nE), dim3(bw), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, rec_at(h, t, rec),
                           SideDone{h->dFlags + 5, h->dFlags + 6, (unsigned)h->cfg.N, t}, SideWait{h->dFlags + 6, h->dFlags + 6, t, h->dErr},
                           rec_at(h, t + 1, rec), SideDone{h->dFlags, h->dFlags + 1, nE, t + 1});
     launch_side_merged(h, t + 1, tm);

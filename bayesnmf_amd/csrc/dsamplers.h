@@ -205,15 +205,17 @@ BNMF_DEV double ralpha(Stream& s, double c, double tau, double xprev, int* n_att
 // a row: the general 3-tangent sampler ralpha, on the same stream.
 constexpr int ALUT_I0 = 1013 << 6;     // 2^-10 <= 1e-3
 constexpr int ALUT_N = 24 * 64;        // up to 2^14 > 1e4
-__device__ double g_alut[2 * ALUT_N];
+__device__ double g_alut[3 * ALUT_N];   // lgamma, digamma at the grid point; slope of the chord of lgamma to the next one
 BNMF_DEV double alut_x(int i) { return __longlong_as_double((long long)((uint64_t)((uint32_t)(i + ALUT_I0) << 14) << 32)); }
 BNMF_DEV int alut_idx(double x) {
   const int i = (int)((uint32_t)((uint64_t)__double_as_longlong(x) >> 32) >> 14) - ALUT_I0;
   return i < 0 ? 0 : (i > ALUT_N - 1 ? ALUT_N - 1 : i);
 }
-__global__ void k_alut_fill() {
+__global__ void k_alut_fill(int pass) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < ALUT_N) { double lg, dg; lgamma_digamma<true>(alut_x(i), lg, dg); g_alut[2 * i] = lg; g_alut[2 * i + 1] = dg; }
+  if (i >= ALUT_N) return;
+  if (pass == 0) { double lg, dg; lgamma_digamma<true>(alut_x(i), lg, dg); g_alut[3 * i] = lg; g_alut[3 * i + 1] = dg; }
+  else g_alut[3 * i + 2] = i + 1 < ALUT_N ? (g_alut[3 * (i + 1)] - g_alut[3 * i]) / (alut_x(i + 1) - alut_x(i)) : g_alut[3 * i + 1];
 }
 constexpr int FAST_ATTEMPTS = 64;
 BNMF_DEV double ralpha_fast(Stream& s, double c, double tau, double xprev, int* n_attempts = nullptr) {
@@ -225,7 +227,7 @@ BNMF_DEV double ralpha_fast(Stream& s, double c, double tau, double xprev, int* 
   const double cm1 = c - 1.0;
   for (int it = 0; it < 12; ++it) {    // H(x) = (c-1)/x - tau - psi(x), psi from the table, psi'(x) ~ 1/x + 1/x^2
     const int i = alut_idx(x);
-    const double xg = alut_x(i), psi = g_alut[2 * i + 1];
+    const double xg = alut_x(i), psi = g_alut[3 * i + 1];
     const double inv = 1.0 / xg;
     const double H = (cm1 * inv - tau) - psi;
     const double dH = -cm1 * (inv * inv) - (inv + inv * inv);
@@ -239,7 +241,7 @@ BNMF_DEV double ralpha_fast(Stream& s, double c, double tau, double xprev, int* 
     if (dx <= 0.03 * xg) break;
   }
   const int i0 = alut_idx(x);
-  const double x0 = alut_x(i0), lg0 = g_alut[2 * i0], psi0 = g_alut[2 * i0 + 1];
+  const double x0 = alut_x(i0), lg0 = g_alut[3 * i0], psi0 = g_alut[3 * i0 + 1];
   const double r = tau + psi0;
   // expected acceptance ~ 1 / sqrt(1 + rho), rho = psi'(x0) var(x): a broad or skewed target (small c) goes to the general sampler
   const double i0v = 1.0 / x0, tri = i0v + i0v * i0v;
@@ -257,8 +259,17 @@ BNMF_DEV double ralpha_fast(Stream& s, double c, double tau, double xprev, int* 
     v = v * v * v;
     const double xs = (d * v) / r;
     if (!(xs >= L && xs <= U)) continue;
-    const double rhs = (0.5 * (z * z) + d * ((1.0 - v) + dlog(v))) + ((b0 + psi0 * xs) - dlgamma(xs));
-    if (dlog(u) < rhs) { if (n_attempts) *n_attempts = it + 1; return xs; }
+    // lgamma(xs) between its tangent at the grid point below xs and its chord to the next one (lgamma is convex): most
+    // attempts are decided without evaluating it
+    const double a = (0.5 * (z * z) + d * ((1.0 - v) + dlog(v))) + (b0 + psi0 * xs);
+    const double lu = dlog(u);
+    const int ix = alut_idx(xs);
+    const double dx = xs - alut_x(ix);
+    bool accept;
+    if (dx >= 0.0 && ix + 1 < ALUT_N && lu < a - (g_alut[3 * ix] + g_alut[3 * ix + 2] * dx)) accept = true;           // below a - chord
+    else if (dx >= 0.0 && ix + 1 < ALUT_N && lu >= a - (g_alut[3 * ix] + g_alut[3 * ix + 1] * dx)) accept = false;    // at / above a - tangent
+    else accept = lu < a - dlgamma(xs);
+    if (accept) { if (n_attempts) *n_attempts = it + 1; return xs; }
   }
   int na = 0;
   const double xs = ralpha(s, c, tau, xprev, &na);

@@ -291,11 +291,12 @@ constexpr int DW = 1024;
 __global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, SideDone pd, SideWait pw, RecDst rec_next, SideDone ed) {
   __shared__ double Pn[DW];
   const int tid = threadIdx.x, N = d.N, K = d.K;
+  const int BW = blockDim.x;                              // <= DW: chosen by the host so that the E workgroups fill the CUs once
   if ((int)blockIdx.x < N) {
     const int n = blockIdx.x;
     const double a_n = d.A[n];
     const double Esum = d.Esum[n];
-    for (int k = tid; k < K; k += DW) {
+    for (int k = tid; k < K; k += BW) {
       const int e = k + K * n;
       double x;
       if (a_n == 0.0) x = prior_draw<0>(d, e, t);
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, Side
     side_done(pd, tid);
     return;
   }
-  const long e = (long)((int)blockIdx.x - N) * DW + tid;
+  const long e = (long)((int)blockIdx.x - N) * BW + tid;
   const bool live = e < (long)d.lenE;
   double x = 0.0, a_n = 0.0;
   bool scaled = false;                                   // x is Gamma(shape, 1) and still has to be divided by the rate

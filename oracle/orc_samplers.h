@@ -236,14 +236,16 @@ static inline double orc_ralpha(orc_stream* s, double c, double tau, double xpre
  * c <= 1, r <= 0 or 64 rejections in a row fall back to the general 3-tangent sampler orc_ralpha (same stream). */
 #define ORC_ALUT_I0 (1013 << 6)        /* 2^-10 <= 1e-3 */
 #define ORC_ALUT_N (24 * 64)           /* up to 2^14 > 1e4 */
-static double orc_alut[2 * ORC_ALUT_N];
+static double orc_alut[3 * ORC_ALUT_N];   /* lgamma, digamma at the grid point; slope of the chord of lgamma to the next one */
 static inline double orc_alut_x(int i) { return orc_u2d((uint64_t)((uint32_t)(i + ORC_ALUT_I0) << 14) << 32); }
 static inline int orc_alut_idx(double x) {
   int i = (int)((uint32_t)(orc_d2u(x) >> 32) >> 14) - ORC_ALUT_I0;
   return i < 0 ? 0 : (i > ORC_ALUT_N - 1 ? ORC_ALUT_N - 1 : i);
 }
 __attribute__((constructor)) static void orc_alut_init(void) {
-  for (int i = 0; i < ORC_ALUT_N; ++i) orc_lgamma_digamma(orc_alut_x(i), &orc_alut[2 * i], &orc_alut[2 * i + 1]);
+  for (int i = 0; i < ORC_ALUT_N; ++i) orc_lgamma_digamma(orc_alut_x(i), &orc_alut[3 * i], &orc_alut[3 * i + 1]);
+  for (int i = 0; i < ORC_ALUT_N; ++i)
+    orc_alut[3 * i + 2] = i + 1 < ORC_ALUT_N ? (orc_alut[3 * (i + 1)] - orc_alut[3 * i]) / (orc_alut_x(i + 1) - orc_alut_x(i)) : orc_alut[3 * i + 1];
 }
 #define ORC_FAST_ATTEMPTS 64
 static inline double orc_ralpha_fast(orc_stream* s, double c, double tau, double xprev, int* n_attempts) {
@@ -255,7 +257,7 @@ static inline double orc_ralpha_fast(orc_stream* s, double c, double tau, double
   const double cm1 = c - 1.0;
   for (int it = 0; it < 12; ++it) {    /* H(x) = (c-1)/x - tau - psi(x), psi from the table, psi'(x) ~ 1/x + 1/x^2 */
     const int i = orc_alut_idx(x);
-    const double xg = orc_alut_x(i), psi = orc_alut[2 * i + 1];
+    const double xg = orc_alut_x(i), psi = orc_alut[3 * i + 1];
     const double inv = 1.0 / xg;
     const double H = (cm1 * inv - tau) - psi;
     const double dH = -cm1 * (inv * inv) - (inv + inv * inv);
@@ -269,7 +271,7 @@ static inline double orc_ralpha_fast(orc_stream* s, double c, double tau, double
     if (dx <= 0.03 * xg) break;
   }
   const int i0 = orc_alut_idx(x);
-  const double x0 = orc_alut_x(i0), lg0 = orc_alut[2 * i0], psi0 = orc_alut[2 * i0 + 1];
+  const double x0 = orc_alut_x(i0), lg0 = orc_alut[3 * i0], psi0 = orc_alut[3 * i0 + 1];
   const double r = tau + psi0;
   /* expected acceptance ~ 1 / sqrt(1 + rho), rho = psi'(x0) var(x): a broad or skewed target (small c) goes to the general sampler */
   const double i0v = 1.0 / x0, tri = i0v + i0v * i0v;
@@ -287,8 +289,17 @@ static inline double orc_ralpha_fast(orc_stream* s, double c, double tau, double
     v = v * v * v;
     const double xs = (d * v) / r;
     if (!(xs >= L && xs <= U)) continue;
-    const double rhs = (0.5 * (z * z) + d * ((1.0 - v) + orc_log(v))) + ((b0 + psi0 * xs) - orc_lgamma(xs));
-    if (orc_log(u) < rhs) { if (n_attempts) *n_attempts = it + 1; return xs; }
+    /* lgamma(xs) between its tangent at the grid point below xs and its chord to the next one (lgamma is convex): most
+     * attempts are decided without evaluating it */
+    const double a = (0.5 * (z * z) + d * ((1.0 - v) + orc_log(v))) + (b0 + psi0 * xs);
+    const double lu = orc_log(u);
+    const int ix = orc_alut_idx(xs);
+    const double dx = xs - orc_alut_x(ix);
+    int accept;
+    if (dx >= 0.0 && ix + 1 < ORC_ALUT_N && lu < a - (orc_alut[3 * ix] + orc_alut[3 * ix + 2] * dx)) accept = 1;        /* below a - chord */
+    else if (dx >= 0.0 && ix + 1 < ORC_ALUT_N && lu >= a - (orc_alut[3 * ix] + orc_alut[3 * ix + 1] * dx)) accept = 0;  /* at / above a - tangent */
+    else accept = lu < a - orc_lgamma(xs);
+    if (accept) { if (n_attempts) *n_attempts = it + 1; return xs; }
   }
   int na = 0;
   const double xs = orc_ralpha(s, c, tau, xprev, &na);
