@@ -60,6 +60,8 @@ struct bnmf_handle {
   int32_t *dM = nullptr, *dZsumK = nullptr, *dZsumG = nullptr, *dZ = nullptr;
   int* dR = nullptr; int* dRedraw = nullptr;
   double *dEsum = nullptr, *dPsum = nullptr, *dlpPn = nullptr, *dlpE = nullptr, *dcol = nullptr;
+  double* hMetrics = nullptr;          // the metric rows live in mapped host memory (dMetrics is its device address): k_compose writes them
+                                       // where the host reads them, no device-to-host copy at the end of a call
   double *dLut = nullptr, *dTemp = nullptr, *dMetrics = nullptr, *dRaw = nullptr, *dRankCol = nullptr, *dRankMhat = nullptr;
   uint32_t* dRankSync = nullptr; int rank_grid = 0; bool rank_reg = false; void* dRankDbg = nullptr;
   int32_t* dMt = nullptr; double* dEt = nullptr;
@@ -434,7 +436,8 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   } else h->cfg.n_temperature = 0;
   h->cfg.temperature = nullptr;
   h->metrics_rows = 1024;
-  HIPCHK(hipMalloc(&h->dMetrics, h->metrics_rows * BNMF_NMETRIC * sizeof(double)));
+  HIPCHK(hipHostMalloc((void**)&h->hMetrics, h->metrics_rows * BNMF_NMETRIC * sizeof(double), hipHostMallocMapped));
+  HIPCHK(hipHostGetDevicePointer((void**)&h->dMetrics, h->hMetrics, 0));
   HIPCHK(hipMalloc(&h->dRaw, h->metrics_rows * 8 * sizeof(double)));
   hipLaunchKernelGGL(k_luts, dim3((mx + 256) / 256), dim3(256), 0, h->stream, h->dLut, h->dLut + (mx + 1), mx);
   HIPCHK(hipGetLastError());
@@ -566,7 +569,7 @@ int bnmf_destroy(bnmf_handle* h) {
   for (auto& a : h->arr) { if (a.d) hipFree(a.d); if (a.ring) hipFree(a.ring); }
   hipFree(h->dM); hipFree(h->dZsumK); hipFree(h->dZsumG); if (h->dZ) hipFree(h->dZ);
   hipFree(h->dR); hipFree(h->dRedraw); hipFree(h->dEsum); hipFree(h->dPsum); hipFree(h->dlpPn);
-  hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); hipFree(h->dMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol); if (h->dRankMhat) hipFree(h->dRankMhat); if (h->dRankSync) hipFree(h->dRankSync);
+  hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); if (h->hMetrics) hipHostFree(h->hMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol); if (h->dRankMhat) hipFree(h->dRankMhat); if (h->dRankSync) hipFree(h->dRankSync);
   if (h->E_alt) hipFree(h->E_alt);
   if (h->dMhatZ) hipFree(h->dMhatZ);
   if (h->dZsItems) hipFree(h->dZsItems); if (h->dZsBlocks) hipFree(h->dZsBlocks); if (h->dZsCols) hipFree(h->dZsCols); if (h->dZsProf) hipFree(h->dZsProf); if (h->dZsM) hipFree(h->dZsM);
@@ -694,9 +697,11 @@ static int need_hyper(bnmf_handle* h, std::initializer_list<int> ids) {
 static int ensure_metrics(bnmf_handle* h, size_t rows) {
   if (rows <= h->metrics_rows) return 0;
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipFree(h->dMetrics));
+  HIPCHK(hipHostFree(h->hMetrics));
+  h->hMetrics = nullptr; h->dMetrics = nullptr;
   h->metrics_rows = rows;
-  HIPCHK(hipMalloc(&h->dMetrics, rows * BNMF_NMETRIC * sizeof(double)));
+  HIPCHK(hipHostMalloc((void**)&h->hMetrics, rows * BNMF_NMETRIC * sizeof(double), hipHostMallocMapped));
+  HIPCHK(hipHostGetDevicePointer((void**)&h->dMetrics, h->hMetrics, 0));
   HIPCHK(hipFree(h->dRaw));
   HIPCHK(hipMalloc(&h->dRaw, rows * 8 * sizeof(double)));
   refresh_dev(h);
@@ -1326,8 +1331,8 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
   hipLaunchKernelGGL(k_compose, dim3(1), dim3(64), 0, h->stream, h->dev, 1, 1u);
   HIPCHK(hipGetLastError());
   double row1[BNMF_NMETRIC];
-  HIPCHK(hipMemcpyAsync(row1, h->dMetrics, BNMF_NMETRIC * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  memcpy(row1, h->hMetrics, BNMF_NMETRIC * sizeof(double));
   HIPCHK(hipStreamSynchronize(h->side));
   HIPCHK(hipStreamSynchronize(h->side2));
   if (metrics_row1) memcpy(metrics_row1, row1, sizeof row1);
@@ -1359,14 +1364,15 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
     // hand-off costs one spin bound and not one per remaining launch
     if (((volatile int*)h->hErr)[0] | ((volatile int*)h->hErr)[1]) break;
   }
+  const bool reduces_on_side2 = h->red_on_side2;          // fixed-rank sweep: every earlier k_reduce sits on side2, which flush_reduce's wait covers
   flush_reduce(h, tm);
-  hipEventRecord(h->ev_z, h->side); hipStreamWaitEvent(h->stream, h->ev_z, 0);   // last k_reduce done
+  if (!reduces_on_side2) { hipEventRecord(h->ev_z, h->side); hipStreamWaitEvent(h->stream, h->ev_z, 0); }   // the k_reduce launches on `side` are done
   hipLaunchKernelGGL(k_compose, dim3((n_iter + 63) / 64), dim3(64), 0, h->stream, h->dev, n_iter, t0);
   HIPCHK(hipGetLastError());
   std::vector<double> own;
   if (!metrics && h->wcap > 0) { own.resize((size_t)n_iter * BNMF_NMETRIC); metrics = own.data(); }
-  if (metrics) HIPCHK(hipMemcpyAsync(metrics, h->dMetrics, (size_t)n_iter * BNMF_NMETRIC * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (metrics) memcpy(metrics, h->hMetrics, (size_t)n_iter * BNMF_NMETRIC * sizeof(double));
   HIPCHK(hipStreamSynchronize(h->side));
   HIPCHK(hipStreamSynchronize(h->side2));
   if (h->wcap > 0 && metrics) {                             // loglik / logpost of the recorded iterations (MAP metrics are window means)
