@@ -267,6 +267,9 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
   }
   ZSTIC(5);
   __syncthreads();
+  ZSTOC(5);
+  {
+  ZSTIC(0);                                               // (profile builds: the epilogue is charged to the set-up slot)
   // ---------------- block epilogue: ZsumK of the block's columns (plain stores), ZsumG (global integer atomics)
   for (int i = tid; i < N * bk.ncols; i += ZT) {
     const int gl = i / N, n = i - gl * N;
@@ -278,7 +281,8 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
     const uint32_t v = PK ? (zG[(size_t)(n >> 1) * KP + kk] >> ((n & 1) << 4)) & 0xFFFFu : zG[(size_t)n * KP + kk];
     if (v) atomicAdd(&d.ZsumG[kk + (size_t)K * n], (int32_t)v);
   }
-  ZSTOC(5);
+  ZSTOC(0);
+  }
   ZSTOC(6);
 #ifdef ZSPROF
   if (s.prof && lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&s.prof[i], (unsigned long long)zsprof[i]);

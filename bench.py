@@ -295,7 +295,7 @@ def main():
     # roofline of the dominant kernel (k_zalloc): HIP events on the chain's own stream, one kernel at a time.
     # Done before the timed region (it advances the chain like any other iterations and keeps the clocks up).
     prof, roof = roofline_of(chain, K_, args.G, N_, args.save_z, total_counts, min(200, max(20, args.steps // 10)), device=local_rank)
-    chain.run(max(args.warmup, 20), metrics=False)   # refill the two-stream pipeline after the serialised profile pass
+    chain.run(max(args.warmup, 200), metrics=False)  # refill the stream pipeline after the serialised profile pass; keeps the clocks up
 
     rep_dt = []
     met = None

@@ -28,6 +28,19 @@ for p in sorted(glob.glob("$OUT/*/")):
             v2 = v[len(v) // 4:]                      # steady state: drop the first quarter of the launches
             res.setdefault(tag, {})[k + ":" + c] = {"launches": len(v), "mean": sum(v2) / len(v2), "min": min(v2), "max": max(v2)}
 json.dump(res, open("$OUT/pmc_counters.json", "w"), indent=1)
+# HBM traffic per launch in the form bench.py reads (gfx950: FETCH_SIZE reports half of a coalesced read stream, MI355X_MICROARCH.md)
+def kib(tag, kern, ctr):
+    for k, v in res.get(tag, {}).items():
+        if k.startswith(kern) and k.endswith(":" + ctr): return v["mean"]
+    return None
+tr = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tools/pmc_r3.sh -> tools/prof.py, record window 1000), K=96 G=10000 N=20, "
+              "per launch, steady state (first quarter of the launches dropped), KiB; hbm_bytes_per_launch = (2 * FETCH + WRITE) * 1024.  The "
+              "library ran in its serial-safe mode (counter collection serialises dispatches): same kernels, stream waits instead of polling."}
+for name, kern, ft, wt in (("k_zalloc_stats", "k_zalloc_sort", "p1", "p2"), ("k_zalloc_full", "k_zalloc_reg<true", "fz", "wz"), ("k_draw", "k_draw", "p1", "p2"),
+                           ("k_side", "k_side:", "p1", "p2"), ("k_side_lp", "k_side_lp", "p1", "p2")):
+    f, w = kib(ft, kern.rstrip(":") if kern != "k_side:" else "k_side", "FETCH_SIZE"), kib(wt, kern.rstrip(":") if kern != "k_side:" else "k_side", "WRITE_SIZE")
+    if f is not None and w is not None: tr[name] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2 * f + w) * 1024}
+json.dump(tr, open("$OUT/pmc_traffic.json", "w"), indent=1)
 for tag, d in res.items():
     for k, v in d.items():
         if any(x in k for x in ("zalloc", "k_draw", "k_side")): print(tag, k, "mean %.5g  min %.5g  max %.5g  n %d" % (v["mean"], v["min"], v["max"], v["launches"]))
