@@ -680,6 +680,18 @@ int bnmf_debug_zsort(bnmf_handle* h, unsigned long long* out) {   // diagnostics
   HIPCHK(hipMemset(h->dZsProf, 0, 8 * sizeof(unsigned long long)));
   return 0;
 }
+#ifdef ZSPROF
+int bnmf_debug_draw(bnmf_handle* h, unsigned long long* out, int reset) {   // diagnostics (-DZSPROF builds): [wave][8] section ticks of k_draw's E waves
+  if (!h) return fail(BNMF_EINVAL, "null");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_drprof), 8 * DRPROF_W * sizeof(unsigned long long)));
+  if (reset) {
+    std::vector<unsigned long long> z(8 * DRPROF_W, 0ull);
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_drprof), z.data(), z.size() * sizeof(unsigned long long)));
+  }
+  return DRPROF_W;
+}
+#endif
 int bnmf_debug_set_timeout(bnmf_handle* h, int word) {   // tests: what a bounded in-kernel wait does when it gives up
   if (!h || word < 0 || word > 1) return fail(BNMF_EINVAL, "bnmf_debug_set_timeout: bad argument");
   ((volatile int*)h->hErr)[word] = 2;

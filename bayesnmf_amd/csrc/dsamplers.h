@@ -18,6 +18,18 @@ BNMF_DEV double rnorm_std(Stream& s) { const u32x4 w = s.next(); return dqnorm(u
 BNMF_DEV double runif(Stream& s) { const u32x4 w = s.next(); return u52(w.x, w.y); }
 BNMF_DEV double rexp(Stream& s, double rate) { const u32x4 w = s.next(); return -dlog(u52(w.x, w.y)) / rate; }
 
+#ifdef ZSPROF
+constexpr int DRPROF_W = 4096;
+__device__ unsigned long long g_drprof[8 * DRPROF_W];   // diagnostics: section ticks of k_draw's E waves, [wave][8]; the last row's [4]: lanes that left ralpha_fast for the general sampler
+#define FB_COUNT atomicAdd(&g_drprof[8 * (DRPROF_W - 1) + 4], 1ull)
+// wave-level pass counters (first active lane counts) and lane-level attempt counters, last row: [0] Newton wave-iterations,
+// [1] Alpha wave-passes, [2] Alpha lane-attempts, [3] Newton lane-iterations, [5] rgamma wave-passes, [6] rgamma lane-attempts
+#define PCOUNT(w, l) do { if ((int)(threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_drprof[8 * (DRPROF_W - 1) + (w)], 1ull); \
+                          atomicAdd(&g_drprof[8 * (DRPROF_W - 1) + (l)], 1ull); } while (0)
+#else
+#define FB_COUNT
+#define PCOUNT(w, l)
+#endif
 BNMF_DEV double rgamma(Stream& s, double a, double rate) {
   if (!(a > 0.0)) return (a == 0.0) ? 0.0 : BNMF_NAN;
   const bool boost = a < 1.0;
@@ -26,6 +38,7 @@ BNMF_DEV double rgamma(Stream& s, double a, double rate) {
   const double c = 1.0 / dsqrt(9.0 * d);
   double v = 1.0;
   for (int it = 0; it < MAX_ATTEMPTS; ++it) {
+    PCOUNT(5, 6);
     const u32x4 w = s.next();
     const double z = dqnorm(u52(w.x, w.y));
     const double ua = u52(w.z, w.w);
@@ -34,7 +47,13 @@ BNMF_DEV double rgamma(Stream& s, double a, double rate) {
     v = v * v * v;
     const double z2 = z * z;
     if (ua < 1.0 - 0.0331 * (z2 * z2)) break;
-    if (dlog(ua) < 0.5 * z2 + d * ((1.0 - v) + dlog(v))) break;
+    // accept iff log(ua) < R.  (ua - 1) / ua <= log(ua) <= ua - 1 decides all but a sliver of width ~ (1 - ua)^2 without the
+    // logarithm (a wavefront pays for it whenever one lane needs it)
+    const double R = 0.5 * z2 + d * ((1.0 - v) + dlog(v));
+    const double um1 = ua - 1.0;
+    if (um1 < R) break;
+    if (um1 / ua >= R) continue;
+    if (dlog(ua) < R) break;
   }
   double g = d * v;
   if (boost) {
@@ -218,16 +237,18 @@ __global__ void k_alut_fill(int pass) {
   else g_alut[3 * i + 2] = i + 1 < ALUT_N ? (g_alut[3 * (i + 1)] - g_alut[3 * i]) / (alut_x(i + 1) - alut_x(i)) : g_alut[3 * i + 1];
 }
 constexpr int FAST_ATTEMPTS = 64;
-BNMF_DEV double ralpha_fast(Stream& s, double c, double tau, double xprev, int* n_attempts = nullptr) {
+// lut: the table (g_alut, or a workgroup's copy of it in LDS: k_draw)
+BNMF_DEV double ralpha_fast(Stream& s, double c, double tau, double xprev, int* n_attempts = nullptr, const double* lut = g_alut) {
   const double L = 1e-3, U = 1e4;
-  if (!(c > 1.0)) return ralpha(s, c, tau, xprev, n_attempts);
+  if (!(c > 1.0)) { FB_COUNT; return ralpha(s, c, tau, xprev, n_attempts); }
   double x = xprev;
   if (!(x >= L)) x = L;
   if (x > U) x = U;
   const double cm1 = c - 1.0;
   for (int it = 0; it < 12; ++it) {    // H(x) = (c-1)/x - tau - psi(x), psi from the table, psi'(x) ~ 1/x + 1/x^2
+    PCOUNT(0, 3);
     const int i = alut_idx(x);
-    const double xg = alut_x(i), psi = g_alut[3 * i + 1];
+    const double xg = alut_x(i), psi = lut[3 * i + 1];
     const double inv = 1.0 / xg;
     const double H = (cm1 * inv - tau) - psi;
     const double dH = -cm1 * (inv * inv) - (inv + inv * inv);
@@ -241,16 +262,17 @@ BNMF_DEV double ralpha_fast(Stream& s, double c, double tau, double xprev, int* 
     if (dx <= 0.03 * xg) break;
   }
   const int i0 = alut_idx(x);
-  const double x0 = alut_x(i0), lg0 = g_alut[3 * i0], psi0 = g_alut[3 * i0 + 1];
+  const double x0 = alut_x(i0), lg0 = lut[3 * i0], psi0 = lut[3 * i0 + 1];
   const double r = tau + psi0;
   // expected acceptance ~ 1 / sqrt(1 + rho), rho = psi'(x0) var(x): a broad or skewed target (small c) goes to the general sampler
   const double i0v = 1.0 / x0, tri = i0v + i0v * i0v;
   const double rho = tri / (cm1 * (i0v * i0v) + tri);
-  if (!(r > 0.0) || !(rho < 0.35)) return ralpha(s, c, tau, xprev, n_attempts);
+  if (!(r > 0.0) || !(rho < 0.35)) { FB_COUNT; return ralpha(s, c, tau, xprev, n_attempts); }
   const double d = c - 0.333333333333333333333;
   const double cc = 1.0 / dsqrt(9.0 * d);
   const double b0 = lg0 - psi0 * x0;
   for (int it = 0; it < FAST_ATTEMPTS; ++it) {
+    PCOUNT(1, 2);
     const u32x4 w = s.next();
     const double z = dqnorm(u52(w.x, w.y));
     const double u = u52(w.z, w.w);
@@ -262,15 +284,25 @@ BNMF_DEV double ralpha_fast(Stream& s, double c, double tau, double xprev, int* 
     // lgamma(xs) between its tangent at the grid point below xs and its chord to the next one (lgamma is convex): most
     // attempts are decided without evaluating it
     const double a = (0.5 * (z * z) + d * ((1.0 - v) + dlog(v))) + (b0 + psi0 * xs);
-    const double lu = dlog(u);
     const int ix = alut_idx(xs);
     const double dx = xs - alut_x(ix);
+    const bool grid = dx >= 0.0 && ix + 1 < ALUT_N;
+    const double tc = a - (lut[3 * ix] + lut[3 * ix + 2] * dx);   // a - chord   <= a - lgamma(xs)
+    const double tt = a - (lut[3 * ix] + lut[3 * ix + 1] * dx);   // a - tangent >= a - lgamma(xs)
+    // (u - 1) / u <= log(u) <= u - 1: the two grid tests without the logarithm when the bounds already decide them
+    const double um1 = u - 1.0;
     bool accept;
-    if (dx >= 0.0 && ix + 1 < ALUT_N && lu < a - (g_alut[3 * ix] + g_alut[3 * ix + 2] * dx)) accept = true;           // below a - chord
-    else if (dx >= 0.0 && ix + 1 < ALUT_N && lu >= a - (g_alut[3 * ix] + g_alut[3 * ix + 1] * dx)) accept = false;    // at / above a - tangent
-    else accept = lu < a - dlgamma(xs);
+    if (grid && um1 < tc) accept = true;
+    else if (grid && um1 / u >= tt) accept = false;
+    else {
+      const double lu = dlog(u);
+      if (grid && lu < tc) accept = true;                  // below a - chord
+      else if (grid && lu >= tt) accept = false;           // at / above a - tangent
+      else accept = lu < a - dlgamma(xs);
+    }
     if (accept) { if (n_attempts) *n_attempts = it + 1; return xs; }
   }
+  FB_COUNT;
   int na = 0;
   const double xs = ralpha(s, c, tau, xprev, &na);
   if (n_attempts) *n_attempts = FAST_ATTEMPTS + na;

@@ -90,9 +90,27 @@ BNMF_DEV void side_wait(const SideWait& sw, int tid) {
 }
 BNMF_DEV double ld_ag(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+#ifdef ZSPROF
+#define DRSTAMP(i) const unsigned long long st##i = __builtin_amdgcn_s_memtime()
+#else
+#define DRSTAMP(i)
+#endif
 // ---- hyper sweep of one element: R/sample_priors.R:150-200 (element-wise conditionals) ----
+// PRE: `pre` is the Gamma(shape, 1) part of the element's first draw, made by hyper_pre before v was known (k_draw: before the
+// wait for P); rgamma(s, shape, rate) is that value divided by the rate, so the result is the same bits.  lut: ralpha_fast's table.
 template <int SIDE>
-BNMF_DEV void hyper_elem(const Dev& d, int e, uint32_t t, double v, double* rec0 = nullptr, double* rec1 = nullptr) {
+BNMF_DEV double hyper_pre(const Dev& d, int e, uint32_t t) {
+  const HRef& hA = SIDE ? d.hA_e : d.hA_p;
+  if (d.prior == BNMF_GAMMA) {
+    Stream s(d.k0, d.k1, SIDE ? BNMF_V_BETA_E : BNMF_V_BETA_P, (uint32_t)e, t);
+    return rgamma(s, hy(hA, e) + slot<SIDE>(d, SIDE ? d.Alpha_e : d.Alpha_p, t - 1)[e], 1.0);
+  }
+  Stream s(d.k0, d.k1, SIDE ? BNMF_V_LAMBDA_E : BNMF_V_LAMBDA_P, (uint32_t)e, t);
+  return rgamma(s, hy(hA, e) + 1.0, 1.0);
+}
+template <int SIDE, bool PRE = false>
+BNMF_DEV void hyper_elem(const Dev& d, int e, uint32_t t, double v, double* rec0 = nullptr, double* rec1 = nullptr, double pre = 0.0,
+                         const double* lut = g_alut) {
   if (d.prior == BNMF_GAMMA) {
     const HRef &hA = SIDE ? d.hA_e : d.hA_p, &hB = SIDE ? d.hB_e : d.hB_p;
     const HRef &hC = SIDE ? d.hC_e : d.hC_p, &hD = SIDE ? d.hD_e : d.hD_p;
@@ -100,19 +118,19 @@ BNMF_DEV void hyper_elem(const Dev& d, int e, uint32_t t, double v, double* rec0
     double* Be = SIDE ? d.Beta_e : d.Beta_p;
     Stream s(d.k0, d.k1, SIDE ? BNMF_V_BETA_E : BNMF_V_BETA_P, (uint32_t)e, t);
     const double al_old = slot<SIDE>(d, Al, t - 1)[e];
-    const double b = rgamma(s, hy(hA, e) + al_old, hy(hB, e) + v);        // sample_Beta_*  :323-345
+    const double b = PRE ? pre / (hy(hB, e) + v) : rgamma(s, hy(hA, e) + al_old, hy(hB, e) + v);        // sample_Beta_*  :323-345
     st_wt(&slot<SIDE>(d, Be, t)[e], b);
     if (rec1) rec1[e] = b;
     const double tau = (hy(hD, e) - dlog(clamp_tiny(b))) - dlog(clamp_tiny(v));
     Stream s2(d.k0, d.k1, SIDE ? BNMF_V_ALPHA_E : BNMF_V_ALPHA_P, (uint32_t)e, t);
-    const double al = ralpha_fast(s2, hy(hC, e), tau, al_old);              // sample_Alpha_* :356-397
+    const double al = ralpha_fast(s2, hy(hC, e), tau, al_old, nullptr, lut);   // sample_Alpha_* :356-397
     st_wt(&slot<SIDE>(d, Al, t)[e], al);
     if (rec0) rec0[e] = al;
   } else if (d.prior == BNMF_EXPONENTIAL) {
     const HRef &hA = SIDE ? d.hA_e : d.hA_p, &hB = SIDE ? d.hB_e : d.hB_p;
     double* La = SIDE ? d.Lam_e : d.Lam_p;
     Stream s(d.k0, d.k1, SIDE ? BNMF_V_LAMBDA_E : BNMF_V_LAMBDA_P, (uint32_t)e, t);
-    const double la = rgamma(s, hy(hA, e) + 1.0, hy(hB, e) + v);            // sample_Lambda_* :284-308
+    const double la = PRE ? pre / (hy(hB, e) + v) : rgamma(s, hy(hA, e) + 1.0, hy(hB, e) + v);            // sample_Lambda_* :284-308
     st_wt(&slot<SIDE>(d, La, t)[e], la);
     if (rec0) rec0[e] = la;
   } else {
@@ -290,6 +308,7 @@ constexpr int DW = 1024;
 // t + 1 for the prior parameters; ed: the E-side flag of the hand-off protocol (k_side raises it when it does this work).
 __global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, SideDone pd, SideWait pw, RecDst rec_next, SideDone ed) {
   __shared__ double Pn[DW];
+  __shared__ double lutS[3 * ALUT_N];                     // E workgroups: ralpha_fast's table (its look-ups are dependent loads inside the Newton and attempt loops)
   const int tid = threadIdx.x, N = d.N, K = d.K;
   const int BW = blockDim.x;                              // <= DW: chosen by the host so that the E workgroups fill the CUs once
   if ((int)blockIdx.x < N) {
@@ -326,9 +345,12 @@ __global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, Side
   }
   const long e = (long)((int)blockIdx.x - N) * BW + tid;
   const bool live = e < (long)d.lenE;
+  DRSTAMP(0);
+  if (d.prior == BNMF_GAMMA) for (int i = tid; i < 3 * ALUT_N; i += BW) lutS[i] = g_alut[i];   // visible after side_wait's barrier
   double x = 0.0, a_n = 0.0;
   bool scaled = false;                                   // x is Gamma(shape, 1) and still has to be divided by the rate
   double base = 0.0;                                     // the rate without its Psum term
+  double hpre = 0.0;                                     // Gamma(shape, 1) part of the hyper sweep's first draw (needs nothing from this iteration)
   int n = 0;
   if (live) {
     n = (int)(e % N);
@@ -342,8 +364,11 @@ __global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, Side
       x = rgamma(s, shape, 1.0);
       scaled = true;
     }
+    hpre = hyper_pre<1>(d, (int)e, t + 1);
   }
+  DRSTAMP(1);
   side_wait<false>(pw, tid);
+  DRSTAMP(2);
   if (live) {
     if (scaled) {
       const double rate = base + a_n * ld_ag(&d.Psum[n]);
@@ -353,7 +378,17 @@ __global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, Side
     d.E[e] = x;
     if (rec.E) rec.E[e] = x;
     if (d.zsumk_accum) d.ZsumK[e] = 0;
-    hyper_elem<1>(d, (int)e, t + 1, x, rec_next.pp[2], rec_next.pp[3]);
+#ifdef ZSPROF
+    DRSTAMP(3);
+    hyper_elem<1, true>(d, (int)e, t + 1, x, rec_next.pp[2], rec_next.pp[3], hpre, lutS);
+    DRSTAMP(4);
+    if ((tid & 63) == 0 && (e >> 6) < DRPROF_W - 1) {
+      unsigned long long* o = &g_drprof[8 * (e >> 6)];
+      o[0] += st1 - st0; o[1] += st2 - st1; o[2] += st3 - st2; o[3] += st4 - st3; o[5] += st4 - st0; o[6] = st0; o[7] += 1ull;
+    }
+#else
+    hyper_elem<1, true>(d, (int)e, t + 1, x, rec_next.pp[2], rec_next.pp[3], hpre, lutS);
+#endif
   }
   side_done(ed, tid);
 }

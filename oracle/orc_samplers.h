@@ -49,7 +49,12 @@ static inline double orc_rgamma(orc_stream* s, double a, double rate) {
     v = v * v * v;
     double z2 = z * z;
     if (ua < 1.0 - 0.0331 * (z2 * z2)) break;
-    if (orc_log(ua) < 0.5 * z2 + d * ((1.0 - v) + orc_log(v))) break;
+    /* accept iff log(ua) < R; (ua - 1) / ua <= log(ua) <= ua - 1 decides all but a sliver without the logarithm */
+    double R = 0.5 * z2 + d * ((1.0 - v) + orc_log(v));
+    double um1 = ua - 1.0;
+    if (um1 < R) break;
+    if (um1 / ua >= R) continue;
+    if (orc_log(ua) < R) break;
   }
   double g = d * v;
   if (boost) {
@@ -292,13 +297,22 @@ static inline double orc_ralpha_fast(orc_stream* s, double c, double tau, double
     /* lgamma(xs) between its tangent at the grid point below xs and its chord to the next one (lgamma is convex): most
      * attempts are decided without evaluating it */
     const double a = (0.5 * (z * z) + d * ((1.0 - v) + orc_log(v))) + (b0 + psi0 * xs);
-    const double lu = orc_log(u);
     const int ix = orc_alut_idx(xs);
     const double dx = xs - orc_alut_x(ix);
+    const int grid = dx >= 0.0 && ix + 1 < ORC_ALUT_N;
+    const double tc = a - (orc_alut[3 * ix] + orc_alut[3 * ix + 2] * dx);   /* a - chord   <= a - lgamma(xs) */
+    const double tt = a - (orc_alut[3 * ix] + orc_alut[3 * ix + 1] * dx);   /* a - tangent >= a - lgamma(xs) */
+    /* (u - 1) / u <= log(u) <= u - 1: the two grid tests without the logarithm when the bounds already decide them */
+    const double um1 = u - 1.0;
     int accept;
-    if (dx >= 0.0 && ix + 1 < ORC_ALUT_N && lu < a - (orc_alut[3 * ix] + orc_alut[3 * ix + 2] * dx)) accept = 1;        /* below a - chord */
-    else if (dx >= 0.0 && ix + 1 < ORC_ALUT_N && lu >= a - (orc_alut[3 * ix] + orc_alut[3 * ix + 1] * dx)) accept = 0;  /* at / above a - tangent */
-    else accept = lu < a - orc_lgamma(xs);
+    if (grid && um1 < tc) accept = 1;
+    else if (grid && um1 / u >= tt) accept = 0;
+    else {
+      const double lu = orc_log(u);
+      if (grid && lu < tc) accept = 1;                     /* below a - chord */
+      else if (grid && lu >= tt) accept = 0;               /* at / above a - tangent */
+      else accept = lu < a - orc_lgamma(xs);
+    }
     if (accept) { if (n_attempts) *n_attempts = it + 1; return xs; }
   }
   int na = 0;
