@@ -1855,15 +1855,17 @@ int bnmf_test_sampler(int device, int which, uint64_t seed, uint32_t chain, uint
   hipFree(da); hipFree(db); hipFree(dc); hipFree(dou);
   return 0;
 }
-int bnmf_test_philox(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+static int test_philox_r(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4], int rounds) {
   HIPCHK(hipSetDevice(device));
   uint32_t* d;
   HIPCHK(hipMalloc(&d, 16));
-  hipLaunchKernelGGL(k_test_philox, dim3(1), dim3(1), 0, 0, ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], d);
+  hipLaunchKernelGGL(k_test_philox, dim3(1), dim3(1), 0, 0, ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], d, rounds);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(out, d, 16, hipMemcpyDeviceToHost));
   hipFree(d);
   return 0;
 }
+int bnmf_test_philox(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { return test_philox_r(device, ctr, key, out, 10); }
+int bnmf_test_philox7(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { return test_philox_r(device, ctr, key, out, 7); }
 
 }  // extern "C"

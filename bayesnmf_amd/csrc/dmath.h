@@ -12,12 +12,15 @@ namespace bnmf {
 
 #define BNMF_DEV __device__ __forceinline__
 
-// ---------------------------------------------------------------- Philox4x32-10
+// ---------------------------------------------------------------- Philox4x32 (Salmon et al., SC'11), R rounds
+// Ten rounds (the authors' default) for every stream but the count-allocation words, which take seven: the smallest round
+// count the authors report as Crush-resistant (it passes BigCrush), and 97 % of all the words an iteration draws.
 struct u32x4 { uint32_t x, y, z, w; };
 
-BNMF_DEV u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+template <int R>
+BNMF_DEV u32x4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < R; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;   // v_mad_u64_u32
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);   // a ^ b ^ c in one v_bitop3_b32 (gfx950)
@@ -27,6 +30,8 @@ BNMF_DEV u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
   }
   return u32x4{c0, c1, c2, c3};
 }
+BNMF_DEV u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) { return philox4x32<10>(c0, c1, c2, c3, k0, k1); }
+BNMF_DEV u32x4 philox4x32_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) { return philox4x32<7>(c0, c1, c2, c3, k0, k1); }
 
 // counter = (block, element, iteration, variable id); key = (seed_lo, seed_hi ^ chain)
 struct Stream {

@@ -590,7 +590,7 @@ __global__ __launch_bounds__(ZT) void k_zalloc(Dev d, uint32_t t, ZGeom zg, int 
             }
             const int j0 = (qi - cstart) << 2;
             const int nd = mc - j0;                        // >= 1; draws of this quad = min(4, nd)
-            const u32x4 w = philox4x32_10((uint32_t)(j0 >> 2), (uint32_t)(kbase + cell + (size_t)K * g), t, BNMF_V_Z, d.k0, d.k1);
+            const u32x4 w = philox4x32_7((uint32_t)(j0 >> 2), (uint32_t)(kbase + cell + (size_t)K * g), t, BNMF_V_Z, d.k0, d.k1);
             const uint32_t* col = thr + cell;
             const uint32_t u0 = min(w.x, 0xFFFFFFFEu), u1 = min(w.y, 0xFFFFFFFEu), u2 = min(w.z, 0xFFFFFFFEu), u3 = min(w.w, 0xFFFFFFFEu);
             int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
@@ -919,8 +919,8 @@ __global__ void k_test_sampler(int which, uint32_t k0, uint32_t k1, uint32_t var
   }
   out[i] = r;
 }
-__global__ void k_test_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
-  const u32x4 w = philox4x32_10(c0, c1, c2, c3, k0, k1);
+__global__ void k_test_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out, int rounds) {
+  const u32x4 w = rounds == 7 ? philox4x32_7(c0, c1, c2, c3, k0, k1) : philox4x32_10(c0, c1, c2, c3, k0, k1);
   out[0] = w.x; out[1] = w.y; out[2] = w.z; out[3] = w.w;
 }
 

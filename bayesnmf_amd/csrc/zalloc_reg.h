@@ -280,7 +280,7 @@ __global__ __launch_bounds__(ZT, 4) void k_zalloc_reg(ZArgs d, uint32_t t, ZGeom
           ND = ((cend - cstart) << 2) - (int)(kkpad >> 30) - (jq_ << 2);       /* counts left in the cell: >= 1 */  \
           u32x4 w_;                                                                                                \
           if (DIAG && (ablate & 16)) w_ = u32x4{(uint32_t)(QI) * 2654435761u, (uint32_t)(QI) * 40503u, (uint32_t)(QI), ~(uint32_t)(QI)}; \
-          else w_ = philox4x32_10((uint32_t)jq_, CELL + gK, t, BNMF_V_Z, d.k0, d.k1);                              \
+          else w_ = philox4x32_7((uint32_t)jq_, CELL + gK, t, BNMF_V_Z, d.k0, d.k1);                              \
           U0 = min(w_.x, 0xFFFFFFFEu); U1 = min(w_.y, 0xFFFFFFFEu); U2 = min(w_.z, 0xFFFFFFFEu); U3 = min(w_.w, 0xFFFFFFFEu); \
           J0 = J1 = J2 = J3 = 0;                                                                                   \
           if (NPV > 0) cmp_acc4(pa.x, U0, U1, U2, U3, J0, J1, J2, J3);                                             \

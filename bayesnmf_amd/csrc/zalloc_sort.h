@@ -219,7 +219,7 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
     const uint32_t celem = (uint32_t)k + (uint32_t)K * (uint32_t)g;
     // one quad: Philox block q of the cell's stream -> 4 words -> 4 buckets -> 4 histogram increments (inc: 1, or 0 for a pad)
     auto quad = [&](int qidx, uint32_t inc0, uint32_t inc1, uint32_t inc2, uint32_t inc3) {
-      const u32x4 w = philox4x32_10((uint32_t)qidx, celem, t, BNMF_V_Z, d.k0, d.k1);
+      const u32x4 w = philox4x32_7((uint32_t)qidx, celem, t, BNMF_V_Z, d.k0, d.k1);
       const uint32_t u0 = min(w.x, 0xFFFFFFFEu), u1 = min(w.y, 0xFFFFFFFEu), u2 = min(w.z, 0xFFFFFFFEu), u3 = min(w.w, 0xFFFFFFFEu);
       uint32_t j0 = 0, j1 = 0, j2 = 0, j3 = 0;
 #pragma unroll

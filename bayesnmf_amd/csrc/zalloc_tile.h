@@ -211,7 +211,7 @@ __global__ __launch_bounds__(ZT, LEAN ? 4 : 2) void k_zalloc_tile(ZArgs d, doubl
           }
           const int j0 = (qi - cstart) << 2;
           const int nd = mc - j0;                          // >= 1; draws of this quad = min(4, nd)
-          const u32x4 w = philox4x32_10((uint32_t)(j0 >> 2), (uint32_t)(k0 + cell) + (uint32_t)K * (uint32_t)gcol, t, BNMF_V_Z, d.k0, d.k1);
+          const u32x4 w = philox4x32_7((uint32_t)(j0 >> 2), (uint32_t)(k0 + cell) + (uint32_t)K * (uint32_t)gcol, t, BNMF_V_Z, d.k0, d.k1);
           const uint32_t* col = thr + cell;
           const uint32_t u0 = min(w.x, 0xFFFFFFFEu), u1 = min(w.y, 0xFFFFFFFEu), u2 = min(w.z, 0xFFFFFFFEu), u3 = min(w.w, 0xFFFFFFFEu);
           int b0 = 0, b1 = 0, b2 = 0, b3 = 0;

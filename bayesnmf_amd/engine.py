@@ -67,7 +67,7 @@ WHY = {0: None, 1: "no change", 2: "no best", 3: "max iters"}
 
 ABI_SYMBOLS = ["bnmf_create", "bnmf_destroy", "bnmf_set_array", "bnmf_get_array", "bnmf_get_array_i32",
                "bnmf_init", "bnmf_run", "bnmf_window", "bnmf_map", "bnmf_run_until", "bnmf_run_post_warmup", "bnmf_assign", "bnmf_get_iter", "bnmf_profile",
-               "bnmf_kernel_name", "bnmf_ubench", "bnmf_test_math", "bnmf_test_sampler", "bnmf_test_philox",
+               "bnmf_kernel_name", "bnmf_ubench", "bnmf_test_math", "bnmf_test_sampler", "bnmf_test_philox", "bnmf_test_philox7",
                "bnmf_device_info", "bnmf_device_count", "bnmf_last_error", "bnmf_version"]
 
 
@@ -102,6 +102,7 @@ def lib():
         L.bnmf_test_sampler.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.c_uint32, dp, dp, dp, dp, C.c_size_t]
         L.bnmf_test_philox.argtypes = [C.c_int, up, up, up]
+        L.bnmf_test_philox7.argtypes = [C.c_int, up, up, up]
         L.bnmf_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         L.bnmf_device_count.restype = C.c_int
         L.bnmf_last_error.restype = C.c_char_p
@@ -159,11 +160,11 @@ def test_sampler(which, a=None, b=None, c=None, n=None, seed=1, chain=0, var=2, 
     return out
 
 
-def test_philox(ctr, key, device=0):
+def test_philox(ctr, key, device=0, rounds=10):
     c = (C.c_uint32 * 4)(*ctr)
     k = (C.c_uint32 * 2)(*key)
     o = (C.c_uint32 * 4)()
-    _chk(lib().bnmf_test_philox(device, c, k, o))
+    _chk((lib().bnmf_test_philox7 if rounds == 7 else lib().bnmf_test_philox)(device, c, k, o))
     return [int(v) for v in o]
 
 

@@ -181,7 +181,8 @@ int bnmf_test_math(int device, int fn, const double* in, double* out, size_t n);
 int bnmf_test_sampler(int device, int which, uint64_t seed, uint32_t chain, uint32_t var,
                       uint32_t elem0, uint32_t iter, const double* a, const double* b,
                       const double* c, double* out, size_t n);
-int bnmf_test_philox(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+int bnmf_test_philox(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);    /* Philox4x32-10 */
+int bnmf_test_philox7(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);   /* Philox4x32-7: the count-allocation words */
 
 int bnmf_device_info(int device, char* buf, size_t buflen);
 int bnmf_device_count(void);

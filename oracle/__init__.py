@@ -69,6 +69,7 @@ def lib():
         L.orc_t_u52.restype = C.c_double
         L.orc_t_u52.argtypes = [C.c_uint32, C.c_uint32]
         L.orc_t_philox.argtypes = [up, up, up]
+        L.orc_t_philox7.argtypes = [up, up, up]
         L.orc_t_canon_sum.restype = C.c_double
         L.orc_t_canon_sum.argtypes = [dp, C.c_long, C.c_long, C.c_int]
         hdr = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
@@ -93,11 +94,11 @@ def vec(fname, x):
     return np.array([fn(float(v)) for v in x.ravel()]).reshape(x.shape)
 
 
-def philox(ctr, key):
+def philox(ctr, key, rounds=10):
     c = (C.c_uint32 * 4)(*ctr)
     k = (C.c_uint32 * 2)(*key)
     o = (C.c_uint32 * 4)()
-    lib().orc_t_philox(c, k, o)
+    (lib().orc_t_philox7 if rounds == 7 else lib().orc_t_philox)(c, k, o)
     return [int(v) for v in o]
 
 

@@ -288,7 +288,7 @@ static void sample_E_poisson(orc_handle* o, uint32_t t, int from_prior) {
  * sample_Zkg R/sample_params.R:253-265: probs[n] = P[k,n]*A[n]*E[n,g]; sum==0 -> zeros;
  * else Multinomial(M[k,g], probs/sum).  Stream spec: the M[k,g] counts of a cell are
  * allocated one by one; count j uses 32-bit word (j&3) of block (j>>2) of stream
- * (V_Z, cell=k+K*g, iter); it lands in the first n whose cumulative threshold
+ * (V_Z, cell=k+K*g, iter) — Philox4x32 with SEVEN rounds for this stream —; it lands in the first n whose cumulative threshold
  * thr[n] = floor(cum[n] * 2^32 / sum) exceeds the word; the word is clamped to 2^32-2 and
  * thresholds at or beyond the last n with a positive probability (or that saturate) are
  * 2^32-1 = "never", so no count can land on a factor of zero probability.  The sum of M independent categorical draws is
@@ -317,7 +317,7 @@ static void z_cell(const orc_handle* o, long k, long g, uint32_t t, int32_t* zro
   orc_stream s = ST(o, V_Z, (uint32_t)(k + K * g), t);
   uint32_t w[4];
   for (int32_t j = 0; j < m; ++j) {
-    if ((j & 3) == 0) orc_stream_next(&s, w);
+    if ((j & 3) == 0) { orc_philox4x32_r(s.blk, s.elem, s.iter, s.var, s.k0, s.k1, w, 7); s.blk++; }
     uint32_t u = w[j & 3];
     if (u > 0xFFFFFFFEu) u = 0xFFFFFFFEu;
     long b = 0;
@@ -921,6 +921,9 @@ int orc_t_step(orc_handle* o, int what, uint32_t t, int converged) {
 }
 
 /* ---- unit-test exports ---- */
+void orc_t_philox7(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  orc_philox4x32_r(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out, 7);
+}
 void orc_t_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   orc_philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
 }

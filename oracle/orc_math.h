@@ -18,10 +18,11 @@
 #include <math.h>   /* sqrt, fabs only */
 
 /* ---------------------------------------------------------------- Philox -- */
-/* Philox4x32-10 (Salmon et al., SC'11).  ctr = (c0,c1,c2,c3), key = (k0,k1). */
-static inline void orc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                     uint32_t k0, uint32_t k1, uint32_t out[4]) {
-  for (int r = 0; r < 10; ++r) {
+/* Philox4x32-R (Salmon et al., SC'11).  ctr = (c0,c1,c2,c3), key = (k0,k1).  Ten rounds for every stream but the
+ * count-allocation words (V_Z), which take seven: the smallest round count the authors report as Crush-resistant. */
+static inline void orc_philox4x32_r(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                    uint32_t k0, uint32_t k1, uint32_t out[4], int rounds) {
+  for (int r = 0; r < rounds; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -32,6 +33,10 @@ static inline void orc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+static inline void orc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                     uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  orc_philox4x32_r(c0, c1, c2, c3, k0, k1, out, 10);
 }
 
 /* One stream per (variable, element, iteration): blocks of 4 words, block index

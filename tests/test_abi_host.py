@@ -208,7 +208,7 @@ def test_r_shim_binds_every_entry_point_of_the_header():
     hdr = open(os.path.join(ROOT, "include", "bnmf.h")).read()
     declared = set(re.findall(r"^(?:int|const char\*)\s+(bnmf_\w+)\(", hdr, re.M))
     # not bound: unit probes of the parity tests, the profiler hook, library-level queries R has no use for
-    not_bound = {"bnmf_ubench", "bnmf_test_math", "bnmf_test_sampler", "bnmf_test_philox", "bnmf_profile", "bnmf_kernel_name", "bnmf_version",
+    not_bound = {"bnmf_ubench", "bnmf_test_math", "bnmf_test_sampler", "bnmf_test_philox", "bnmf_test_philox7", "bnmf_profile", "bnmf_kernel_name", "bnmf_version",
                  "bnmf_device_count", "bnmf_last_error", "bnmf_get_array_i32"}
     src, fns = _shim_functions()
     for name in sorted(declared - not_bound):

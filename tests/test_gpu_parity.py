@@ -31,6 +31,11 @@ def test_philox_kat_on_device():
     assert E.test_philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert E.test_philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    # Random123 kat_vectors, philox4x32-7: the count-allocation words
+    assert E.test_philox([0, 0, 0, 0], [0, 0], rounds=7) == [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]
+    assert E.test_philox([0xffffffff] * 4, [0xffffffff] * 2, rounds=7) == [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]
+    assert E.test_philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0], rounds=7) == \
+        [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]
 
 
 @pytest.mark.parametrize("fn", ["log", "exp", "lgamma", "digamma", "qnorm", "log_pnorm", "sqrt", "recip"])
