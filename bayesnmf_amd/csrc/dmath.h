@@ -84,6 +84,23 @@ BNMF_DEV double dlog(double x) {
   return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
 }
 
+// log(1 + f) for |f| <= 0.25: dlog's kernel (its k = 0 branch) applied to f directly — no exponent extraction, no special cases.
+// The Marsaglia-Tsang test needs log((1 + c z)^3) = 3 log(1 + c z) with c z small whenever the shape is not.
+BNMF_DEV double dlog1p_small(double f) {
+  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+               Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+               Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  const double s = f / (2.0 + f);
+  const double z = s * s;
+  const double w = z * z;
+  const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  return f - (hfsq - s * (hfsq + R));
+}
+
 // dlog for a positive, finite, NORMAL argument: the same operations as dlog (hence the same bits) without the
 // special-case branches, so that independent evaluations can be interleaved by the compiler
 BNMF_DEV double dlog_fin(double x) {

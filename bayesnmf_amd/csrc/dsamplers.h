@@ -42,14 +42,16 @@ BNMF_DEV double rgamma(Stream& s, double a, double rate) {
     const u32x4 w = s.next();
     const double z = dqnorm(u52(w.x, w.y));
     const double ua = u52(w.z, w.w);
-    v = 1.0 + c * z;
+    const double cz = c * z;
+    v = 1.0 + cz;
     if (v <= 0.0) continue;
     v = v * v * v;
     const double z2 = z * z;
     if (ua < 1.0 - 0.0331 * (z2 * z2)) break;
     // accept iff log(ua) < R.  (ua - 1) / ua <= log(ua) <= ua - 1 decides all but a sliver of width ~ (1 - ua)^2 without the
     // logarithm (a wavefront pays for it whenever one lane needs it)
-    const double R = 0.5 * z2 + d * ((1.0 - v) + dlog(v));
+    const double lv = dabs(cz) <= 0.25 ? 3.0 * dlog1p_small(cz) : dlog(v);   // log v
+    const double R = 0.5 * z2 + d * ((1.0 - v) + lv);
     const double um1 = ua - 1.0;
     if (um1 < R) break;
     if (um1 / ua >= R) continue;
@@ -276,14 +278,16 @@ BNMF_DEV double ralpha_fast(Stream& s, double c, double tau, double xprev, int* 
     const u32x4 w = s.next();
     const double z = dqnorm(u52(w.x, w.y));
     const double u = u52(w.z, w.w);
-    double v = 1.0 + cc * z;
+    const double cz = cc * z;
+    double v = 1.0 + cz;
     if (v <= 0.0) continue;
     v = v * v * v;
     const double xs = (d * v) / r;
     if (!(xs >= L && xs <= U)) continue;
     // lgamma(xs) between its tangent at the grid point below xs and its chord to the next one (lgamma is convex): most
     // attempts are decided without evaluating it
-    const double a = (0.5 * (z * z) + d * ((1.0 - v) + dlog(v))) + (b0 + psi0 * xs);
+    const double lv = dabs(cz) <= 0.25 ? 3.0 * dlog1p_small(cz) : dlog(v);   // log v
+    const double a = (0.5 * (z * z) + d * ((1.0 - v) + lv)) + (b0 + psi0 * xs);
     const int ix = alut_idx(xs);
     const double dx = xs - alut_x(ix);
     const bool grid = dx >= 0.0 && ix + 1 < ALUT_N;

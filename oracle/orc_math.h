@@ -100,6 +100,22 @@ static inline double orc_log(double x) {
   return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
 }
 
+/* log(1 + f) for |f| <= 0.25: orc_log's kernel (its k = 0 branch) applied to f directly */
+static inline double orc_log1p_small(double f) {
+  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+               Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+               Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  double s = f / (2.0 + f);
+  double z = s * s;
+  double w = z * z;
+  double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  double R = t2 + t1;
+  double hfsq = 0.5 * f * f;
+  return f - (hfsq - s * (hfsq + R));
+}
+
 /* ------------------------------------------------------------------- exp -- */
 static inline double orc_exp(double x) {
   const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,

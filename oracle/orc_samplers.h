@@ -44,13 +44,15 @@ static inline double orc_rgamma(orc_stream* s, double a, double rate) {
     uint32_t w[4]; orc_stream_next(s, w);
     double z = orc_qnorm(orc_u52(w[0], w[1]));
     double ua = orc_u52(w[2], w[3]);
-    v = 1.0 + c * z;
+    double cz = c * z;
+    v = 1.0 + cz;
     if (v <= 0.0) continue;
     v = v * v * v;
     double z2 = z * z;
     if (ua < 1.0 - 0.0331 * (z2 * z2)) break;
     /* accept iff log(ua) < R; (ua - 1) / ua <= log(ua) <= ua - 1 decides all but a sliver without the logarithm */
-    double R = 0.5 * z2 + d * ((1.0 - v) + orc_log(v));
+    double lv = fabs(cz) <= 0.25 ? 3.0 * orc_log1p_small(cz) : orc_log(v);   /* log v = 3 log(1 + c z) */
+    double R = 0.5 * z2 + d * ((1.0 - v) + lv);
     double um1 = ua - 1.0;
     if (um1 < R) break;
     if (um1 / ua >= R) continue;
@@ -289,14 +291,16 @@ static inline double orc_ralpha_fast(orc_stream* s, double c, double tau, double
     uint32_t w[4]; orc_stream_next(s, w);
     const double z = orc_qnorm(orc_u52(w[0], w[1]));
     const double u = orc_u52(w[2], w[3]);
-    double v = 1.0 + cc * z;
+    const double cz = cc * z;
+    double v = 1.0 + cz;
     if (v <= 0.0) continue;
     v = v * v * v;
     const double xs = (d * v) / r;
     if (!(xs >= L && xs <= U)) continue;
     /* lgamma(xs) between its tangent at the grid point below xs and its chord to the next one (lgamma is convex): most
      * attempts are decided without evaluating it */
-    const double a = (0.5 * (z * z) + d * ((1.0 - v) + orc_log(v))) + (b0 + psi0 * xs);
+    const double lv = fabs(cz) <= 0.25 ? 3.0 * orc_log1p_small(cz) : orc_log(v);   /* log v */
+    const double a = (0.5 * (z * z) + d * ((1.0 - v) + lv)) + (b0 + psi0 * xs);
     const int ix = orc_alut_idx(xs);
     const double dx = xs - orc_alut_x(ix);
     const int grid = dx >= 0.0 && ix + 1 < ORC_ALUT_N;
