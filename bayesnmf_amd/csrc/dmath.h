@@ -189,7 +189,7 @@ BNMF_DEV double dqnorm(double p) {
   double r, val;
   {
     const double y = q + q;
-    const double w = -dlog((1.0 - y) * (1.0 + y));
+    const double w = -dlog_fin((1.0 - y) * (1.0 + y));   // argument in [2^-51, 1]: positive, normal, finite — the same bits as dlog
     if (w < 6.25) {
       const double s = w - 3.125;
       double a = -5.081556263217504e-22;

@@ -98,18 +98,26 @@ BNMF_DEV double ld_ag(const double* p) { return __hip_atomic_load(p, __ATOMIC_RE
 // ---- hyper sweep of one element: R/sample_priors.R:150-200 (element-wise conditionals) ----
 // PRE: `pre` is the Gamma(shape, 1) part of the element's first draw, made by hyper_pre before v was known (k_draw: before the
 // wait for P); rgamma(s, shape, rate) is that value divided by the rate, so the result is the same bits.  lut: ralpha_fast's table.
+// It also carries the element's hyper-prior values and previous Alpha: loaded before the wait, not behind it.
+struct HyperPre { double g, hB, hC, hD, al_old; };
 template <int SIDE>
-BNMF_DEV double hyper_pre(const Dev& d, int e, uint32_t t) {
-  const HRef& hA = SIDE ? d.hA_e : d.hA_p;
+BNMF_DEV HyperPre hyper_pre(const Dev& d, int e, uint32_t t) {
+  const HRef &hA = SIDE ? d.hA_e : d.hA_p, &hB = SIDE ? d.hB_e : d.hB_p;
+  HyperPre p{0.0, hy(hB, e), 0.0, 0.0, 0.0};
   if (d.prior == BNMF_GAMMA) {
+    const HRef &hC = SIDE ? d.hC_e : d.hC_p, &hD = SIDE ? d.hD_e : d.hD_p;
+    p.hC = hy(hC, e); p.hD = hy(hD, e);
+    p.al_old = slot<SIDE>(d, SIDE ? d.Alpha_e : d.Alpha_p, t - 1)[e];
     Stream s(d.k0, d.k1, SIDE ? BNMF_V_BETA_E : BNMF_V_BETA_P, (uint32_t)e, t);
-    return rgamma(s, hy(hA, e) + slot<SIDE>(d, SIDE ? d.Alpha_e : d.Alpha_p, t - 1)[e], 1.0);
+    p.g = rgamma(s, hy(hA, e) + p.al_old, 1.0);
+    return p;
   }
   Stream s(d.k0, d.k1, SIDE ? BNMF_V_LAMBDA_E : BNMF_V_LAMBDA_P, (uint32_t)e, t);
-  return rgamma(s, hy(hA, e) + 1.0, 1.0);
+  p.g = rgamma(s, hy(hA, e) + 1.0, 1.0);
+  return p;
 }
 template <int SIDE, bool PRE = false>
-BNMF_DEV void hyper_elem(const Dev& d, int e, uint32_t t, double v, double* rec0 = nullptr, double* rec1 = nullptr, double pre = 0.0,
+BNMF_DEV void hyper_elem(const Dev& d, int e, uint32_t t, double v, double* rec0 = nullptr, double* rec1 = nullptr, const HyperPre& pre = HyperPre{},
                          const double* lut = g_alut) {
   if (d.prior == BNMF_GAMMA) {
     const HRef &hA = SIDE ? d.hA_e : d.hA_p, &hB = SIDE ? d.hB_e : d.hB_p;
@@ -117,20 +125,20 @@ BNMF_DEV void hyper_elem(const Dev& d, int e, uint32_t t, double v, double* rec0
     double* Al = SIDE ? d.Alpha_e : d.Alpha_p;
     double* Be = SIDE ? d.Beta_e : d.Beta_p;
     Stream s(d.k0, d.k1, SIDE ? BNMF_V_BETA_E : BNMF_V_BETA_P, (uint32_t)e, t);
-    const double al_old = slot<SIDE>(d, Al, t - 1)[e];
-    const double b = PRE ? pre / (hy(hB, e) + v) : rgamma(s, hy(hA, e) + al_old, hy(hB, e) + v);        // sample_Beta_*  :323-345
+    const double al_old = PRE ? pre.al_old : slot<SIDE>(d, Al, t - 1)[e];
+    const double b = PRE ? pre.g / (pre.hB + v) : rgamma(s, hy(hA, e) + al_old, hy(hB, e) + v);        // sample_Beta_*  :323-345
     st_wt(&slot<SIDE>(d, Be, t)[e], b);
     if (rec1) rec1[e] = b;
-    const double tau = (hy(hD, e) - dlog(clamp_tiny(b))) - dlog(clamp_tiny(v));
+    const double tau = ((PRE ? pre.hD : hy(hD, e)) - dlog(clamp_tiny(b))) - dlog(clamp_tiny(v));
     Stream s2(d.k0, d.k1, SIDE ? BNMF_V_ALPHA_E : BNMF_V_ALPHA_P, (uint32_t)e, t);
-    const double al = ralpha_fast(s2, hy(hC, e), tau, al_old, nullptr, lut);   // sample_Alpha_* :356-397
+    const double al = ralpha_fast(s2, PRE ? pre.hC : hy(hC, e), tau, al_old, nullptr, lut);   // sample_Alpha_* :356-397
     st_wt(&slot<SIDE>(d, Al, t)[e], al);
     if (rec0) rec0[e] = al;
   } else if (d.prior == BNMF_EXPONENTIAL) {
     const HRef &hA = SIDE ? d.hA_e : d.hA_p, &hB = SIDE ? d.hB_e : d.hB_p;
     double* La = SIDE ? d.Lam_e : d.Lam_p;
     Stream s(d.k0, d.k1, SIDE ? BNMF_V_LAMBDA_E : BNMF_V_LAMBDA_P, (uint32_t)e, t);
-    const double la = PRE ? pre / (hy(hB, e) + v) : rgamma(s, hy(hA, e) + 1.0, hy(hB, e) + v);            // sample_Lambda_* :284-308
+    const double la = PRE ? pre.g / (pre.hB + v) : rgamma(s, hy(hA, e) + 1.0, hy(hB, e) + v);            // sample_Lambda_* :284-308
     st_wt(&slot<SIDE>(d, La, t)[e], la);
     if (rec0) rec0[e] = la;
   } else {
@@ -346,11 +354,10 @@ __global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, Side
   const long e = (long)((int)blockIdx.x - N) * BW + tid;
   const bool live = e < (long)d.lenE;
   DRSTAMP(0);
-  if (d.prior == BNMF_GAMMA) for (int i = tid; i < 3 * ALUT_N; i += BW) lutS[i] = g_alut[i];   // visible after side_wait's barrier
   double x = 0.0, a_n = 0.0;
   bool scaled = false;                                   // x is Gamma(shape, 1) and still has to be divided by the rate
   double base = 0.0;                                     // the rate without its Psum term
-  double hpre = 0.0;                                     // Gamma(shape, 1) part of the hyper sweep's first draw (needs nothing from this iteration)
+  HyperPre hpre{};                                       // Gamma(shape, 1) part of the hyper sweep's first draw and the element's hyper-prior values (need nothing from this iteration)
   int n = 0;
   if (live) {
     n = (int)(e % N);
@@ -366,6 +373,9 @@ __global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, Side
     }
     hpre = hyper_pre<1>(d, (int)e, t + 1);
   }
+  // the Alpha table: behind the draws (the waves arrive here one by one, so its loads overlap the others' arithmetic; at the head of
+  // the kernel every wave sat through them at once), visible after side_wait's barrier
+  if (d.prior == BNMF_GAMMA) for (int i = tid; i < 3 * ALUT_N; i += BW) lutS[i] = g_alut[i];
   DRSTAMP(1);
   side_wait<false>(pw, tid);
   DRSTAMP(2);
