@@ -230,7 +230,7 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   if (const char* e = getenv("BNMF_ZSORT")) if (atoi(e) == 0) return 0;          // diagnostics / tests: the register kernel
   const int nblk = (int)((N + 4) / 5);                                             // threshold blocks per cell
   const int KP = (K % 32 == 0) ? (int)K + 1 : (int)(K | 1);
-  size_t budget = 128 * 1024;                                                     // leaves the hyper sweep's workgroups room on the CU
+  size_t budget = 156 * 1024;                                                     // of 160: the side streams' workgroups (2 KB each) keep room on the CU
   if (const char* e = getenv("BNMF_ZSLDS")) budget = (size_t)atol(e) * 1024;
   long nb = std::min<long>((long)G, n_cu);
   int GBc = 0, W = 0;

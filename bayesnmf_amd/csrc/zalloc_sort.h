@@ -52,7 +52,7 @@ BNMF_HD size_t zsort_shared_bytes(int K, int N, int KP, int GBc, bool pk) {
   w = (w + 3) & ~(size_t)3;
   return (w * 4 + ((size_t)K * N + (size_t)N * GBc) * 8 + 15) & ~(size_t)15;   // + Pl, ae (fp64); the waves' slabs are 16-byte aligned
 }
-BNMF_HD size_t zsort_wave_bytes(int NBLK, int N) { return (size_t)NBLK * 64 * 16 + (size_t)((N + 1) / 2) * 64 * 4; }
+BNMF_HD size_t zsort_wave_bytes(int NBLK, int N) { return (size_t)NBLK * 64 * 16 + (size_t)(2 * ((N + 1) / 2)) * 64 * 4; }   // threshold blocks + one histogram word per factor and lane
 
 // <= 128 VGPRs (4 waves per SIMD by registers): three waves per SIMD of this kernel then leave the side streams' kernels
 // (128 VGPRs) a wave slot on every SIMD — at 133 VGPRs they could not start before the first workgroups here had ended
@@ -80,7 +80,8 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
   double* ae = Pl + (size_t)K * N;                         // [N][GBc]  A[n] E[n, column]
   unsigned char* wbase = smem + zsort_shared_bytes(K, N, KP, GBc, PK) + (size_t)wave * zsort_wave_bytes(NBLK, N);
   u4* tblk = (u4*)wbase;                                   // [NBLK][64]
-  uint32_t* hist = (uint32_t*)(tblk + NBLK * 64);          // [(N+1)/2][64] packed 16-bit bucket counts of the lane's item
+  uint32_t* hist = (uint32_t*)(tblk + NBLK * 64);          // [2 HW][64] bucket counts of the lane's item: one word each (the update is an
+                                                           // address and an add; packed in 16-bit halves it was three more instructions per count)
 #ifdef ZSPROF
   uint64_t zsprof[8] = {0, 0, 0, 0, 0, 0, 0, 1};
 #endif
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
   ZSTIC(0);
   // ---------------- block set-up.  Three independent global-memory chains (P; the block's slab of M; column ids -> E) go
   // to different waves, so that their latencies overlap instead of adding up
-  for (int i = lane; i < HW * 64; i += 64) hist[i] = 0;
+  for (int i = lane; i < 2 * HW * 64; i += 64) hist[i] = 0;
   {
     const int job = wave % 3, jw = wave / 3, nj = (ZW - job + 2) / 3;   // waves job, job + 3, ... do this job
     const int jt = jw * 64 + lane, jn = nj * 64;
@@ -229,10 +230,10 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
       const uint32_t b1 = 5 * j1 + (k1.x <= u1) + (k1.y <= u1) + (k1.z <= u1) + (k1.w <= u1);
       const uint32_t b2 = 5 * j2 + (k2.x <= u2) + (k2.y <= u2) + (k2.z <= u2) + (k2.w <= u2);
       const uint32_t b3 = 5 * j3 + (k3.x <= u3) + (k3.y <= u3) + (k3.z <= u3) + (k3.w <= u3);
-      lds_add(mad24(b0 >> 1, 256, hlb), inc0 << ((b0 & 1) << 4));
-      lds_add(mad24(b1 >> 1, 256, hlb), inc1 << ((b1 & 1) << 4));
-      lds_add(mad24(b2 >> 1, 256, hlb), inc2 << ((b2 & 1) << 4));
-      lds_add(mad24(b3 >> 1, 256, hlb), inc3 << ((b3 & 1) << 4));
+      lds_add(mad24(b0, 256, hlb), inc0);
+      lds_add(mad24(b1, 256, hlb), inc1);
+      lds_add(mad24(b2, 256, hlb), inc2);
+      lds_add(mad24(b3, 256, hlb), inc3);
     };
     wave_lds_fence();
     ZSTOC(1);
@@ -248,9 +249,10 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
     if (nq > 0) {
       const uint32_t zgb = lds_off(zG) + ((uint32_t)k << 2), zkb = lds_off(zK) + ((uint32_t)gl << 2);
       for (int w = 0; w < HW; ++w) {
-        const uint32_t v = hist[w * 64 + lane];
+        const uint32_t v0 = hist[(2 * w) * 64 + lane], v1 = hist[(2 * w + 1) * 64 + lane];
+        const uint32_t v = v0 | (v1 << 16);                // a cell holds at most 4 ZS_QMAX counts per item
         if (v) {
-          hist[w * 64 + lane] = 0;
+          hist[(2 * w) * 64 + lane] = 0; hist[(2 * w + 1) * 64 + lane] = 0;
           if (PK) {                      // the pair of factors 2w, 2w + 1 in one add (no half can overflow: checked at bnmf_create)
             lds_add(zgb + (uint32_t)w * (uint32_t)KP * 4u, v); lds_add(zkb + (uint32_t)w * (uint32_t)GBc * 4u, v);
           } else {
