@@ -299,6 +299,12 @@ BNMF_DEV double dlog_pnorm(double z) {
 // ----------------------------------------------------------- canonical reductions
 // canon_sum(x, L, W): accumulator i adds x[i], x[i+W], ... in order from +0.0, then the
 // halving tree acc[i] += acc[i+h], h = W/2..1.  W = 64: one wavefront; larger W: a workgroup.
+BNMF_DEV double down32(double v) {                        // lane l < 32 gets lane l + 32's value
+  const unsigned lo = (unsigned)__double_as_longlong(v), hi = (unsigned)(__double_as_longlong(v) >> 32);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __longlong_as_double(((long long)b[1] << 32) | (unsigned)a[1]);
+}
 // The same halving tree (lane i adds lane i + h for h = 32, 16, 8, 4, 2, 1: same operands, same bits as the __shfl_down
 // form) without the LDS crossbar: gfx950's v_permlane32_swap / v_permlane16_swap bring lanes i + 32 / i + 16 down, DPP
 // row shifts do the rest.  A tree is ~20 VALU instructions instead of 12 dependent ds_bpermute round trips.

@@ -184,12 +184,6 @@ BNMF_DEV double rank_decide(const Dev& d, double u /* the factor's uniform: bloc
 // column 2p + 1, row 64 + (lane & 31)), so that no lane idles on a half-empty second pass; the upper half's terms are
 // brought down with v_permlane32_swap before they are added to their column's accumulators (lane i = rows i, i + 64, as
 // the canonical sum demands).  Otherwise a wave walks its blocks b = w, w + Wt, ... and Mhat lives in the global scratch.
-BNMF_DEV double down32(double v) {                        // lane l < 32 gets lane l + 32's value
-  const unsigned lo = (unsigned)__double_as_longlong(v), hi = (unsigned)(__double_as_longlong(v) >> 32);
-  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return __longlong_as_double(((long long)b[1] << 32) | (unsigned)a[1]);
-}
 template <bool REG, bool NORMAL>
 __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsigned long long* granbuf /* [4][2 NB] */, int NB, int* err, double* mhg, unsigned long long* dbg,
                                                          int row /* metrics row, or -1 */, double* recA, double* recR) {

@@ -139,7 +139,12 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
       double a_sse[ZS_MCOL], a_ll[ZS_MCOL], a_kl[ZS_MCOL];
 #pragma unroll
       for (int j = 0; j < ZS_MCOL; ++j) { a_sse[j] = 0.0; a_ll[j] = 0.0; a_kl[j] = 0.0; }
-      for (int r = 0; r < KR; ++r) {
+      // a last pass of at most 32 rows (K = 96: rows 64..95): the two columns share it, lanes 0..31 column 0, lanes 32..63
+      // column 1, and column 1's terms come down with v_permlane32_swap to the lanes whose accumulators they belong to —
+      // the same additions in the same order, without half the wave idling through a pass
+      const int KL = K - ((KR - 1) << 6);
+      const bool split = ZS_MCOL == 2 && KL <= 32;
+      for (int r = 0; r < KR - (split ? 1 : 0); ++r) {
         const int kk = (r << 6) + lane;
         if (kk < K) {
           int m[ZS_MCOL];
@@ -168,6 +173,33 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
             a_ll[j] = a_ll[j] + (((double)m[j] * lmh - mh) - lgf[j]);
             a_kl[j] = a_kl[j] + mt * (lgm[j] - lmh);
           }
+        }
+      }
+      if (split) {
+        const int jc = lane >> 5, rl = lane & 31;
+        const int kk = ((KR - 1) << 6) + rl;
+        double tsse = 0.0, tll = 0.0, tkl = 0.0;
+        if (rl < KL) {
+          const int gl = min(gl0 + jc, bk.ncols - 1);
+          const int m = Ms[kk + (size_t)K * gl];
+          const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
+          const double lgf = d.lgfact[mi], lgm = d.logm[mi];
+          double c = 0.0;
+#pragma unroll
+          for (int n = 0; n < NC; ++n) if (n < NMIN || n < N) c = c + Pl[kk + (size_t)K * n] * ae[(size_t)n * GBc + gl];
+          const double dd = c - (double)m;
+          const double mh = c < 1e-6 ? 1e-6 : c;
+          const double lmh = dlog(mh);
+          const double mt = m < 1 ? 1e-6 : (double)m;
+          tsse = dd * dd;
+          tll = ((double)m * lmh - mh) - lgf;
+          tkl = mt * (lgm - lmh);
+        }
+        const double u0 = down32(tsse), u1 = down32(tll), u2 = down32(tkl);
+        if (lane < 32 && rl < KL) {
+          a_sse[0] = a_sse[0] + tsse; a_ll[0] = a_ll[0] + tll; a_kl[0] = a_kl[0] + tkl;
+          constexpr int J1 = ZS_MCOL > 1 ? 1 : 0;
+          if (ZS_MCOL > 1) { a_sse[J1] = a_sse[J1] + u0; a_ll[J1] = a_ll[J1] + u1; a_kl[J1] = a_kl[J1] + u2; }
         }
       }
 #pragma unroll
