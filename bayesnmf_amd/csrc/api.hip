@@ -1773,13 +1773,13 @@ int bnmf_assign(bnmf_handle* h, int last_n, const int32_t* used, const double* r
   return 0;
 }
 
-// ---- measured ceilings for bench.py's roofline: Philox4x32-10 words per second with nothing else in the loop (the floor of
-// any allocation kernel: one word per count), and the device-to-device copy bandwidth ----
+// ---- measured ceilings for bench.py's roofline: Philox4x32-7 words per second (the count-allocation stream's generator) with
+// nothing else in the loop (the floor of any allocation kernel: one word per count), and the device-to-device copy bandwidth ----
 __global__ __launch_bounds__(256) void k_ubench_philox(uint32_t* out, int blocks_per_lane, uint32_t seed) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t acc = 0;
   for (int q = 0; q < blocks_per_lane; ++q) {
-    const u32x4 w = philox4x32_10((uint32_t)q, gid, seed, 5u, 17u, 29u);
+    const u32x4 w = philox4x32_7((uint32_t)q, gid, seed, 5u, 17u, 29u);
     acc += w.x ^ w.y ^ w.z ^ w.w;
   }
   out[gid] = acc;

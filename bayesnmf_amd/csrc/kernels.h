@@ -309,6 +309,10 @@ __global__ __launch_bounds__(ES_T) void k_edraw(Dev d, uint32_t t, int from_prio
 // the flag (one lane polls; the P workgroups have the lowest indices, so they are resident before any E workgroup) and divides
 // by the rate — the same operations in the same order as rgamma(shape, rate).  The kernel waits for nothing outside itself: the
 // allocation kernel before it has waited (one lane, at its end) for the hyper sweep of this iteration.
+// ASSUMPTION (stated, not enforced): the dispatcher starts the workgroups of a launch in index order, so the N P workgroups are running
+// before an E workgroup can hold a slot they need.  If that ever failed (other chains filling the CUs in between), the E workgroups'
+// bounded wait would time out: the call fails with BNMF_EHIP and the handle is poisoned — an error, never a wrong draw.  Covered with
+// other chains on the device by tests/test_gpu_configs.py::test_four_different_chains_at_once_match_their_solo_runs (K G = 768,000).
 constexpr int DW = 1024;
 // The E workgroups also run the E-side hyper sweep of iteration t + 1 (hyper_elem<1>: element-wise, it needs nothing but the
 // element's own E_t): beside the allocation kernel that sweep got one wave per SIMD and the leftover issue slots (85 us for

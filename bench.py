@@ -59,7 +59,7 @@ _CEILINGS = {}
 
 
 def ceilings(device):
-    """Measured ceilings of this box: Philox4x32-10 words/s with nothing else in the loop (one word per
+    """Measured ceilings of this box: Philox4x32-7 words/s (the count-allocation stream's generator) with nothing else in the loop (one word per
     allocated count is the floor of any allocation kernel) and the device-to-device copy bandwidth, next to the nominal 8 TB/s."""
     if device not in _CEILINGS:
         from bayesnmf_amd.engine import ubench
@@ -84,7 +84,7 @@ def roofline_of(chain, K, G, N, save_Z, total_counts, n_iter, kernel=None, devic
                   # the bound that actually binds in stats mode: one Philox word per allocated count
                   "alu": {"achieved_philox_words_per_s": draws, "peak_philox_words_per_s": philox_peak,
                           "frac": draws / philox_peak if philox_peak > 0 else None,
-                          "note": "peak = Philox4x32-10 alone at 8 waves/SIMD, measured on this box (bnmf_ubench); the kernel also "
+                          "note": "peak = Philox4x32-7 (the generator of the count-allocation words) alone at 8 waves/SIMD, measured on this box (bnmf_ubench); the kernel also "
                                   "searches 19 thresholds and updates two tables per word"},
                   "note": "stats mode moves 6.3 MB per 40 M categorical draws: the kernel is VALU/Philox-bound, not HBM-bound (DESIGN.md 5)"
                           if not save_Z else "full mode: Z (K x N x G int32) written every iteration"}

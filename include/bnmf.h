@@ -171,7 +171,7 @@ int bnmf_get_iter(bnmf_handle* h, int* iter);
 int bnmf_profile(bnmf_handle* h, int n_iter, int converged, double* out_ms);
 const char* bnmf_kernel_name(int i);
 
-/* measured ceilings of the device for bench.py's roofline: Philox4x32-10 words per second with nothing else in the loop
+/* measured ceilings of the device for bench.py's roofline: Philox4x32-7 words per second (the count-allocation generator) alone in a loop
  * (one word per allocated count: the floor of sample_Zkg, R/sample_params.R:253-265) and the device-to-device copy
  * bandwidth in GB/s (read + write), next to the nominal 8 TB/s */
 int bnmf_ubench(int device, double* philox_words_per_s, double* copy_gbs);
