@@ -9,7 +9,7 @@ cp $(ls $O/prof/*/*kernel_stats.csv | head -1) $O/bench_kernel_stats.csv
 bash tools/pmc_r3.sh $O/pmc > $O/pmc.txt 2>&1; echo "pmc rc=$?"; tail -1 $O/pmc.txt
 for c in 3 3c 4; do CFG=$c ITERS=30 bash tools/prof_cfg.sh $c r03/cfg$c 14 > $O/cfg$c.txt 2>&1; cp $(ls $O/cfg$c/*/*kernel_stats.csv | head -1) $O/cfg${c}_kernel_stats.csv; done
 G5=50000 ITERS=8 WINDOW=2 CFG=5 bash tools/prof_cfg.sh 5 r03/cfg5 10 > $O/cfg5.txt 2>&1; cp $(ls $O/cfg5/*/*kernel_stats.csv | head -1) $O/cfg5_kernel_stats.csv
-CFG=m ITERS=60 bash tools/prof_cfg.sh m r03/cfgm 18 > $O/timeline_steady_state.txt 2>&1
+CFG=m ITERS=800 WINDOW=1000 bash tools/prof_cfg.sh m r03/cfgm 18 > $O/timeline_steady_state.txt 2>&1
 python tools/zsprof.py 10000 > $O/zsort_sections.txt 2>&1
 python tools/drprof.py > $O/draw_sections.txt 2>&1
 ./tools/bin/ubench_scan > $O/ubench_scan.txt 2>&1
