@@ -59,6 +59,7 @@ def lib():
         L.orc_run.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
         L.orc_get_iter.argtypes = [C.c_void_p]
         L.orc_set_M.argtypes = [C.c_void_p, ip]
+        L.orc_set_fresh_mhat.argtypes = [C.c_void_p, C.c_int]
         L.orc_t_step.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int]
         L.orc_last_error.restype = C.c_char_p
         L.orc_last_error.argtypes = [C.c_void_p]
@@ -231,6 +232,10 @@ class Oracle:
         rc = lib().orc_t_step(self._h, self.STEPS[what], int(t), int(converged))
         if rc != 0:
             raise ValueError(f"orc_t_step({what}) not defined for this model")
+
+    def set_fresh_mhat(self, on=True):
+        """Recompute P diag(A) E from scratch at every factor (what the R code does) instead of maintaining it (the stream spec)."""
+        lib().orc_set_fresh_mhat(self._h, int(bool(on)))
 
     def set_M(self, M):
         M = np.asfortranarray(M, dtype=np.int32)

@@ -65,6 +65,7 @@ typedef struct { double* p; long n; long stride; int set; } arr_t;
 typedef struct orc_handle {
   orc_config cfg;
   int iter, converged, R;
+  int fresh_mhat;   /* checker of the checker (orc_set_fresh_mhat): recompute P diag(A) E from scratch wherever the stream spec maintains it */
   int32_t* M;
   int32_t *Z, *ZsumK, *ZsumG;
   arr_t a[ID_MAX];
@@ -473,6 +474,21 @@ static void sample_A(orc_handle* o, uint32_t t, int from_prior) {
     }
     double ll_alt = hsum_cols(col, G);
     double ll0 = (a_old == 1.0) ? ll_alt : ll_cur, ll1 = (a_old == 1.0) ? ll_cur : ll_alt;
+    if (o->fresh_mhat) {                                          /* as R: both log-likelihoods from P diag(A^j) E, from scratch */
+      for (int state = 0; state < 2; ++state) {
+#pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
+        for (long g = 0; g < G; ++g) {
+          double l[4096];
+          for (long k = 0; k < K; ++k) {
+            double c = 0.0;
+            for (long j = 0; j < N; ++j) c = c + (AR(ID_P)[k + K * j] * (j == n ? (double)state : AR(ID_A)[j])) * AR(ID_E)[j + N * g];
+            l[k] = ll_cell_rank(o, o->M[k + K * g], c, g);
+          }
+          col[g] = orc_canon_sum(l, K, 1, 64);
+        }
+        if (state == 0) ll0 = hsum_cols(col, G); else ll1 = hsum_cols(col, G);
+      }
+    }
     double sumA = 0.0;
     for (long j = 0; j < N; ++j) sumA = sumA + AR(ID_A)[j];
     double sumA0 = sumA - a_old, sumA1 = sumA0 + 1.0;
@@ -539,6 +555,16 @@ static inline double mhat_cell(const orc_handle* o, long k, long g, long skip /*
   }
   return c;
 }
+static inline double mhat_cell_e(const orc_handle* o, long k, long g, long skip, double e_over, long n_over) {   /* E[n_over, g] replaced */
+  const long K = o->cfg.K, N = o->cfg.N;
+  double c = 0.0;
+  for (long j = 0; j < N; ++j) {
+    double a = (j == skip) ? 0.0 : o->a[ID_A].p[j];
+    double ejg = (j == n_over) ? e_over : o->a[ID_E].p[j + N * g];
+    c = c + (o->a[ID_P].p[k + K * j] * a) * ejg;
+  }
+  return c;
+}
 static inline double dpois_log(int32_t m, double lam) {   /* get_loglik_ poisson branch R/utils.R:98-106 */
   double mh = lam < 1e-6 ? 1e-6 : lam;
   return ((double)m * orc_log(mh) - mh) - orc_lgamma((double)m + 1.0);
@@ -590,11 +616,13 @@ static void sample_P_seq(orc_handle* o, uint32_t t) {
       const double a_n = AR(ID_A)[n];
       if (a_n == 0.0) { P[e] = prior_draw(o, 0, e, t); continue; }                /* sample_Pn :12; term of Mhat is 0 */
       const double pa = P[e] * a_n;
+      const int fresh = o->fresh_mhat;
+      if (fresh) for (long g = 0; g < G; ++g) row[g] = mhat_cell(o, k, g, -1, NULL, 0);   /* as R: from scratch at every factor */
       double num1 = 0.0, den = 0.0;
       if (!allzero[n]) {
         for (long g = 0; g < G; ++g) {
           double en = AR(ID_E)[n + N * g];
-          double mno = row[g] - pa * en;                                           /* Mhat_no_n */
+          double mno = fresh ? mhat_cell(o, k, g, n, NULL, 0) : row[g] - pa * en;  /* Mhat_no_n */
           double V = normal ? AR(ID_SIGMASQ)[g] : row[g];                          /* sigmasq_kg :137-147 */
           double rV = 1.0 / V;                                                     /* one reciprocal serves both sums (stream spec) */
           x1[g] = en * (((double)o->M[k + K * g] - mno) * rV);                     /* :155-161 */
@@ -610,7 +638,7 @@ static void sample_P_seq(orc_handle* o, uint32_t t) {
       else {
         for (long g = 0; g < G; ++g) {
           double en = AR(ID_E)[n + N * g];
-          double m0 = row[g], m1 = (m0 - pa * en) + pra * en;
+          double m0 = row[g], m1 = fresh ? mhat_cell(o, k, g, -1, &pr, n) : (m0 - pa * en) + pra * en;
           int32_t m = o->M[k + K * g];
           y[g] = dpois_log(m, m1);                                       /* loglik_poisson_new :216-218 */
           y[G + g] = dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);     /* loglik_normal_old :219-224 */
@@ -654,11 +682,13 @@ static void sample_E_seq(orc_handle* o, uint32_t t) {
       const double a_n = AR(ID_A)[n];
       if (a_n == 0.0) { E[e] = prior_draw(o, 1, e, t); continue; }     /* sample_En :12 */
       const double eold = E[e];
+      const int fresh = o->fresh_mhat;
+      if (fresh) for (long k = 0; k < K; ++k) mhc[k] = mhat_cell(o, k, g, -1, NULL, 0);
       double num1 = 0.0, den = 0.0;
       if (!allzero[n]) {
         for (long k = 0; k < K; ++k) {
           double pn = AR(ID_P)[k + K * n];
-          double mno = mhc[k] - (pn * a_n) * eold;
+          double mno = fresh ? mhat_cell(o, k, g, n, NULL, 0) : mhc[k] - (pn * a_n) * eold;
           double V = normal ? sg : mhc[k];
           double rV = 1.0 / V;
           x1[k] = pn * (((double)o->M[k + K * g] - mno) * rV);
@@ -673,7 +703,7 @@ static void sample_E_seq(orc_handle* o, uint32_t t) {
       else {
         for (long k = 0; k < K; ++k) {
           double pna = AR(ID_P)[k + K * n] * a_n;
-          double m0 = mhc[k], m1 = (m0 - pna * eold) + pna * pr;
+          double m0 = mhc[k], m1 = fresh ? mhat_cell_e(o, k, g, -1, pr, n) : (m0 - pna * eold) + pna * pr;
           int32_t m = o->M[k + K * g];
           y[k] = dpois_log(m, m1);
           y[K + k] = dnorm_log((double)m, m0, m1 < 1.0 ? 1.0 : m1);
@@ -896,6 +926,11 @@ const char* orc_last_error(orc_handle* o) { return o->err; }
 
 /* ---- single-step hooks for the law tests (tests/test_oracle_laws.py): one conditional of the sweep on the
  * current state with the streams of iteration t; orc_set_M swaps the data (Geweke joint-distribution test) ---- */
+/* The stream spec maintains Mhat incrementally in the rank sweep and the MH / Normal sweeps (O(N K G)); the R code recomputes
+ * P diag(A) E by BLAS products at every factor (R/sample_params.R:101-166, R/sample_Pn.R:132-187, R/sample_En.R).  With this switch on the
+ * oracle does what R does — every Mhat, Mhat without factor n and Mhat with the proposed value from scratch, in factor order —
+ * so that tests/test_oracle.py can tie the maintained form to the R semantics without the GPU (agreement to rounding). */
+int orc_set_fresh_mhat(orc_handle* o, int on) { o->fresh_mhat = on; return 0; }
 int orc_set_M(orc_handle* o, const int32_t* M) {
   memcpy(o->M, M, sizeof(int32_t) * (size_t)o->cfg.K * o->cfg.G);
   return 0;
