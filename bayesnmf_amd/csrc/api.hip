@@ -1098,7 +1098,7 @@ static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged, bool poll = 
   }
   double* accP = h->arr[BNMF_ACC_P].d; double* accE = h->arr[BNMF_ACC_E].d;
   const bool regP = S <= MHP_W;                              // one 320-column segment per wave: the row's cells stay in registers
-  const size_t ldsP = (4 * (size_t)S + 2 * N + 2 + ((regP && mhstep) ? (size_t)MH_CPL * MHP_T : 0)) * sizeof(double);
+  const size_t ldsP = (4 * (size_t)S + 2 * N + 2 + (size_t)(PRE_W + 2) * N + ((regP && mhstep) ? (size_t)MH_CPL * MHP_T : 0)) * sizeof(double);
   auto goP = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(K), dim3(MHP_T), ldsP, h->stream, h->dev, t, S, (const int*)h->dNzE, h->dNzE + N, accP, h->dMhat, h->dMhat + (size_t)K * h->cfg.G,
                                                 poll ? SideWait{h->dFlags + 1, h->dFlags + 1, t, h->dErr} : SideWait{}); };
   if (normal) { if (regP) goP(k_mh_prow<true, true, false>); else goP(k_mh_prow<true, false, false>); }
@@ -1109,7 +1109,7 @@ static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged, bool poll = 
     // lanes per column: 16 for the Gibbs-only sweep, 32 with the MH step (measured at config 3: 117 / 126 us and 276 / 205 us)
     const int gw = h->mhe_gw ? h->mhe_gw : (mhstep ? 32 : 16), cpw = 64 / gw;
     int g16 = ((G + cpw - 1) / cpw + 3) / 4; if (g16 > 2048) g16 = 2048;
-    const size_t lds16 = 4 * (size_t)cpw * N * sizeof(double);
+    const size_t lds16 = 4 * (size_t)cpw * N * (1 + PRE_W) * sizeof(double);
     auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)(h->dNzE + N), accE, 0); };
     if (gw == 16) { if (mhstep) go(k_mh_ecol16<false, true, 16>); else go(k_mh_ecol16<false, false, 16>); }
     else { if (mhstep) go(k_mh_ecol16<false, true, 32>); else go(k_mh_ecol16<false, false, 32>); }
@@ -1124,7 +1124,7 @@ static int launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells, bool with_r
     if (h->cfg.K <= MHE16_KMAX) {
       const int gw = h->mhe_gw ? h->mhe_gw : 16, cpw = 64 / gw;
       int g16 = ((G + cpw - 1) / cpw + 3) / 4; if (g16 > 2048) g16 = 2048;
-      const size_t lds16 = 4 * (size_t)cpw * N * sizeof(double);
+      const size_t lds16 = 4 * (size_t)cpw * N * (1 + PRE_W) * sizeof(double);
       if (gw == 16) hipLaunchKernelGGL((k_mh_ecol16<true, false, 16>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
       else hipLaunchKernelGGL((k_mh_ecol16<true, false, 32>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
     } else {

@@ -90,6 +90,48 @@ BNMF_DEV double rtnorm0(Stream& s, double mu, double sd) {
   return x < 0.0 ? 0.0 : x;
 }
 
+// rtnorm0 with the parts of its first attempt that need neither mu nor sd taken out: the block's first uniform through the
+// normal quantile and through the logarithm, and its second uniform.  The sequential sweeps of the MH / Normal models draw one
+// truncated normal per factor inside a chain of dependent steps; these three values per factor are made before the chain starts
+// (all factors at once, one per lane).  rtnorm0_pre(s, rt_pre(...), mu, sd) performs rtnorm0's operations in rtnorm0's order.
+struct RtPre { double z, lu, u2; };
+BNMF_DEV RtPre rt_pre(uint32_t k0, uint32_t k1, uint32_t var, uint32_t elem, uint32_t iter) {
+  const u32x4 w = philox4x32_10(0u, elem, iter, var, k0, k1);
+  const double u1 = u52(w.x, w.y);
+  return RtPre{dqnorm(u1), dlog(u1), u52(w.z, w.w)};
+}
+BNMF_DEV double rtnorm0_pre(Stream& s /* of the same (variable, element, iteration), at block 0 */, const RtPre& p, double mu, double sd) {
+  const double alpha = -mu / sd;
+  double z = alpha;
+  s.blk = 1;
+  if (alpha < 0.45) {
+    z = p.z;
+    if (!(z >= alpha))
+      for (int it = 1; it < MAX_ATTEMPTS; ++it) {
+        const u32x4 w = s.next();
+        z = dqnorm(u52(w.x, w.y));
+        if (z >= alpha) break;
+      }
+  } else {
+    const double lam = 0.5 * (alpha + dsqrt(alpha * alpha + 4.0));
+    const double e0 = -p.lu / lam;
+    z = alpha + e0;
+    const double t0 = z - lam;
+    const double rho0 = dexp(-0.5 * (t0 * t0));
+    if (!(p.u2 <= rho0))
+      for (int it = 1; it < MAX_ATTEMPTS; ++it) {
+        const u32x4 w = s.next();
+        const double e = -dlog(u52(w.x, w.y)) / lam;
+        z = alpha + e;
+        const double t = z - lam;
+        const double rho = dexp(-0.5 * (t * t));
+        if (u52(w.z, w.w) <= rho) break;
+      }
+  }
+  const double x = mu + sd * z;
+  return x < 0.0 ? 0.0 : x;
+}
+
 // log f(x) = (c-1) log x - tau x - lgamma(x) and its derivative
 BNMF_DEV void alpha_h(double x, double c, double tau, double& h, double& hp) {
   double lg, dg;

@@ -474,6 +474,14 @@ BNMF_DEV void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
+// Workgroup barrier for hand-offs that go through LDS only: every wave waits for its own LDS (and scalar) operations, not for its
+// outstanding global loads and stores, as __syncthreads() does — inside a chain of short dependent steps that wait is a round trip to
+// L2 per barrier (a store of the step's result, a prefetch for the next step).
+BNMF_DEV void wg_lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 BNMF_DEV uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);

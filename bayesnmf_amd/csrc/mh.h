@@ -63,6 +63,42 @@ BNMF_DEV double mh_prior_or_cond(const Dev& d, int e, uint32_t t, bool use_prior
   return rtnorm0(s, mu, dsqrt(var));
 }
 
+// What a factor's update needs that depends on nothing computed inside the sweep: rt_pre of its proposal stream, its prior
+// parameters, and the uniform of its accept / reject step.  Made for all factors of a row / column before the N sequential
+// updates start (one factor per lane), so that the chain of dependent steps holds no Philox block, no quantile and no load.
+struct DrawPre { RtPre r; double p0, p1, umh, q0, q1; };   // q0 = p0 / p1, q1 = 1 / p1 (truncated-normal prior: the conditional's two divisions by Sigmasq)
+template <int SIDE>
+BNMF_DEV DrawPre draw_pre(const Dev& d, int e, uint32_t t, bool mhstep) {
+  DrawPre q;
+  q.r = rt_pre(d.k0, d.k1, SIDE ? BNMF_V_E : BNMF_V_P, (uint32_t)e, t);
+  if (d.prior == BNMF_EXPONENTIAL) { q.p0 = slot<SIDE>(d, SIDE ? d.Lam_e : d.Lam_p, t)[e]; q.p1 = 0.0; }
+  else { q.p0 = slot<SIDE>(d, SIDE ? d.Mu_e : d.Mu_p, t)[e]; q.p1 = slot<SIDE>(d, SIDE ? d.Sig_e : d.Sig_p, t)[e]; }
+  q.q0 = q.q1 = 0.0;
+  if (d.prior != BNMF_EXPONENTIAL) { q.q0 = q.p0 / q.p1; q.q1 = 1.0 / q.p1; }
+  q.umh = 0.0;
+  if (mhstep) { Stream su(d.k0, d.k1, SIDE ? BNMF_V_MHU_E : BNMF_V_MHU_P, (uint32_t)e, t); q.umh = runif(su); }
+  return q;
+}
+BNMF_DEV void pre_store(double* a, const DrawPre& q) { a[0] = q.r.z; a[1] = q.r.lu; a[2] = q.r.u2; a[3] = q.p0; a[4] = q.p1; a[5] = q.umh; a[6] = q.q0; a[7] = q.q1; }
+BNMF_DEV DrawPre pre_load(const double* a) { return DrawPre{RtPre{a[0], a[1], a[2]}, a[3], a[4], a[5], a[6], a[7]}; }
+constexpr int PRE_W = 8;                                  // doubles per factor
+// mh_prior_or_cond (and the prior_draw it falls back to) on a DrawPre: the same operations in the same order
+template <int SIDE>
+BNMF_DEV double mh_prior_or_cond_pre(const Dev& d, int e, uint32_t t, bool use_prior, double num1, double den, const DrawPre& q) {
+  Stream s(d.k0, d.k1, SIDE ? BNMF_V_E : BNMF_V_P, (uint32_t)e, t);
+  if (use_prior) {                                        // prior_draw<SIDE>
+    if (d.prior == BNMF_EXPONENTIAL) return -q.r.lu / q.p0;
+    return rtnorm0_pre(s, q.r, q.p0, dsqrt(q.p1));
+  }
+  double mu, var;
+  if (d.prior == BNMF_EXPONENTIAL) { mu = (num1 - q.p0) / den; var = 1.0 / den; }
+  else {
+    const double den2 = den + q.q1;
+    mu = (num1 + q.q0) / den2; var = 1.0 / den2;
+  }
+  return rtnorm0_pre(s, q.r, mu, dsqrt(var));
+}
+
 // nzE[n] = number of non-zero entries in row n of E (all(E[n,] == 0) test of sample_Pn_normal :56); also writes
 // the transpose Et[g + G n] = E[n, g] that the P-side kernels read (E is constant during the P updates): there a
 // wave's lanes walk consecutive columns g of ONE row, and E[n + N g] / M[k + K g] would be 64 cache lines per load
@@ -109,14 +145,21 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
   double* pa = part + 4 * (size_t)S;                    // [N] P[k,j] * A[j]
   double* bc = pa + N;                                  // [2] broadcast: proposal, accept flag
   double* pcur = bc + 2;                                // [N] the row's current P[k, .] (thread 0 keeps it): for nzP at the end
-  double* lgc = pcur + N + tid;                         // REG && MHSTEP: [MH_CPL][MHP_T] this step's candidate logarithms
+  double* prq = pcur + N;                               // [N][PRE_W] the factors' DrawPre
+  double* anz = prq + PRE_W * N;                        // [2][N] A[n] and the all(E[n,] == 0) flags: read from LDS inside the chain, not by scalar loads
+  double* lgc = anz + 2 * N + tid;                          // REG && MHSTEP: [MH_CPL][MHP_T] this step's candidate logarithms
   double* row = mhrow + (size_t)k * G;
   double* lrow = mhlog + (size_t)k * G;                 // !REG: log(max(Mhat, 1e-6)) of the row; candidates at lrow + K G
   double* lcand = lrow + (size_t)K * G;
   const double LOG1 = dlog(1.0);
   const int32_t* Mk = d.Mt + (size_t)G * k;             // M[k, g] at Mt[g + G k]
-  for (int j = tid; j < N; j += MHP_T) { const double pj = d.P[k + (size_t)K * j]; pa[j] = pj * d.A[j]; pcur[j] = pj; }
-  __syncthreads();
+  for (int j = tid; j < N; j += MHP_T) {
+    const double pj = d.P[k + (size_t)K * j]; pa[j] = pj * d.A[j]; pcur[j] = pj;
+    anz[j] = d.A[j]; anz[N + j] = nzE[j] == 0 ? 1.0 : 0.0;
+  }
+  // one factor per WAVE (lane 0): sixteen factors at a time beside each other, not one lane's worth of divergent code per wave
+  for (int j = wave; j < N; j += MHP_W) if (lane == 0) pre_store(prq + PRE_W * j, draw_pre<0>(d, k + K * j, t, MHSTEP));
+  wg_lds_barrier();
   double mh[REG ? MH_CPL : 1], enr[REG ? MH_CPL : 1], enx[REG ? MH_CPL : 1], sgr[(REG && NORMAL) ? MH_CPL : 1];
   double lg[(REG && MHSTEP) ? MH_CPL : 1];              // log(max(Mhat, 1e-6)) of the lane's cells
   int mr[REG ? MH_CPL : 1];
@@ -148,7 +191,7 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
   }
   for (int n = 0; n < N; ++n) {
     const int e = k + K * n;
-    const double a_n = d.A[n];
+    const double a_n = anz[n];
     if (REG) {
 #pragma unroll
       for (int i = 0; i < MH_CPL; ++i) enr[i] = enx[i];
@@ -158,7 +201,7 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
       }
     }
     if (a_n == 0.0) { if (tid == 0) { const double x = prior_draw<0>(d, e, t); d.P[e] = x; pcur[n] = x; } continue; }          // sample_Pn :12
-    const bool allzero = nzE[n] == 0;
+    const bool allzero = anz[N + n] != 0.0;
     const double pold = pa[n];                                                             // P[k,n] * A[n]
     const double* En = d.Et + (size_t)G * n;
     if (!allzero) {
@@ -198,13 +241,13 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
         }
       }
     }
-    __syncthreads();
+    wg_lds_barrier();
     if (tid == 0) {
       double num1 = 0.0, den = 0.0;
       if (!allzero) for (int s = 0; s < S; ++s) { num1 = num1 + part[s]; den = den + part[S + s]; }
-      bc[0] = mh_prior_or_cond<0>(d, e, t, allzero, num1, den);
+      bc[0] = mh_prior_or_cond_pre<0>(d, e, t, allzero, num1, den, pre_load(prq + PRE_W * n));
     }
-    __syncthreads();
+    wg_lds_barrier();
     const double pr = bc[0];
     const double pnew = pr * a_n;
     bool take = true;
@@ -244,17 +287,16 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
           if (lane == 0) { part[s] = a0; part[S + s] = a1; part[2 * S + s] = a2; part[3 * S + s] = a3; }
         }
       }
-      __syncthreads();
+      wg_lds_barrier();
       if (tid == 0) {
         double A_ = 0.0, B_ = 0.0, C_ = 0.0, D_ = 0.0;
         for (int s = 0; s < S; ++s) { A_ = A_ + part[s]; B_ = B_ + part[S + s]; C_ = C_ + part[2 * S + s]; D_ = D_ + part[3 * S + s]; }
         double ratio = dexp((A_ + B_) - (C_ + D_));
         if (ratio > 1.0) ratio = 1.0;                                                      // pmin(accept_ratio, 1) :239
         accP[e] = ratio;
-        Stream su(d.k0, d.k1, BNMF_V_MHU_P, (uint32_t)e, t);
-        bc[1] = (runif(su) < ratio) ? 1.0 : 0.0;
+        bc[1] = (prq[PRE_W * n + 5] < ratio) ? 1.0 : 0.0;                                    // runif of stream (MHU_P, e, t)
       }
-      __syncthreads();
+      wg_lds_barrier();
       take = bc[1] != 0.0;
     } else if (tid == 0 && accP) accP[e] = 1.0;                                            // :201-204
     if (take) {
@@ -269,7 +311,7 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
       }
       if (tid == 0) { d.P[e] = pr; pa[n] = pnew; pcur[n] = pr; }
     }
-    __syncthreads();                                      // part / bc are reused by the next factor
+    wg_lds_barrier();                                      // part / bc are reused by the next factor
   }
   // nzP[n] = number of non-zero entries of column n of P after the sweep (all(P[,n] == 0) test of sample_En_normal :56);
   // zeroed by k_mh_tail of the previous iteration (or the host before the first one)
@@ -460,7 +502,8 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol16(Dev d, uint32_t t, const in
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane % GW, grp = lane / GW;
   const int K = d.K, G = d.G, N = d.N;
-  double* ec = (double*)smem + (size_t)(wave * CPW + grp) * N;   // [N] current column of E, one per group
+  double* ec = (double*)smem + (size_t)(wave * CPW + grp) * N * (1 + PRE_W);   // [N] current column of E, one per group
+  double* prq = ec + N;                                       // [N][PRE_W] the column's DrawPre
   const double LOG1 = dlog(1.0);
   const bool normal = d.likelihood == BNMF_NORMAL;
   const int ngrp = (G + CPW - 1) / CPW;                       // sets of CPW columns
@@ -469,6 +512,7 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol16(Dev d, uint32_t t, const in
     const bool live = g < G;                                  // a row beyond G works on column G - 1 and writes nothing
     const int gc = live ? g : G - 1;
     for (int i = j; i < N; i += GW) ec[i] = d.E[i + (size_t)N * gc];
+    if (!METRICS_ONLY) for (int i = j; i < N; i += GW) pre_store(prq + PRE_W * i, draw_pre<1>(d, i + N * gc, t, MHSTEP));   // one factor per lane
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     double sg_col = normal ? d.sigmasq[gc] : 1.0;
@@ -516,7 +560,7 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol16(Dev d, uint32_t t, const in
           }
           s1 = grp_bcast0<GW>(grp_tree<GW>(a1), lane); s2 = grp_bcast0<GW>(grp_tree<GW>(a2), lane);
         }
-        const double pr = mh_prior_or_cond<1>(d, e, t, allzero, s1, s2);
+        const double pr = mh_prior_or_cond_pre<1>(d, e, t, allzero, s1, s2, pre_load(prq + PRE_W * n));
         bool take = true;
         if (MHSTEP) {
           double tA[NS] = {}, tB[NS] = {}, tC[NS] = {}, tD[NS] = {};
@@ -537,8 +581,7 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol16(Dev d, uint32_t t, const in
           double ratio = dexp((A_ + B_) - (C_ + D_));
           if (ratio > 1.0) ratio = 1.0;
           if (j == 0 && live) accE[e] = ratio;
-          Stream su(d.k0, d.k1, BNMF_V_MHU_E, (uint32_t)e, t);
-          take = runif(su) < ratio;
+          take = prq[PRE_W * n + 5] < ratio;                                               // runif of stream (MHU_E, e, t)
         } else if (j == 0 && live && accE) accE[e] = 1.0;
         if (take) {
 #pragma unroll
