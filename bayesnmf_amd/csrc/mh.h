@@ -311,8 +311,10 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
       }
       if (tid == 0) { d.P[e] = pr; pa[n] = pnew; pcur[n] = pr; }
     }
-    wg_lds_barrier();                                      // part / bc are reused by the next factor
+    // no barrier here: the next factor's writers of `part` / `bc` are behind barriers that every wave reaches only after it has read
+    // this factor's values (tid 0 reads `part` before the barrier that publishes bc; bc is rewritten only behind the next one)
   }
+  wg_lds_barrier();                                        // pcur is complete
   // nzP[n] = number of non-zero entries of column n of P after the sweep (all(P[,n] == 0) test of sample_En_normal :56);
   // zeroed by k_mh_tail of the previous iteration (or the host before the first one)
   for (int j = tid; j < N; j += MHP_T) if (pcur[j] != 0.0) atomicAdd(&nzP[j], 1);
