@@ -43,6 +43,19 @@ def z_bytes(K, G, N, save_Z):
     return b
 
 
+def pmc_valu_busy(save_Z):
+    """Fraction of the SIMDs' cycles the hot kernel's VALU pipe is busy, from the committed SQ counters (rocprofv3 --pmc,
+    tools/pmc_r3.sh): SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / SQ_WAVES x SIMDs) — both count quad-cycles, and the kernel's waves
+    are persistent (one set per launch), so WAVE_CYCLES / WAVES is the launch's length.  None if absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_counters.json")))["p3"]
+        key = next(k.split(":")[0] for k in d if k.startswith("k_zalloc_reg<true" if save_Z else "k_zalloc_sort") and k.endswith(":SQ_WAVES"))
+        waves, wc, act = (d[f"{key}:{c}"]["mean"] for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU"))
+        return act / (wc / waves * 1024.0) if not save_Z else None      # the save_Z kernel's waves are not persistent
+    except Exception:
+        return None
+
+
 def pmc_traffic(save_Z):
     """HBM bytes per k_zalloc launch from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
     rocprofv3 --pmc passes by tools/pmc2.sh, gfx950-corrected; committed under profiles/).  None if absent."""
@@ -84,6 +97,7 @@ def roofline_of(chain, K, G, N, save_Z, total_counts, n_iter, kernel=None, devic
                   # the bound that actually binds in stats mode: one Philox word per allocated count
                   "alu": {"achieved_philox_words_per_s": draws, "peak_philox_words_per_s": philox_peak,
                           "frac": draws / philox_peak if philox_peak > 0 else None,
+                          "valu_busy_frac": pmc_valu_busy(save_Z),
                           "note": "peak = Philox4x32-7 (the generator of the count-allocation words) alone at 8 waves/SIMD, measured on this box (bnmf_ubench); the kernel also "
                                   "searches 19 thresholds and updates two tables per word"},
                   "note": "stats mode moves 6.3 MB per 40 M categorical draws: the kernel is VALU/Philox-bound, not HBM-bound (DESIGN.md 5)"
