@@ -267,3 +267,19 @@ def test_maintained_mhat_agrees_with_recomputing_it_as_the_reference_does(oracle
     fin = np.isfinite(m0) & np.isfinite(m1)
     assert np.array_equal(np.isfinite(m0), np.isfinite(m1))
     assert np.max(np.abs(m0[fin] - m1[fin]) / np.maximum(np.abs(m0[fin]), 1e-9)) < 1e-9
+
+
+def test_qnorm_polynomial_is_the_committed_fit():
+    """The 25 coefficients of the normal quantile's central polynomial in oracle/orc_math.h and csrc/dmath.h are what
+    tools/fit_qnorm.py produces (Chebyshev interpolation of sqrt(2) erfinv(y) / y at 60 digits): the same literals in both files."""
+    import importlib.util, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fit_qnorm", os.path.join(root, "tools", "fit_qnorm.py"))
+    fit = importlib.util.module_from_spec(spec); spec.loader.exec_module(fit)
+    want = [repr(c) for c in fit.coef]
+    for rel in ("oracle/orc_math.h", "bayesnmf_amd/csrc/dmath.h"):
+        src = open(os.path.join(root, rel)).read()
+        body = src[src.index("const double s = w - 3.125;"):]
+        body = body[:body.index("return y * a;")]
+        got = re.findall(r"double a = ([-0-9.e]+);", body) + re.findall(r"a = a \* s \+ ([-0-9.e]+);", body)
+        assert got == want[::-1], rel

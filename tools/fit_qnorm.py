@@ -32,18 +32,20 @@ for j in range(n):
     for i, x in enumerate(T[j]):
         mono[i] += c[j] * x
 coef = [float(mono[i] / (W / 2) ** i) for i in range(n)]      # ascending powers of s = w - 3.125
-for x in coef:
-    print(repr(x))
+if __name__ == "__main__":
+    for x in coef:
+        print(repr(x))
 
-rng = np.random.default_rng(1)
-p = np.concatenate([rng.random(200000), 0.5 + np.linspace(-0.4995, 0.4995, 20001), 0.5 + 10.0 ** rng.uniform(-17, -1, 20000)])
-y = 2 * (p - 0.5)
-w = -np.log((1 - y) * (1 + y))
-m = w < 6.25
-s = w - 3.125
-acc = np.full_like(s, coef[-1])
-for x in coef[-2::-1]:
-    acc = acc * s + x
-res = y * acc
-err = [float(abs(mp.mpf(float(res[i])) / (mp.sqrt(2) * mp.erfinv(mp.mpf(float(y[i])))) - 1)) for i in np.where(m & (y != 0))[0][::7]]
-print(f"central fraction {m.mean():.5f}; max relative error {max(err):.3g} over {len(err)} points")
+if __name__ == "__main__":
+    rng = np.random.default_rng(1)
+    p = np.concatenate([rng.random(200000), 0.5 + np.linspace(-0.4995, 0.4995, 20001), 0.5 + 10.0 ** rng.uniform(-17, -1, 20000)])
+    y = 2 * (p - 0.5)
+    w = -np.log((1 - y) * (1 + y))
+    m = w < 6.25
+    s = w - 3.125
+    acc = np.full_like(s, coef[-1])
+    for x in coef[-2::-1]:
+        acc = acc * s + x
+    res = y * acc
+    err = [float(abs(mp.mpf(float(res[i])) / (mp.sqrt(2) * mp.erfinv(mp.mpf(float(y[i])))) - 1)) for i in np.where(m & (y != 0))[0][::7]]
+    print(f"central fraction {m.mean():.5f}; max relative error {max(err):.3g} over {len(err)} points")
