@@ -1159,12 +1159,12 @@ static int sweep_mh(bnmf_handle* h, int row, int converged, Timer& tm) {
   return 0;
 }
 // Merged draw kernel + gate at the end of the allocation kernel (k_draw, zalloc_reg.h): pays when the allocation kernel is long
-// enough to cover the hyper sweep that its last lane waits for — 125.4 -> 121.3 us per iteration at K = 96, G = 10,000, even at G = 7,000, but
-// 54.5 -> 57.9 us at G = 2,000, where the hyper sweep outlasts the kernel and the gate puts it on the main stream's path.
+// enough to cover the side streams' kernels that its last lane waits for: 107 -> 92.5 us per iteration at K = 96, G = 10,000, 59.4 -> 52.7 at
+// G = 3,000, but 45.2 -> 51.1 us at G = 2,000, where they outlast the kernel and the gate puts them on the main stream's path.
 // BNMF_GATE=0 / 1 forces it off / on (diagnostics).
 static bool gate_enabled(const bnmf_handle* h) {
   if (h->gate_forced >= 0) return h->gate_forced != 0;
-  return (size_t)h->cfg.K * h->cfg.G >= 750000;   // tools/gatesize.py: break-even at K = 96, G = 7,000
+  return (size_t)h->cfg.K * h->cfg.G >= 250000;   // tools/gatesize.py, round 3: 45.2 / 51.1 us at K = 96, G = 2,000; 59.4 / 52.7 at G = 3,000; 107 / 92.5 at G = 10,000
 }
 static int sweep(bnmf_handle* h, int row, Timer& tm) {
   h->iter += 1;
