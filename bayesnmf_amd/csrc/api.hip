@@ -17,6 +17,7 @@
 #include "zalloc_reg.h"
 #include "zalloc_sort.h"
 #include "zalloc_tile.h"
+#include "zalloc_step.h"
 #include "rank.h"
 #include "mh.h"
 
@@ -44,6 +45,7 @@ struct bnmf_handle {
   bool side_valid = false;             // k_side of iteration iter+1 has been issued
   int gate_forced = -1;                // BNMF_GATE at bnmf_create: 0 / 1 forces the merged draw kernel off / on, else by size
   int draw_bw = 0;                     // lanes per workgroup of the merged draw kernel (chosen at the first launch)
+  int dbg_side_delay_us = 0;           // BNMF_DEBUG_SIDE_DELAY_US (tests): a delay kernel in front of the P-side hyper sweep of launch_side_merged
   int gate_f0 = 1;                     // flag the gate waits for beside [3]: [1] E-side sweep (k_side), [9] P-side sweep on its own stream (merged draw path)
   uint32_t z_gate_next = 0;            // != 0: the allocation kernel being launched waits at its end for the hyper sweep of this iteration
   uint32_t z_gated_for = 0;            // the last allocation kernel gated for this iteration's hyper sweep (merged draw kernel, BNMF_GATE)
@@ -76,6 +78,9 @@ struct bnmf_handle {
   // k_zalloc_sort (zalloc_sort.h): stats mode, N <= 24 — the static schedule built from M at bnmf_create
   bool z_sort = false, zs_pk = false; ZSGeom zsg{}; int zs_nblk = 0, zs_w = 0; size_t zs_lds = 0; int32_t* dZsM = nullptr;
   uint32_t* dZsItems = nullptr; ZSBlock* dZsBlocks = nullptr; int* dZsCols = nullptr; unsigned long long* dZsProf = nullptr;
+  // k_zalloc_step (zalloc_step.h): stats mode, 25 <= N <= 100, any K — the static schedule built from M at bnmf_create
+  bool z_step = false; ZPGeom zpg{}; int zp_ns = 0, zp_gbp = 0; size_t zp_lds = 0;
+  uint32_t* dZpItems = nullptr; ZPWg* dZpWgs = nullptr; ZPBatch* dZpBatches = nullptr; ZPStep* dZpSteps = nullptr; int* dZpCols = nullptr;
   hipEvent_t ev[2 * BNMF_NKERNEL]{};
   bool have_ev = false;
   double* dMap = nullptr; size_t map_words = 0;   // scratch of bnmf_map (grown on demand)
@@ -323,6 +328,109 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   return 0;
 }
 
+// Static schedule of k_zalloc_step (zalloc_step.h): columns dealt to the workgroups by total count (largest first, to the
+// lightest workgroup that still has room), a workgroup's columns cut into batches of <= GBP, a batch's rows into chunks of
+// 32; the cells of a step (chunk x batch) as items — zero-count cells too: their Mhat feeds the metric terms — sorted by
+// their number of quads (counting sort), 64 per task.  M is fixed for the life of the handle, so this runs once.
+static int build_zstep(bnmf_handle* h, const int32_t* M, int n_cu) {
+  const bnmf_config& c = h->cfg;
+  const size_t K = c.K, G = c.G, N = c.N;
+  h->z_step = false;
+  if (c.save_Z || N <= (size_t)ZNMAX || N > (size_t)ZP_NMAX) return 0;
+  if (const char* e = getenv("BNMF_ZSTEP")) if (atoi(e) == 0) return 0;            // diagnostics / tests: the tile kernel
+  const int NS = (int)((N + 24) / 25), L = NS <= 2 ? 2 : 4;
+  size_t budget = 156 * 1024;                                                      // of 160: the side streams' workgroups keep room on the CU
+  int GBP = 0;
+  for (int gbp : {40, 32}) if (zstep_shared_bytes(NS, (int)N, gbp) + ZP_W * zstep_wave_bytes(NS, L, (int)N) <= budget) { GBP = gbp; break; }
+  if (const char* e = getenv("BNMF_ZPGB")) { const int v = atoi(e); if (v == 32 || v == 40) GBP = v; }   // diagnostics / tests
+  if (!GBP) return 0;
+  const int nch = (int)((K + ZP_KC - 1) / ZP_KC);
+  const long nwg = std::min<long>((long)G, n_cu);
+  // columns -> workgroups
+  std::vector<long> ctot(G, 0);
+  for (size_t g = 0; g < G; ++g) { long sacc = 0; for (size_t k = 0; k < K; ++k) sacc += M[k + K * g]; ctot[g] = sacc; }
+  std::vector<int> order(G);
+  for (size_t g = 0; g < G; ++g) order[g] = (int)g;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ctot[a] > ctot[b]; });
+  const size_t cap = (G + nwg - 1) / nwg + 2;                                      // the threshold work of a column does not depend on its counts
+  std::vector<std::vector<int>> wcols(nwg);
+  {
+    std::vector<std::pair<long, int>> heap;
+    for (int b = 0; b < nwg; ++b) heap.push_back({0L, b});
+    auto cmp = [](const std::pair<long, int>& a, const std::pair<long, int>& b) { return a > b; };
+    std::make_heap(heap.begin(), heap.end(), cmp);
+    for (int g : order) {
+      std::pop_heap(heap.begin(), heap.end(), cmp);
+      auto top = heap.back(); heap.pop_back();
+      wcols[top.second].push_back(g);
+      top.first += ctot[g] + 64 * (long)K;                                         // + the cells' fixed cost (Mhat, thresholds), in counts
+      if (wcols[top.second].size() < cap) { heap.push_back(top); std::push_heap(heap.begin(), heap.end(), cmp); }
+    }
+  }
+  std::vector<ZPWg> wgs(nwg);
+  std::vector<ZPBatch> batches;
+  std::vector<int> cols;
+  for (int b = 0; b < nwg; ++b) {
+    std::sort(wcols[b].begin(), wcols[b].end());
+    const int nc = (int)wcols[b].size(), nb = (nc + GBP - 1) / GBP;
+    wgs[b] = ZPWg{(int)batches.size(), nb};
+    for (int i = 0; i < nb; ++i) {
+      const int c0 = (int)((long)nc * i / nb), c1 = (int)((long)nc * (i + 1) / nb);
+      batches.push_back(ZPBatch{(int)cols.size(), c1 - c0});
+      for (int x = c0; x < c1; ++x) cols.push_back(wcols[b][x]);
+    }
+  }
+  std::vector<ZPStep> steps(batches.size() * (size_t)nch);
+  std::vector<uint32_t> items;
+  items.reserve((size_t)((double)K * (double)G * 1.05) + 64 * steps.size());
+  std::vector<uint32_t> bucket[ZP_QMAX + 1];
+  for (size_t bi = 0; bi < batches.size(); ++bi) {
+    const ZPBatch& bt = batches[bi];
+    for (int ch = 0; ch < nch; ++ch) {
+      const size_t k0 = (size_t)ch * ZP_KC, kc = std::min<size_t>(ZP_KC, K - k0);
+      for (auto& v : bucket) v.clear();
+      for (int gl = 0; gl < bt.ncols; ++gl) {
+        const size_t g = (size_t)cols[bt.col0 + gl];
+        for (size_t kl = 0; kl < kc; ++kl) {
+          const int m = M[k0 + kl + K * g];
+          const int qt = m > 0 ? (m + 3) >> 2 : 0;
+          const uint32_t base = (uint32_t)kl | ((uint32_t)gl << 5);
+          if (qt == 0) { bucket[0].push_back(base); continue; }
+          for (int f = 0; f * ZP_QMAX < qt; ++f) {
+            if (f >= (1 << 21)) return fail(BNMF_EINVAL, "bnmf_create: a cell of M holds %d counts: unsupported", m);
+            bucket[std::min(ZP_QMAX, qt - f * ZP_QMAX)].push_back(base | ((uint32_t)f << 11));
+          }
+        }
+      }
+      ZPStep& st = steps[bi * (size_t)nch + ch];
+      st.item0 = (long long)items.size(); st.pad = 0;
+      for (int qn = ZP_QMAX; qn >= 0; --qn) items.insert(items.end(), bucket[qn].begin(), bucket[qn].end());
+      while ((items.size() - (size_t)st.item0) % 64) items.push_back(0xFFFFFFFFu);
+      st.ntask = (int)((items.size() - (size_t)st.item0) / 64);
+    }
+  }
+  if (items.empty()) items.push_back(0xFFFFFFFFu);
+  HIPCHK(hipMalloc(&h->dZpItems, items.size() * sizeof(uint32_t)));
+  HIPCHK(hipMemcpy(h->dZpItems, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&h->dZpWgs, wgs.size() * sizeof(ZPWg)));
+  HIPCHK(hipMemcpy(h->dZpWgs, wgs.data(), wgs.size() * sizeof(ZPWg), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&h->dZpBatches, batches.size() * sizeof(ZPBatch)));
+  HIPCHK(hipMemcpy(h->dZpBatches, batches.data(), batches.size() * sizeof(ZPBatch), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&h->dZpSteps, steps.size() * sizeof(ZPStep)));
+  HIPCHK(hipMemcpy(h->dZpSteps, steps.data(), steps.size() * sizeof(ZPStep), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&h->dZpCols, cols.size() * sizeof(int)));
+  HIPCHK(hipMemcpy(h->dZpCols, cols.data(), cols.size() * sizeof(int), hipMemcpyHostToDevice));
+  h->zpg = ZPGeom{nch, (int)nwg, nullptr};
+#ifdef ZPPROF
+  HIPCHK(hipMalloc(&h->zpg.prof, 8 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(h->zpg.prof, 0, 8 * sizeof(unsigned long long)));
+#endif
+  h->zp_ns = NS; h->zp_gbp = GBP;
+  h->zp_lds = (zstep_shared_bytes(NS, (int)N, GBP) + ZP_W * zstep_wave_bytes(NS, L, (int)N) + 15) & ~(size_t)15;
+  h->z_step = true;
+  return 0;
+}
+
 static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h) {
   const size_t K = cfg->K, G = cfg->G, N = cfg->N;
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -346,6 +454,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   HIPCHK(hipMemset(h->dZsumG, 0, K * N * sizeof(int32_t)));
   if (cfg->save_Z) HIPCHK(hipMalloc(&h->dZ, K * N * G * sizeof(int32_t)));
   if (const char* e = getenv("BNMF_GATE")) h->gate_forced = atoi(e) != 0 ? 1 : 0;   // diagnostics / tests
+  if (const char* e = getenv("BNMF_DEBUG_SIDE_DELAY_US")) h->dbg_side_delay_us = std::max(0, std::min(20000, atoi(e)));   // tests only
   {
     // A lane that polls inside a main-stream kernel for a side-stream kernel deadlocks (until its bound) when dispatches cannot
     // overlap: the waited-for kernel only starts once the waiting one has ended.  Where the process is known to serialise its
@@ -506,8 +615,10 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
     const long want = ((long)G + best_w - 1) / best_w;
     h->z_grid = (int)(want < resident ? want : resident);
     if (const char* e = getenv("BNMF_ZGRID")) h->z_grid = atoi(e);          // diagnostics only
+    // N > 24, stats mode: the statically scheduled lane-per-item kernel (zalloc_step.h), where its LDS layout fits
+    if (!h->z_reg) if (int rc = build_zstep(h, M, prop.multiProcessorCount)) return rc;
     // N > 24 (or K too large for the register kernel): the tile kernel, when at least two waves per CU fit
-    if (!h->z_reg) {
+    if (!h->z_reg && !h->z_step) {
       bool want_tile = true;
       if (const char* e = getenv("BNMF_ZTILE")) want_tile = atoi(e) != 0;   // diagnostics / tests: 0 = k_zalloc
       ZTGeom& tg = h->ztg;
@@ -553,7 +664,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
       }
     }
     if (const char* e = getenv("BNMF_ABLATE")) h->z_ablate = atoi(e);       // diagnostics only
-    if (!h->z_tile && !h->z_ablate) if (int rc = build_zsort(h, M, prop.multiProcessorCount)) return rc;
+    if (!h->z_tile && !h->z_step && !h->z_ablate) if (int rc = build_zsort(h, M, prop.multiProcessorCount)) return rc;
   }
   HIPCHK(hipStreamSynchronize(h->stream));
   refresh_dev(h);
@@ -572,6 +683,8 @@ int bnmf_destroy(bnmf_handle* h) {
   hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); if (h->hMetrics) hipHostFree(h->hMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol); if (h->dRankMhat) hipFree(h->dRankMhat); if (h->dRankSync) hipFree(h->dRankSync);
   if (h->E_alt) hipFree(h->E_alt);
   if (h->dMhatZ) hipFree(h->dMhatZ);
+  if (h->zpg.prof) hipFree(h->zpg.prof);
+  if (h->dZpItems) hipFree(h->dZpItems); if (h->dZpWgs) hipFree(h->dZpWgs); if (h->dZpBatches) hipFree(h->dZpBatches); if (h->dZpSteps) hipFree(h->dZpSteps); if (h->dZpCols) hipFree(h->dZpCols);
   if (h->dZsItems) hipFree(h->dZsItems); if (h->dZsBlocks) hipFree(h->dZsBlocks); if (h->dZsCols) hipFree(h->dZsCols); if (h->dZsProf) hipFree(h->dZsProf); if (h->dZsM) hipFree(h->dZsM);
   if (h->dMhat) hipFree(h->dMhat); if (h->dAccPn) hipFree(h->dAccPn); if (h->dAccEpart) hipFree(h->dAccEpart); if (h->dNzE) hipFree(h->dNzE);
   if (h->dEt) hipFree(h->dEt); if (h->dMt) hipFree(h->dMt); if (h->zring) hipFree(h->zring);
@@ -673,11 +786,12 @@ int bnmf_debug_rank(bnmf_handle* h, unsigned long long* out, size_t n) {   // di
   HIPCHK(hipMemcpy(out, h->dRankDbg, n * 8, hipMemcpyDeviceToHost));
   return h->rank_grid;
 }
-int bnmf_debug_zsort(bnmf_handle* h, unsigned long long* out) {   // diagnostics (-DZSPROF builds): section ticks of k_zalloc_sort, then reset
-  if (!h || !h->dZsProf) return fail(BNMF_ESTATE, "not a -DZSPROF build / kernel not in use");
+int bnmf_debug_zsort(bnmf_handle* h, unsigned long long* out) {   // diagnostics (-DZSPROF / -DZPPROF builds): section ticks of k_zalloc_sort / k_zalloc_step, then reset
+  unsigned long long* src = h ? (h->dZsProf ? h->dZsProf : h->zpg.prof) : nullptr;
+  if (!src) return fail(BNMF_ESTATE, "not a -DZSPROF / -DZPPROF build, or the kernel is not in use");
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipMemcpy(out, h->dZsProf, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemset(h->dZsProf, 0, 8 * sizeof(unsigned long long)));
+  HIPCHK(hipMemcpy(out, src, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(src, 0, 8 * sizeof(unsigned long long)));
   return 0;
 }
 #ifdef ZSPROF
@@ -844,6 +958,7 @@ static void launch_side_merged(bnmf_handle* h, uint32_t t, Timer& tm) {
   const int N = h->cfg.N;
   const int nbP = (int)(((size_t)h->cfg.K * N + RT - 1) / RT);
   hipStreamWaitEvent(h->side, h->ev_draw, 0);
+  if (h->dbg_side_delay_us) hipLaunchKernelGGL(k_debug_delay, dim3(1), dim3(64), 0, h->side, h->dbg_side_delay_us);   // tests: a late P-side sweep
   hipLaunchKernelGGL(k_side, dim3(nbP), dim3(RT), 0, h->side, h->dev, t, nbP, N, rec_at(h, t, fused_rec(h)), SideDone{h->dFlags + 8, h->dFlags + 9, (unsigned)nbP, t});
   hipStreamWaitEvent(h->side2, h->ev_draw, 0);
   if (h->red_issued && !h->red_on_side2) hipStreamWaitEvent(h->side2, h->ev_red, 0);   // lpPn slot reuse, see launch_side_P
@@ -971,8 +1086,30 @@ static int launch_zsort(bnmf_handle* h, uint32_t t) {
     default: return launch_zsort_t<256>(h, t);
   }
 }
+static int launch_zstep(bnmf_handle* h, uint32_t t) {
+  const ZPArgs pa{zargs(h), h->dZpItems, h->dZpWgs, h->dZpBatches, h->dZpSteps, h->dZpCols};
+  auto go = [&](auto kern) -> int {
+    if (h->z_attr_kernel != (const void*)kern) {
+      HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      h->z_attr_kernel = (const void*)kern;
+    }
+    hipLaunchKernelGGL(kern, dim3(h->zpg.nwg), dim3(ZP_T), h->zp_lds, h->stream, pa, t, h->zpg);
+    return 0;
+  };
+  if (h->zp_gbp == 40) switch (h->zp_ns) {
+    case 2: return go(k_zalloc_step<2, 2, 40>);
+    case 3: return go(k_zalloc_step<3, 4, 40>);
+    default: return go(k_zalloc_step<4, 4, 40>);
+  }
+  switch (h->zp_ns) {
+    case 2: return go(k_zalloc_step<2, 2, 32>);
+    case 3: return go(k_zalloc_step<3, 4, 32>);
+    default: return go(k_zalloc_step<4, 4, 32>);
+  }
+}
 static int launch_zalloc(bnmf_handle* h, uint32_t t) {
   if (h->z_sort) return launch_zsort(h, t);
+  if (h->z_step) return launch_zstep(h, t);
   const bool sz = h->cfg.save_Z != 0;
   switch (h->z_zw) {
     case 16: return sz ? launch_zalloc_t<true, 1024>(h, t) : launch_zalloc_t<false, 1024>(h, t);
@@ -1212,6 +1349,11 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
                           rec_at(h, t + 1, rec), SideDone{h->dFlags, h->dFlags + 1, nE, t + 1});
     launch_side_merged(h, t + 1, tm);
   } else {
+    // The side work of this iteration may have been issued by launch_side_merged (the sweep before took the merged path without
+    // arming the allocation kernel's gate: first sweep after init / set_array).  Its P-side sweep then runs on `side` under flag
+    // [9], which k_pdraw does not poll ([1] was raised by k_draw, [3] covers side2 only): the main stream waits for it here, and
+    // with it launch_side_P below (released by k_pdraw's stop event) cannot overwrite the slot that sweep still reads.
+    if (poll && h->gate_f0 == 9) { hipEventRecord(h->ev_side, h->side); hipStreamWaitEvent(h->stream, h->ev_side, 0); }
     // completion events ride on the dispatches themselves (stop events): no marker packets on the main stream
     hipExtLaunchKernelGGL(k_pdraw, dim3(h->cfg.N), dim3(PD_T), (uint32_t)(2 * (size_t)h->cfg.K * sizeof(double)), h->stream,
                           nullptr, h->ev_p, 0, h->dev, t, 0, 0, rec_pdraw(h, t, rec),

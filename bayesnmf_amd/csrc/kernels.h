@@ -905,6 +905,11 @@ __global__ void k_luts(double* lgfact, double* logm, int maxM) {
 }
 
 // ---- probes for the parity tests ----
+// holds its stream for about `us` microseconds (s_memrealtime ticks at 100 MHz): lets a test make a side-stream kernel late
+__global__ void k_debug_delay(int us) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(32);
+}
 __global__ void k_test_math(int fn, const double* in, double* out, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

@@ -301,20 +301,27 @@ def test_register_kernel_threshold_row_boundaries(N):
         e.close()
 
 
-@pytest.mark.parametrize("kernel", ["tile", "wave"])
+@pytest.mark.parametrize("kernel", ["step", "step32", "tile", "wave"])
 @pytest.mark.parametrize("shape,force", [((200, 9, 30), True), ((33, 17, 26), True), ((130, 12, 40), True),
                                          ((1536, 12, 100), False), ((96, 300, 50), False), ((70, 40, 128), False),
-                                         ((45, 23, 140), False)])
+                                         ((45, 23, 140), False), ((50, 45, 75), False), ((77, 30, 76), False), ((31, 300, 25), False)])
 def test_general_allocation_kernels(shape, force, kernel, monkeypatch):
-    """N > 24 (BASELINE configs 4 and 5: N = 50, K = 96; N = 100, K = 1,536).  "tile": k_zalloc_tile, the default
-    (workgroup per 32-row chunk, P chunk in LDS, ZsumK accumulated across the chunks, metrics from the Mhat it writes).
-    "wave": k_zalloc (BNMF_ZTILE=0), one wave per column; where the column's thresholds do not fit one wave's LDS slab
-    it walks the rows in chunks of 64 and keeps ZsumG in global memory (forced on small shapes with BNMF_ZCHUNK=1, taken
-    automatically at the config-5 row/factor counts).  Both bit-exact against the oracle."""
+    """N > 24 (BASELINE configs 4 and 5: N = 50, K = 96; N = 100, K = 1,536).  "step": k_zalloc_step, the default of the
+    stats mode for N <= 100 (static schedule, lane = item, three-level threshold table, row chunks x column batches, metric
+    accumulators in registers; "step32": its 32-column batch layout, BNMF_ZPGB=32).  "tile": k_zalloc_tile (BNMF_ZSTEP=0; the
+    default for N > 100 and with save_Z: workgroup per 32-row chunk, P chunk in LDS, ZsumK accumulated across the chunks,
+    metrics from the Mhat it writes).  "wave": k_zalloc (BNMF_ZTILE=0), one wave per column; where the column's thresholds
+    do not fit one wave's LDS slab it walks the rows in chunks of 64 and keeps ZsumG in global memory (forced on small shapes
+    with BNMF_ZCHUNK=1, taken automatically at the config-5 row/factor counts).  All bit-exact against the oracle; the
+    shapes hold empty rows and columns, a cell split over several items (2,000 counts) and ragged last chunks."""
     import oracle as O
     from bayesnmf_amd import Engine
     from bayesnmf_amd.setup import apply_hyperprior_params
     K, G, N = shape
+    if kernel == "step32":
+        monkeypatch.setenv("BNMF_ZPGB", "32")
+    if kernel in ("tile", "wave"):
+        monkeypatch.setenv("BNMF_ZSTEP", "0")
     if kernel == "wave":
         monkeypatch.setenv("BNMF_ZTILE", "0")
         if force:
@@ -323,7 +330,10 @@ def test_general_allocation_kernels(shape, force, kernel, monkeypatch):
     M = rng.poisson(rng.gamma(0.5, 12.0, size=(K, G))).astype(np.int32)
     M[:, G // 2] = 0
     M[K // 3, :] = 0
+    M[1, 1] = 2000
     for save_Z in (False, True):
+        if save_Z and kernel == "step32":
+            continue                                         # save_Z takes the tile kernel either way
         o = O.Oracle(M, N, prior="gamma", seed=9, save_Z=True, nthreads=4)
         e = Engine(M, N, prior="gamma", seed=9, save_Z=save_Z)
         apply_hyperprior_params(o, "gamma", M, N)
@@ -558,6 +568,36 @@ def test_merged_draw_kernel_bitexact(prior, window, gate, monkeypatch):
         for (po, eo), pw, ew in zip(kept, e.window("P", 3), e.window("E", 3)):
             assert np.array_equal(po.view(np.uint64), np.ascontiguousarray(pw).view(np.uint64))
             assert np.array_equal(eo.view(np.uint64), np.ascontiguousarray(ew).view(np.uint64))
+    e.close()
+
+
+def test_late_p_side_sweep_after_init_is_waited_for(monkeypatch):
+    """the first sweep after bnmf_init / bnmf_set_array takes the merged draw path without arming the
+    allocation kernel's gate and issues the next iteration's P-side hyper sweep on its own stream under flag [9]; the sweep
+    after it takes the two-kernel form, whose k_pdraw polls flags [1] and [3] only.  BNMF_DEBUG_SIDE_DELAY_US puts a delay
+    kernel in front of every such P-side sweep (3 ms: far longer than the allocation kernel that used to hide the missing
+    wait): P, E, the Z statistics and the metrics stay bit-identical to the oracle across init, runs and a set()."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    monkeypatch.setenv("BNMF_GATE", "1")
+    monkeypatch.setenv("BNMF_DEBUG_SIDE_DELAY_US", "3000")
+    M, _, _ = synth_counts(96, 700, 4, 41)
+    N = 12
+    o = O.Oracle(M, N, prior="gamma", seed=5, nthreads=8)
+    e = Engine(M, N, prior="gamma", seed=5, window=4)
+    for c in (o, e):
+        apply_hyperprior_params(c, "gamma", M, N)
+    o.init(); e.init()
+    for step, n_it in enumerate((3, 1, 4)):
+        mo, me = o.run(n_it), e.run(n_it)
+        for nm in ("P", "E", "ZsumK", "ZsumG", "Alpha_p", "Beta_p"):
+            a, b = np.ascontiguousarray(o.get(nm), dtype=np.float64), np.ascontiguousarray(e.get(nm), dtype=np.float64)
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (nm, step)
+        assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), step
+        if step == 1:                                        # a set() invalidates the pre-issued side work: the path starts over
+            P1 = o.get("P").copy()
+            o.set("P", P1); e.set("P", P1)
     e.close()
 
 
