@@ -79,7 +79,7 @@ struct bnmf_handle {
   bool z_sort = false, zs_pk = false; ZSGeom zsg{}; int zs_nblk = 0, zs_w = 0; size_t zs_lds = 0; int32_t* dZsM = nullptr;
   uint32_t* dZsItems = nullptr; ZSBlock* dZsBlocks = nullptr; int* dZsCols = nullptr; unsigned long long* dZsProf = nullptr;
   // k_zalloc_step (zalloc_step.h): stats mode, 25 <= N <= 100, any K — the static schedule built from M at bnmf_create
-  bool z_step = false; ZPGeom zpg{}; int zp_ns = 0, zp_gbp = 0; size_t zp_lds = 0;
+  bool z_step = false; ZPGeom zpg{}; int zp_ns = 0 /* waves per workgroup */, zp_gbp = 0; size_t zp_lds = 0;
   uint32_t* dZpItems = nullptr; ZPWg* dZpWgs = nullptr; ZPBatch* dZpBatches = nullptr; ZPStep* dZpSteps = nullptr; int* dZpCols = nullptr;
   hipEvent_t ev[2 * BNMF_NKERNEL]{};
   bool have_ev = false;
@@ -331,17 +331,20 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
 // Static schedule of k_zalloc_step (zalloc_step.h): columns dealt to the workgroups by total count (largest first, to the
 // lightest workgroup that still has room), a workgroup's columns cut into batches of <= GBP, a batch's rows into chunks of
 // 32; the cells of a step (chunk x batch) as items — zero-count cells too: their Mhat feeds the metric terms — sorted by
-// their number of quads (counting sort), 64 per task.  M is fixed for the life of the handle, so this runs once.
+// their number of quads (counting sort) and dealt to the workgroup's waves in snake order, 64 per task: the waves of a step
+// get the same number of items of the same sizes.  M is fixed for the life of the handle, so this runs once.
 static int build_zstep(bnmf_handle* h, const int32_t* M, int n_cu) {
   const bnmf_config& c = h->cfg;
   const size_t K = c.K, G = c.G, N = c.N;
   h->z_step = false;
   if (c.save_Z || N <= (size_t)ZNMAX || N > (size_t)ZP_NMAX) return 0;
   if (const char* e = getenv("BNMF_ZSTEP")) if (atoi(e) == 0) return 0;            // diagnostics / tests: the tile kernel
-  const int NS = (int)((N + 24) / 25), L = NS <= 2 ? 2 : 4;
+  const int L = 4;                                                                 // lanes per cell (with <= 20 included factors the search then skips a level)
   size_t budget = 156 * 1024;                                                      // of 160: the side streams' workgroups keep room on the CU
-  int GBP = 0;
-  for (int gbp : {40, 32}) if (zstep_shared_bytes(NS, (int)N, gbp) + ZP_W * zstep_wave_bytes(NS, L, (int)N) <= budget) { GBP = gbp; break; }
+  int GBP = 0, W = 0;
+  // 8 waves (two per SIMD).  12 waves fit the LDS up to N = 60 and were measured at config 4: 114.5 against 121 us per launch, but
+  // at the 168 registers three waves per SIMD leave, the kernel spills 16-36 bytes per lane — not kept
+  for (int gbp : {40, 32}) if (zstep_shared_bytes((int)N, gbp) + 8 * zstep_wave_bytes(L) <= budget) { GBP = gbp; W = 8; break; }
   if (const char* e = getenv("BNMF_ZPGB")) { const int v = atoi(e); if (v == 32 || v == 40) GBP = v; }   // diagnostics / tests
   if (!GBP) return 0;
   const int nch = (int)((K + ZP_KC - 1) / ZP_KC);
@@ -383,7 +386,7 @@ static int build_zstep(bnmf_handle* h, const int32_t* M, int n_cu) {
   std::vector<ZPStep> steps(batches.size() * (size_t)nch);
   std::vector<uint32_t> items;
   items.reserve((size_t)((double)K * (double)G * 1.05) + 64 * steps.size());
-  std::vector<uint32_t> bucket[ZP_QMAX + 1];
+  std::vector<uint32_t> bucket[ZP_QMAX + 1], wlist[ZP_WMAX], sorted;
   for (size_t bi = 0; bi < batches.size(); ++bi) {
     const ZPBatch& bt = batches[bi];
     for (int ch = 0; ch < nch; ++ch) {
@@ -402,11 +405,17 @@ static int build_zstep(bnmf_handle* h, const int32_t* M, int n_cu) {
           }
         }
       }
+      // sorted by size, then dealt to the waves in snake order: every wave gets the same number of items (+-1) of the same sizes
+      sorted.clear();
+      for (int qn = ZP_QMAX; qn >= 0; --qn) sorted.insert(sorted.end(), bucket[qn].begin(), bucket[qn].end());
+      for (int w = 0; w < W; ++w) wlist[w].clear();
+      for (size_t i = 0; i < sorted.size(); ++i) { const int r = (int)(i % (2 * (size_t)W)); wlist[r < W ? r : 2 * W - 1 - r].push_back(sorted[i]); }
+      size_t mx = 0;
+      for (int w = 0; w < W; ++w) mx = std::max(mx, wlist[w].size());
       ZPStep& st = steps[bi * (size_t)nch + ch];
       st.item0 = (long long)items.size(); st.pad = 0;
-      for (int qn = ZP_QMAX; qn >= 0; --qn) items.insert(items.end(), bucket[qn].begin(), bucket[qn].end());
-      while ((items.size() - (size_t)st.item0) % 64) items.push_back(0xFFFFFFFFu);
-      st.ntask = (int)((items.size() - (size_t)st.item0) / 64);
+      st.ntw = (int)((mx + 63) / 64);
+      for (int w = 0; w < W; ++w) { const auto& v = wlist[w]; items.insert(items.end(), v.begin(), v.end()); items.insert(items.end(), (size_t)st.ntw * 64 - v.size(), 0xFFFFFFFFu); }
     }
   }
   if (items.empty()) items.push_back(0xFFFFFFFFu);
@@ -425,8 +434,8 @@ static int build_zstep(bnmf_handle* h, const int32_t* M, int n_cu) {
   HIPCHK(hipMalloc(&h->zpg.prof, 8 * sizeof(unsigned long long)));
   HIPCHK(hipMemset(h->zpg.prof, 0, 8 * sizeof(unsigned long long)));
 #endif
-  h->zp_ns = NS; h->zp_gbp = GBP;
-  h->zp_lds = (zstep_shared_bytes(NS, (int)N, GBP) + ZP_W * zstep_wave_bytes(NS, L, (int)N) + 15) & ~(size_t)15;
+  h->zp_ns = W; h->zp_gbp = GBP;
+  h->zp_lds = (zstep_shared_bytes((int)N, GBP) + W * zstep_wave_bytes(L) + 15) & ~(size_t)15;
   h->z_step = true;
   return 0;
 }
@@ -1093,19 +1102,10 @@ static int launch_zstep(bnmf_handle* h, uint32_t t) {
       HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       h->z_attr_kernel = (const void*)kern;
     }
-    hipLaunchKernelGGL(kern, dim3(h->zpg.nwg), dim3(ZP_T), h->zp_lds, h->stream, pa, t, h->zpg);
+    hipLaunchKernelGGL(kern, dim3(h->zpg.nwg), dim3(h->zp_ns * 64), h->zp_lds, h->stream, pa, t, h->zpg);
     return 0;
   };
-  if (h->zp_gbp == 40) switch (h->zp_ns) {
-    case 2: return go(k_zalloc_step<2, 2, 40>);
-    case 3: return go(k_zalloc_step<3, 4, 40>);
-    default: return go(k_zalloc_step<4, 4, 40>);
-  }
-  switch (h->zp_ns) {
-    case 2: return go(k_zalloc_step<2, 2, 32>);
-    case 3: return go(k_zalloc_step<3, 4, 32>);
-    default: return go(k_zalloc_step<4, 4, 32>);
-  }
+  return h->zp_gbp == 40 ? go(k_zalloc_step<4, 40, 8>) : go(k_zalloc_step<4, 32, 8>);
 }
 static int launch_zalloc(bnmf_handle* h, uint32_t t) {
   if (h->z_sort) return launch_zsort(h, t);

@@ -307,8 +307,8 @@ def test_register_kernel_threshold_row_boundaries(N):
                                          ((45, 23, 140), False), ((50, 45, 75), False), ((77, 30, 76), False), ((31, 300, 25), False)])
 def test_general_allocation_kernels(shape, force, kernel, monkeypatch):
     """N > 24 (BASELINE configs 4 and 5: N = 50, K = 96; N = 100, K = 1,536).  "step": k_zalloc_step, the default of the
-    stats mode for N <= 100 (static schedule, lane = item, three-level threshold table, row chunks x column batches, metric
-    accumulators in registers; "step32": its 32-column batch layout, BNMF_ZPGB=32).  "tile": k_zalloc_tile (BNMF_ZSTEP=0; the
+    stats mode for N <= 100 (static schedule, lane = item, included factors only, three-level threshold table, row chunks x
+    column batches, metric accumulators in registers; "step32": its 32-column batch layout, BNMF_ZPGB=32).  "tile": k_zalloc_tile (BNMF_ZSTEP=0; the
     default for N > 100 and with save_Z: workgroup per 32-row chunk, P chunk in LDS, ZsumK accumulated across the chunks,
     metrics from the Mhat it writes).  "wave": k_zalloc (BNMF_ZTILE=0), one wave per column; where the column's thresholds
     do not fit one wave's LDS slab it walks the rows in chunks of 64 and keeps ZsumG in global memory (forced on small shapes
@@ -348,6 +348,35 @@ def test_general_allocation_kernels(shape, force, kernel, monkeypatch):
         assert np.array_equal(o.get("E").view(np.uint64), e.get("E").view(np.uint64)), shape
         assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), shape
         e.close()
+
+
+@pytest.mark.parametrize("N,excluded", [(30, [0, 29]), (50, list(range(3, 50))), (100, [n for n in range(100) if n % 7]), (64, list(range(64)))])
+def test_step_kernel_walks_included_factors_only(N, excluded):
+    """k_zalloc_step stages and walks only the factors with A[n] != 0 (an excluded factor adds +0.0 to the running sum and repeats
+    the threshold before it): first and last factor excluded, all but three, six of seven, and every factor excluded (Z = 0,
+    R/sample_params.R:257-261) — ZsumK, ZsumG, P, E and the metric rows bit-exact against the oracle, which walks all N."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import apply_hyperprior_params
+    K, G = 77, 50
+    rng = np.random.default_rng(N)
+    M = rng.poisson(rng.gamma(0.5, 20.0, size=(K, G))).astype(np.int32)
+    M[5, 5] = 1500
+    A0 = np.ones((1, N)); A0[0, excluded] = 0.0
+    o = O.Oracle(M, N, prior="gamma", seed=3, nthreads=4)
+    e = Engine(M, N, prior="gamma", seed=3)
+    for c in (o, e):
+        apply_hyperprior_params(c, "gamma", M, N)
+        c.set("A", A0)
+    o.init(); e.init()
+    mo, me = o.run(4), e.run(4)
+    for nm in ("ZsumK", "ZsumG", "P", "E"):
+        a, b = np.ascontiguousarray(o.get(nm), dtype=np.float64), np.ascontiguousarray(e.get(nm), dtype=np.float64)
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), nm
+    assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64))
+    if len(excluded) == N:
+        assert not e.get("ZsumK").any()
+    e.close()
 
 
 def test_bayesNMF_end_to_end_gpu(tmp_path):

@@ -13,7 +13,7 @@ cfg = os.environ.get("CFG", "4")
 if cfg == "4":
     K, G, N, R, seed, kw = 96, 10000, 50, 12, 20250222, dict(learning_rank=True, temperature=np.ones(8000))
 else:
-    K, G, N, R, seed, kw = 1536, int(os.environ.get("G5", "10000")), 100, 30, 20250223, {}
+    K, G, N, R, seed, kw = 1536, int(os.environ.get("G5", "12800")), 100, 30, 20250223, {}
 M, _, _ = synth_counts(K, G, R, seed)
 e = E.Engine(M, N, prior="gamma", seed=1, window=0, **kw)
 apply_hyperprior_params(e, "gamma", M, N)

@@ -11,7 +11,7 @@ cfg = os.environ.get("CFG", "4")
 if cfg == "4":
     K, G, N, R, seed, iters, kw = 96, 10000, 50, 12, 20250222, 100, dict(learning_rank=True, temperature=np.ones(8000))
 else:
-    K, G, N, R, seed, iters, kw = 1536, int(os.environ.get("G5", "10000")), 100, 30, 20250223, int(os.environ.get("ITERS", "5")), {}
+    K, G, N, R, seed, iters, kw = 1536, int(os.environ.get("G5", "12800")), 100, 30, 20250223, int(os.environ.get("ITERS", "5")), {}
 M, _, _ = synth_counts(K, G, R, seed)
 for zstep in os.environ.get("ORDER", "1,0,1,0").split(","):
     os.environ["BNMF_ZSTEP"] = zstep
