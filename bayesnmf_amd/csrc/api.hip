@@ -84,6 +84,7 @@ struct bnmf_handle {
   hipEvent_t ev[2 * BNMF_NKERNEL]{};
   bool have_ev = false;
   double* dMap = nullptr; size_t map_words = 0;   // scratch of bnmf_map (grown on demand)
+  unsigned char* dAsg = nullptr; size_t asg_bytes = 0;   // scratch of bnmf_assign (grown on demand): catalogue, norms, cosines, slot / signature lists
   unsigned* dFlags = nullptr;                     // [0] counter, [1] flag of the E-side hyper sweep; [2], [3] of P part + Esum
   int* hErr = nullptr; int* dErr = nullptr;       // time-out words of the bounded in-kernel waits, in mapped host memory (read without a copy):
                                                   // [0] a draw kernel waiting for the hyper sweep, [1] the rank sweep's exchange
@@ -184,7 +185,9 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
 // lgamma / digamma table of the Alpha sampler's tangent points (dsamplers.h g_alut): filled once per device
 static int ensure_alut(int device) {
   static bool done[64] = {};
+  static std::mutex mtx;                                  // bnmf_create may be called from several host threads (one chain each)
   if (device < 0 || device >= 64) return fail(BNMF_EINVAL, "device %d out of range", device);
+  std::lock_guard<std::mutex> lock(mtx);
   if (done[device]) return 0;
   hipLaunchKernelGGL(k_alut_fill, dim3((ALUT_N + 255) / 256), dim3(256), 0, 0, 0);
   hipLaunchKernelGGL(k_alut_fill, dim3((ALUT_N + 255) / 256), dim3(256), 0, 0, 1);
@@ -233,6 +236,9 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   h->z_sort = false;
   if (c.save_Z || !h->z_reg || N > (size_t)ZS_NMAX - 1 || K > 1024) return 0;
   if (const char* e = getenv("BNMF_ZSORT")) if (atoi(e) == 0) return 0;          // diagnostics / tests: the register kernel
+  // an item word holds 16 bits of fragment index (k | gl << 10 | f << 16), and f = 65535 with k = 1023, gl = 63 is the empty-lane
+  // sentinel: a cell above 65,534 fragments of 4 ZS_QMAX counts stays with the register kernel
+  if ((long long)h->maxM > 65534LL * 4 * ZS_QMAX) return 0;
   const int nblk = (int)((N + 4) / 5);                                             // threshold blocks per cell
   const int KP = (K % 32 == 0) ? (int)K + 1 : (int)(K | 1);
   size_t budget = 156 * 1024;                                                     // of 160: the side streams' workgroups (2 KB each) keep room on the CU
@@ -700,6 +706,7 @@ int bnmf_destroy(bnmf_handle* h) {
   if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_rank) hipEventDestroy(h->ev_rank); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); if (h->side) hipStreamDestroy(h->side); if (h->side2) hipStreamDestroy(h->side2);
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
   if (h->dMap) hipFree(h->dMap);
+  if (h->dAsg) hipFree(h->dAsg);
   if (h->dFlags) hipFree(h->dFlags); if (h->hErr) hipHostFree(h->hErr);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -1862,21 +1869,25 @@ int bnmf_assign(bnmf_handle* h, int last_n, const int32_t* used, const double* r
   std::vector<double> refT((size_t)K * R), rn2(R, 0.0);
   for (int j = 0; j < R; ++j) for (int k = 0; k < K; ++k) { const double v = ref[k + (size_t)K * j]; refT[(size_t)k * R + j] = v; rn2[j] += v * v; }
   const size_t nout = (size_t)nu * nk * R;
-  double *dRef = nullptr, *dN2 = nullptr, *dOut = nullptr; int *dSl = nullptr, *dSig = nullptr;
-  auto freeall = [&]() { hipFree(dRef); hipFree(dN2); hipFree(dOut); hipFree(dSl); hipFree(dSig); };
-#define ASG(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { freeall(); return fail(BNMF_EHIP, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
-  ASG(hipMalloc(&dRef, refT.size() * 8)); ASG(hipMalloc(&dN2, R * 8)); ASG(hipMalloc(&dOut, nout * 8));
-  ASG(hipMalloc(&dSl, nu * sizeof(int))); ASG(hipMalloc(&dSig, nk * sizeof(int)));
-  ASG(hipMemcpy(dRef, refT.data(), refT.size() * 8, hipMemcpyHostToDevice)); ASG(hipMemcpy(dN2, rn2.data(), R * 8, hipMemcpyHostToDevice));
-  ASG(hipMemcpy(dSl, slots.data(), nu * sizeof(int), hipMemcpyHostToDevice)); ASG(hipMemcpy(dSig, sig.data(), nk * sizeof(int), hipMemcpyHostToDevice));
+  // one scratch allocation per handle, grown on demand (the ensemble assignment is called once per result, but BIC sweeps call it per rank)
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t oRef = 0, oN2 = oRef + up(refT.size() * 8), oOut = oN2 + up((size_t)R * 8), oSl = oOut + up(nout * 8), oSig = oSl + up((size_t)nu * sizeof(int)),
+               need = oSig + up((size_t)nk * sizeof(int));
+  if (need > h->asg_bytes) {
+    if (h->dAsg) { HIPCHK(hipFree(h->dAsg)); h->dAsg = nullptr; h->asg_bytes = 0; }
+    HIPCHK(hipMalloc(&h->dAsg, need));
+    h->asg_bytes = need;
+  }
+  double *dRef = (double*)(h->dAsg + oRef), *dN2 = (double*)(h->dAsg + oN2), *dOut = (double*)(h->dAsg + oOut);
+  int *dSl = (int*)(h->dAsg + oSl), *dSig = (int*)(h->dAsg + oSig);
+  HIPCHK(hipMemcpy(dRef, refT.data(), refT.size() * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dN2, rn2.data(), R * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dSl, slots.data(), nu * sizeof(int), hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dSig, sig.data(), nk * sizeof(int), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_ref_cosine, dim3(nu, nk), dim3(128), 0, h->stream, (const double*)h->arr[BNMF_P].ring, (size_t)K * N, K, (const int*)dSl,
                      (const int*)dSig, nk, (const double*)dRef, (const double*)dN2, R, dOut);
-  ASG(hipGetLastError());
+  HIPCHK(hipGetLastError());
   std::vector<double> cosv(nout);
-  ASG(hipMemcpyAsync(cosv.data(), dOut, nout * 8, hipMemcpyDeviceToHost, h->stream));
-  ASG(hipStreamSynchronize(h->stream));
-#undef ASG
-  freeall();
+  HIPCHK(hipMemcpyAsync(cosv.data(), dOut, nout * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
   // one Hungarian assignment per sample (maximise the total cosine); the cosine of a chosen pair is its vote
   const bool tr = nk > R;                                  // more signatures than references: assign references to signatures
   std::vector<double> cost;

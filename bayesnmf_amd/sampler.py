@@ -444,6 +444,9 @@ class bayesNMF_sampler:
                               inarow_no_change=st.inarow_no_change, inarow_no_best=st.inarow_no_best)
             if st.best_iter:
                 self.state["best_iter"] = st.best_iter
+        from .engine import WHY
+        if st.why in WHY and WHY[st.why] is not None:      # check_convergence_ keeps updating `why` during the post-warm-up checks too
+            self.state["why"] = WHY[st.why]
 
     def _post_warmup_on_engine(self, cc, pw):
         """The MH models' post-warm-up iterations (R/bayesNMF_sampler.R:332-384) as one engine call; the final MAP (kept
@@ -455,6 +458,12 @@ class bayesNMF_sampler:
         self._absorb_map_rows(maps, cc)
         self._absorb_cc_state(st)
         self.get_MAP(final=True)
+        # The reference's last check is update_MAP_metrics(final = TRUE) on the KEPT signatures (R/bayesNMF_sampler.R:364-375); the
+        # engine's rows come from bnmf_map over all N.  With excluded signatures the two differ: the last row is rebuilt here from the
+        # final MAP (n_params, BIC, and RMSE / KL when the device values are not attached to it).
+        if len(maps) and len(self.MAP.get("keep_sigs", [])) < self.dims["N"] and not self.state["MAP_metrics"].empty:
+            self.state["MAP_metrics"] = self.state["MAP_metrics"].iloc[:-1].reset_index(drop=True)
+            self._update_MAP_metrics(final=True)
 
     def _run_until_on_engine(self, cc):
         """The warm-up loop (blocks, MAP, MAP metrics, convergence bookkeeping) as one engine call (SURVEY.md 8 f2);

@@ -184,6 +184,14 @@ int bnmf_test_sampler(int device, int which, uint64_t seed, uint32_t chain, uint
 int bnmf_test_philox(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);    /* Philox4x32-10 */
 int bnmf_test_philox7(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);   /* Philox4x32-7: the count-allocation words */
 
+/* diagnostics of the builder's own tools and tests (tools/rankdbg.py, tools/zsprof.py, tools/zpprof.py, tests/test_gpu_parity.py):
+ * phase time stamps of the rank sweep (BNMF_RANKDBG=1 at bnmf_create; returns the grid size), section ticks of the allocation
+ * kernel (-DZSPROF / -DZPPROF builds only, else BNMF_ESTATE), and what a bounded in-kernel wait does when it gives up
+ * (word 0: a draw kernel waiting for the hyper sweep, word 1: the rank sweep's exchange).  Not part of the drop-in boundary. */
+int bnmf_debug_rank(bnmf_handle* h, unsigned long long* out, size_t n);
+int bnmf_debug_zsort(bnmf_handle* h, unsigned long long* out);
+int bnmf_debug_set_timeout(bnmf_handle* h, int word);
+
 int bnmf_device_info(int device, char* buf, size_t buflen);
 int bnmf_device_count(void);
 const char* bnmf_last_error(void);

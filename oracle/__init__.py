@@ -38,6 +38,9 @@ class OrcConfig(C.Structure):
 
 
 def build(force=False):
+    if os.environ.get("ORACLE_ASAN") == "1":           # tests/test_oracle_asan.py: the sanitizer build (needs libasan preloaded)
+        subprocess.check_call(["make", "-C", _HERE, "-s", "asan"])
+        return os.path.join(_HERE, "liboracle_asan.so")
     so = os.path.join(_HERE, "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("bnmf_oracle.c", "orc_math.h", "orc_samplers.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):

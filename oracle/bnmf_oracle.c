@@ -269,7 +269,7 @@ static void sample_P_poisson(orc_handle* o, uint32_t t, int from_prior) {
 /* sample_En_poisson  R/sample_En.R:97-119 */
 static void sample_E_poisson(orc_handle* o, uint32_t t, int from_prior) {
   const long K = o->cfg.K, G = o->cfg.G, N = o->cfg.N;
-  double Psum[4096];
+  double Psum[N];
   for (long n = 0; n < N; ++n) Psum[n] = orc_canon_sum(AR(ID_P) + K * n, K, 1, 64);
 #pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
   for (long g = 0; g < G; ++g)
@@ -299,7 +299,7 @@ static void sample_E_poisson(orc_handle* o, uint32_t t, int from_prior) {
 static void z_cell(const orc_handle* o, long k, long g, uint32_t t, int32_t* zrow, double* mhat) {
   const long K = o->cfg.K, N = o->cfg.N;
   const double *P = o->a[ID_P].p, *E = o->a[ID_E].p, *A = o->a[ID_A].p;
-  double cum[4096]; uint32_t thr[4096];
+  double cum[N]; uint32_t thr[N];
   double c = 0.0; long nlast = -1;
   for (long n = 0; n < N; ++n) {
     double p = (P[k + K * n] * A[n]) * E[n + N * g];
@@ -348,7 +348,7 @@ static void sample_Z_and_metrics(orc_handle* o, uint32_t t) {
     tid = omp_get_thread_num();
 #endif
     int32_t* zg = zg_part + (size_t)tid * K * N;
-    int32_t zrow[4096];
+    int32_t zrow[N];
     double* csse = (double*)malloc(8 * K * 3);
     double *cll = csse + K, *ckl = csse + 2 * K;
 #pragma omp for schedule(static)
@@ -449,7 +449,7 @@ static void sample_A(orc_handle* o, uint32_t t, int from_prior) {
   double* col = (double*)malloc(8 * G);
 #pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
   for (long g = 0; g < G; ++g) {
-    double l[4096];
+    double l[K];
     for (long k = 0; k < K; ++k) {
       double c = 0.0;
       for (long j = 0; j < N; ++j) c = c + (AR(ID_P)[k + K * j] * AR(ID_A)[j]) * AR(ID_E)[j + N * g];
@@ -463,7 +463,7 @@ static void sample_A(orc_handle* o, uint32_t t, int from_prior) {
     double a_old = AR(ID_A)[n];
 #pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
     for (long g = 0; g < G; ++g) {
-      double l[4096];
+      double l[K];
       double en = AR(ID_E)[n + N * g];
       for (long k = 0; k < K; ++k) {
         double tt = AR(ID_P)[k + K * n] * en;
@@ -478,7 +478,7 @@ static void sample_A(orc_handle* o, uint32_t t, int from_prior) {
       for (int state = 0; state < 2; ++state) {
 #pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
         for (long g = 0; g < G; ++g) {
-          double l[4096];
+          double l[K];
           for (long k = 0; k < K; ++k) {
             double c = 0.0;
             for (long j = 0; j < N; ++j) c = c + (AR(ID_P)[k + K * j] * (j == n ? (double)state : AR(ID_A)[j])) * AR(ID_E)[j + N * g];
@@ -674,7 +674,7 @@ static void sample_E_seq(orc_handle* o, uint32_t t) {
   }
 #pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
   for (long g = 0; g < G; ++g) {
-    double mhc[4096], x1[4096], x2[4096], y[4 * 4096];
+    double mhc[K], x1[K], x2[K], y[4 * K];
     for (long k = 0; k < K; ++k) mhc[k] = mhat_cell(o, k, g, -1, NULL, 0);
     const double sg = normal ? AR(ID_SIGMASQ)[g] : 1.0;
     for (long n = 0; n < N; ++n) {
@@ -734,7 +734,7 @@ static void metrics_cells_mh(orc_handle* o) {
   const long K = o->cfg.K, G = o->cfg.G;
 #pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
   for (long g = 0; g < G; ++g) {
-    double a[4096], b[4096], c[4096];
+    double a[K], b[K], c[K];
     for (long k = 0; k < K; ++k) cell_terms(o, o->M[k + K * g], mhat_cell(o, k, g, -1, NULL, 0), &a[k], &b[k], &c[k]);
     o->colsse[g] = orc_canon_sum(a, K, 1, 64);
     o->colll[g] = orc_canon_sum(b, K, 1, 64);
@@ -747,7 +747,7 @@ static void sample_sigmasq(orc_handle* o, uint32_t t) {
   const long K = o->cfg.K, G = o->cfg.G;
 #pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
   for (long g = 0; g < G; ++g) {
-    double r2[4096];
+    double r2[K];
     for (long k = 0; k < K; ++k) { double r = (double)o->M[k + K * g] - mhat_cell(o, k, g, -1, NULL, 0); r2[k] = r * r; }
     double ss = orc_canon_sum(r2, K, 1, 64);
     orc_stream s = ST(o, V_SIGMASQ, (uint32_t)g, t);
@@ -759,7 +759,7 @@ static void metrics_cells_normal(orc_handle* o) {
   const long K = o->cfg.K, G = o->cfg.G;
 #pragma omp parallel for schedule(static) num_threads(o->cfg.nthreads)
   for (long g = 0; g < G; ++g) {
-    double a[4096], b[4096], c[4096];
+    double a[K], b[K], c[K];
     double sg = AR(ID_SIGMASQ)[g];
     for (long k = 0; k < K; ++k) {
       double mh = mhat_cell(o, k, g, -1, NULL, 0), dummy;

@@ -157,6 +157,8 @@ bayesNMF_sampler_hip <- R6::R6Class(
       if (st[1] == 1 && !isTRUE(self$state$converged)) {
         self$state$converged <- TRUE; self$state$why <- c("no change", "no best", "max iters")[st[2]]
         self$state$converged_iter <- self$state$iter
+      } else if (st[2] > 0) {
+        self$state$why <- c("no change", "no best", "max iters")[st[2]]   # check_convergence_ keeps updating `why` during the post-warm-up checks
       }
     },
     record_sample = function() invisible(NULL),          # recorded on the device (bnmf_window)

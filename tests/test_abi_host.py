@@ -30,6 +30,13 @@ def test_header_symbols_exported():
     assert not missing, f"libbnmf.so lacks {missing}"
     assert set(engine.ABI_SYMBOLS) <= decl
     assert engine.lib().bnmf_version() == 100
+    # ... and nothing beyond it: every bnmf_* symbol the product library exports is declared in the header
+    import shutil
+    import subprocess
+    if shutil.which("nm"):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", engine.LIB_PATH], text=True)
+        exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("bnmf_")}
+        assert exported <= decl, f"exported but not declared in include/bnmf.h: {sorted(exported - decl)}"
 
 
 def test_no_cpu_fallback():
@@ -209,7 +216,7 @@ def test_r_shim_binds_every_entry_point_of_the_header():
     declared = set(re.findall(r"^(?:int|const char\*)\s+(bnmf_\w+)\(", hdr, re.M))
     # not bound: unit probes of the parity tests, the profiler hook, library-level queries R has no use for
     not_bound = {"bnmf_ubench", "bnmf_test_math", "bnmf_test_sampler", "bnmf_test_philox", "bnmf_test_philox7", "bnmf_profile", "bnmf_kernel_name", "bnmf_version",
-                 "bnmf_device_count", "bnmf_last_error", "bnmf_get_array_i32"}
+                 "bnmf_device_count", "bnmf_last_error", "bnmf_get_array_i32", "bnmf_debug_rank", "bnmf_debug_zsort", "bnmf_debug_set_timeout"}
     src, fns = _shim_functions()
     for name in sorted(declared - not_bound):
         b = "C_" + name
