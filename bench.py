@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 K_, G_, N_, R_TRUE, DATA_SEED = 96, 10000, 20, 8, 20250218
 MAP_OVER = 1000                # new_convergence_control() default: depth of the record_sample ring
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"                         # profiles/<tag>_pmc_*.json: the committed counter passes the roofline quotes (falls back to r03)
 
 
 def z_bytes(K, G, N, save_Z):
@@ -43,29 +43,36 @@ def z_bytes(K, G, N, save_Z):
     return b
 
 
-def pmc_valu_busy(save_Z):
-    """Fraction of the SIMDs' cycles the hot kernel's VALU pipe is busy, from the committed SQ counters (rocprofv3 --pmc,
-    tools/pmc_r3.sh): SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / SQ_WAVES x SIMDs) — both count quad-cycles, and the kernel's waves
-    are persistent (one set per launch), so WAVE_CYCLES / WAVES is the launch's length.  None if absent."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_counters.json")))["p3"]
-        key = next(k.split(":")[0] for k in d if k.startswith("k_zalloc_reg<true" if save_Z else "k_zalloc_sort") and k.endswith(":SQ_WAVES"))
-        waves, wc, act = (d[f"{key}:{c}"]["mean"] for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU"))
-        return act / (wc / waves * 1024.0) if not save_Z else None      # the save_Z kernel's waves are not persistent
-    except Exception:
-        return None
+def pmc_valu_busy(save_Z, simds=1024):
+    """Fraction of the SIMDs' cycles the hot kernel's VALU pipe is busy, from the COMMITTED SQ counters (rocprofv3 --pmc,
+    tools/pmc_r3.sh; not measured in this run): SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / SQ_WAVES x SIMDs) — both count
+    quad-cycles, and the kernel's waves are persistent (one set per launch), so WAVE_CYCLES / WAVES is the launch's length.
+    Returns (value, source file) or (None, None)."""
+    if save_Z:
+        return None, None                                                  # the save_Z kernel's waves are not persistent
+    for tag in (PROFILE_TAG, "r03"):
+        try:
+            name = f"profiles/{tag}_pmc_counters.json"
+            d = json.load(open(os.path.join(ROOT, name)))["p3"]
+            key = next(k.split(":")[0] for k in d if k.startswith("k_zalloc_sort") and k.endswith(":SQ_WAVES"))
+            waves, wc, act = (d[f"{key}:{c}"]["mean"] for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU"))
+            return act / (wc / waves * float(simds)), name
+        except Exception:
+            continue
+    return None, None
 
 
 def pmc_traffic(save_Z):
-    """HBM bytes per k_zalloc launch from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
-    rocprofv3 --pmc passes by tools/pmc2.sh, gfx950-corrected; committed under profiles/).  None if absent."""
-    for tag in (PROFILE_TAG, "r01"):
+    """HBM bytes per k_zalloc launch from the COMMITTED PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
+    rocprofv3 --pmc passes, gfx950-corrected; not measured in this run).  Returns (bytes, source file) or (None, None)."""
+    for tag in (PROFILE_TAG, "r03", "r01"):
         try:
-            d = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))
-            return d["k_zalloc_full" if save_Z else "k_zalloc_stats"]["hbm_bytes_per_launch"]
+            name = f"profiles/{tag}_pmc_traffic.json"
+            d = json.load(open(os.path.join(ROOT, name)))
+            return d["k_zalloc_full" if save_Z else "k_zalloc_stats"]["hbm_bytes_per_launch"], name
         except Exception:
             continue
-    return None
+    return None, None
 
 
 _CEILINGS = {}
@@ -89,15 +96,24 @@ def roofline_of(chain, K, G, N, save_Z, total_counts, n_iter, kernel=None, devic
     draws = total_counts / (z_ms * 1e-3) if z_ms > 0 else 0.0
     if kernel is None:
         kernel = "k_zalloc_reg<save_Z>" if save_Z else "k_zalloc_sort"
+    traffic, traffic_src = pmc_traffic(save_Z)
+    try:
+        import torch
+        simds = 4 * torch.cuda.get_device_properties(device).multi_processor_count
+    except Exception:
+        simds = 1024
+    busy, busy_src = pmc_valu_busy(save_Z, simds)
     return prof, {"bound": "hbm", "kernel": kernel, "achieved": achieved,
-                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(save_Z),
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                  "traffic_source": f"{traffic_src} (committed rocprofv3 --pmc passes of this kernel, not collected in this run)" if traffic_src else None,
                   "peak_measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs > 0 else None,
                   "algorithmic_bytes_per_launch": zb, "avg_launch_ms": z_ms,
                   "draws_per_s": draws,
                   # the bound that actually binds in stats mode: one Philox word per allocated count
                   "alu": {"achieved_philox_words_per_s": draws, "peak_philox_words_per_s": philox_peak,
                           "frac": draws / philox_peak if philox_peak > 0 else None,
-                          "valu_busy_frac": pmc_valu_busy(save_Z),
+                          "valu_busy_frac": busy,
+                          "valu_busy_source": f"{busy_src} (committed SQ counters, not collected in this run)" if busy_src else None,
                           "note": "peak = Philox4x32-7 (the generator of the count-allocation words) alone at 8 waves/SIMD, measured on this box (bnmf_ubench); the kernel also "
                                   "searches 19 thresholds and updates two tables per word"},
                   "note": "stats mode moves 6.3 MB per 40 M categorical draws: the kernel is VALU/Philox-bound, not HBM-bound (DESIGN.md 5)"
@@ -214,10 +230,10 @@ def secondary_configs(device, quick=False):
 
     run("2: Poisson-Gamma fixed rank N=20, K=96 x G=2,000", 96, 2000, 20, "gamma", 1000, 8, 2, "k_zalloc_sort")
     run("3: Poisson-TruncNormal+MH fixed rank N=20, K=96 x G=5,000", 96, 5000, 20, "truncnormal", 60, 8, 3, "k_mh", MH=True)
-    run("4: Poisson-Gamma SBFI learned rank 1:50, K=96 x G=10,000", 96, 10000, 50, "gamma", 60, 12, 4, "k_zalloc_tile (+ memset, k_colmetrics)",
+    run("4: Poisson-Gamma SBFI learned rank 1:50, K=96 x G=10,000", 96, 10000, 50, "gamma", 60, 12, 4, "k_zalloc_step",
         learning_rank=True, rank_method="SBFI", temperature=np.ones(8000))
     if not quick:
-        run("5: Poisson-Gamma fixed rank N=100, K=1,536 x G=50,000", 1536, 50000, 100, "gamma", 12, 30, 5, "k_zalloc_tile (+ memset, k_colmetrics)",
+        run("5: Poisson-Gamma fixed rank N=100, K=1,536 x G=50,000", 1536, 50000, 100, "gamma", 12, 30, 5, "k_zalloc_step",
             window=2)
     return out
 
@@ -306,10 +322,12 @@ def main():
         torch.cuda.synchronize()
 
     chain.run(args.warmup, metrics=False)
+    n_prof = min(200, max(20, args.steps // 10))
+    n_refill = max(args.warmup, 200)
     # roofline of the dominant kernel (k_zalloc): HIP events on the chain's own stream, one kernel at a time.
     # Done before the timed region (it advances the chain like any other iterations and keeps the clocks up).
-    prof, roof = roofline_of(chain, K_, args.G, N_, args.save_z, total_counts, min(200, max(20, args.steps // 10)), device=local_rank)
-    chain.run(max(args.warmup, 200), metrics=False)  # refill the stream pipeline after the serialised profile pass; keeps the clocks up
+    prof, roof = roofline_of(chain, K_, args.G, N_, args.save_z, total_counts, n_prof, device=local_rank)
+    chain.run(n_refill, metrics=False)  # refill the stream pipeline after the serialised profile pass; keeps the clocks up
 
     rep_dt = []
     met = None
@@ -337,6 +355,10 @@ def main():
             "value": world * args.steps / tmed,
             "unit": "Gibbs iterations/s (aggregate over chains)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # what ran before the first timed repetition: --warmup iterations, the serialised per-kernel profile pass the roofline
+            # comes from, and a refill of the stream pipeline
+            "warmup_effective": args.warmup + n_prof + n_refill,
+            "rng": "philox4x32-7 (count-allocation words, variable Z) / philox4x32-10 (every other stream)",
             "ms_per_step": 1e3 * tmed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             **({"REHEARSAL": "all ranks on one GPU over gloo: not a measurement"} if rehearse else {}),
