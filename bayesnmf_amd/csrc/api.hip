@@ -45,6 +45,8 @@ struct bnmf_handle {
   bool side_valid = false;             // k_side of iteration iter+1 has been issued
   int gate_forced = -1;                // BNMF_GATE at bnmf_create: 0 / 1 forces the merged draw kernel off / on, else by size
   int draw_bw = 0;                     // lanes per workgroup of the merged draw kernel (chosen at the first launch)
+  unsigned* dDrawOwn = nullptr; unsigned draw_seq = 0;   // k_draw: owner word per column of P, launch sequence number (kernels.h)
+  int dbg_draw_no_p = 0;               // BNMF_DEBUG_DRAW_NO_P (tests): the P workgroups of k_draw leave without claiming their columns
   int dbg_side_delay_us = 0;           // BNMF_DEBUG_SIDE_DELAY_US (tests): a delay kernel in front of the P-side hyper sweep of launch_side_merged
   int gate_f0 = 1;                     // flag the gate waits for beside [3]: [1] E-side sweep (k_side), [9] P-side sweep on its own stream (merged draw path)
   uint32_t z_gate_next = 0;            // != 0: the allocation kernel being launched waits at its end for the hyper sweep of this iteration
@@ -85,7 +87,8 @@ struct bnmf_handle {
   bool have_ev = false;
   double* dMap = nullptr; size_t map_words = 0;   // scratch of bnmf_map (grown on demand)
   unsigned char* dAsg = nullptr; size_t asg_bytes = 0;   // scratch of bnmf_assign (grown on demand): catalogue, norms, cosines, slot / signature lists
-  unsigned* dFlags = nullptr;                     // [0] counter, [1] flag of the E-side hyper sweep; [2], [3] of P part + Esum
+  unsigned* dFlags = nullptr;                     // [0] counter, [1] flag of the E-side hyper sweep; [2], [3] of P part + Esum; [5], [6] P inside k_draw;
+                                                  // [8], [9] P-side sweep on its own stream
   int* hErr = nullptr; int* dErr = nullptr;       // time-out words of the bounded in-kernel waits, in mapped host memory (read without a copy):
                                                   // [0] a draw kernel waiting for the hyper sweep, [1] the rank sweep's exchange
   bool flags_valid = false;                       // the side work of the next iteration publishes its flags
@@ -469,6 +472,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   HIPCHK(hipMemset(h->dZsumG, 0, K * N * sizeof(int32_t)));
   if (cfg->save_Z) HIPCHK(hipMalloc(&h->dZ, K * N * G * sizeof(int32_t)));
   if (const char* e = getenv("BNMF_GATE")) h->gate_forced = atoi(e) != 0 ? 1 : 0;   // diagnostics / tests
+  if (const char* e = getenv("BNMF_DEBUG_DRAW_NO_P")) h->dbg_draw_no_p = atoi(e) != 0 ? 1 : 0;   // tests only
   if (const char* e = getenv("BNMF_DEBUG_SIDE_DELAY_US")) h->dbg_side_delay_us = std::max(0, std::min(20000, atoi(e)));   // tests only
   {
     // A lane that polls inside a main-stream kernel for a side-stream kernel deadlocks (until its bound) when dispatches cannot
@@ -480,6 +484,8 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   }
   HIPCHK(hipMalloc(&h->dFlags, 64));
   HIPCHK(hipMemset(h->dFlags, 0, 64));
+  HIPCHK(hipMalloc(&h->dDrawOwn, N * sizeof(unsigned)));
+  HIPCHK(hipMemset(h->dDrawOwn, 0, N * sizeof(unsigned)));
   HIPCHK(hipHostMalloc((void**)&h->hErr, 64, hipHostMallocMapped));
   memset(h->hErr, 0, 64);
   HIPCHK(hipHostGetDevicePointer((void**)&h->dErr, h->hErr, 0));
@@ -494,27 +500,21 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   HIPCHK(hipMalloc(&h->dlpE, 3 * (size_t)h->nblkE * sizeof(double)));
   HIPCHK(hipMalloc(&h->dcol, 3 * 3 * G * sizeof(double)));   // per-column partials, 3 slots (t % 3)
   if (cfg->learning_rank) {
-    const size_t gran_words = 4 * 2 * ((G + RK_MAXC - 1) / RK_MAXC);        // [4 buffers][2 granules per block sum]
+    const size_t gran_words = (size_t)RK_REP * 4 * 2 * ((G + RK_MAXC - 1) / RK_MAXC);   // [RK_REP copies][4 buffers][2 granules per block sum]
     HIPCHK(hipMalloc(&h->dRankCol, gran_words * sizeof(double)));
     HIPCHK(hipMemset(h->dRankCol, 0, gran_words * sizeof(double)));           // tag 0 is never used
-    if (((size_t)N + (G + RK_MAXC - 1) / RK_MAXC) * sizeof(double) > 60 * 1024) {
-      HIPCHK(hipFuncSetAttribute((const void*)k_rank_sweep<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)k_rank_sweep<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)k_rank_sweep<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)k_rank_sweep<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    }
     HIPCHK(hipMalloc(&h->dRankSync, 32));
     HIPCHK(hipMemset(h->dRankSync, 0, 32));
     // grid of the persistent rank sweep: co-resident by construction (one 512-lane workgroup per CU)
     hipDeviceProp_t prop0;
     HIPCHK(hipGetDeviceProperties(&prop0, cfg->device));
-    const long NB = ((long)G + RK_MAXC - 1) / RK_MAXC;                 // blocks of 8 columns, one wave each
-    const long wg_needed = (NB + RK_W - 1) / RK_W;
+    const long NB = ((long)G + RK_MAXC - 1) / RK_MAXC;                 // blocks of 8 columns, one compute wave each
+    const long wg_needed = (NB + RK_CW - 1) / RK_CW;                   // RK_CW compute waves + the decision wave per workgroup
     // every workgroup of the sweep waits for all others: the grid must be co-resident.  Ask the runtime how many
     // workgroups of each variant fit a CU (registers, LDS); where the answer is SGPR-limited (>= 6 per CU) the query can
     // be one high (MI355X_MICROARCH.md), so one is kept in reserve there; never plan more than two per CU.  Should the
     // grid still not be co-resident, the bounded spins time out and bnmf_run reports it (no hang).
-    const size_t rlds = ((size_t)N + NB + N + 1 + N) * sizeof(double);
+    const size_t rlds = (3 * (size_t)N + 1) * sizeof(double);
     auto fit = [&](const void* fn) {
       int nb = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, RK_T, rlds) != hipSuccess || nb < 1) nb = 1;
@@ -707,7 +707,7 @@ int bnmf_destroy(bnmf_handle* h) {
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
   if (h->dMap) hipFree(h->dMap);
   if (h->dAsg) hipFree(h->dAsg);
-  if (h->dFlags) hipFree(h->dFlags); if (h->hErr) hipHostFree(h->hErr);
+  if (h->dFlags) hipFree(h->dFlags); if (h->dDrawOwn) hipFree(h->dDrawOwn); if (h->hErr) hipHostFree(h->hErr);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -1132,7 +1132,7 @@ static int launch_zalloc(bnmf_handle* h, uint32_t t) {
 static void launch_rank(bnmf_handle* h, uint32_t t, hipEvent_t stop = nullptr, int row = -1) {
   const int N = h->cfg.N;
   const int NB = (h->cfg.G + RK_MAXC - 1) / RK_MAXC;
-  const size_t lds = ((size_t)N + NB + N + 1 + N) * sizeof(double);   // A, block sums, sample_R weights, sample_An uniforms
+  const size_t lds = (3 * (size_t)N + 1) * sizeof(double);            // A, sample_R weights, sample_An uniforms
   const RecDst rr = row >= 0 ? rec_at(h, t, fused_rec(h)) : RecDst{};
   auto go = [&](auto kern) {
     hipExtLaunchKernelGGL(kern, dim3(h->rank_grid), dim3(RK_T), (uint32_t)lds, h->stream, nullptr, stop, 0, h->dev, t, (unsigned long long*)h->dRankCol, NB, h->dErr + 1, h->dRankMhat, (unsigned long long*)h->dRankDbg, row, rr.A, rr.R);
@@ -1353,7 +1353,7 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
     const unsigned nE = (unsigned)(((size_t)h->cfg.N * h->cfg.G + bw - 1) / bw);
     hipExtLaunchKernelGGL(k_draw, dim3(h->cfg.N + nE), dim3(bw), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, rec_at(h, t, rec),
                           SideDone{h->dFlags + 5, h->dFlags + 6, (unsigned)h->cfg.N, t}, SideWait{h->dFlags + 6, h->dFlags + 6, t, h->dErr},
-                          rec_at(h, t + 1, rec), SideDone{h->dFlags, h->dFlags + 1, nE, t + 1});
+                          rec_at(h, t + 1, rec), SideDone{h->dFlags, h->dFlags + 1, nE, t + 1}, h->dDrawOwn, ++h->draw_seq, h->dbg_draw_no_p);
     launch_side_merged(h, t + 1, tm);
   } else {
     // The side work of this iteration may have been issued by launch_side_merged (the sweep before took the merged path without
@@ -1405,7 +1405,7 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
     HIPCHK(hipMemset(h->dFlags, 0, 64));
     memset(h->hErr, 0, 64);
     if (h->dRankSync) HIPCHK(hipMemset(h->dRankSync, 0, 32));
-    if (h->dRankCol) HIPCHK(hipMemset(h->dRankCol, 0, 4 * 2 * (((size_t)h->cfg.G + RK_MAXC - 1) / RK_MAXC) * sizeof(double)));
+    if (h->dRankCol) HIPCHK(hipMemset(h->dRankCol, 0, (size_t)RK_REP * 4 * 2 * (((size_t)h->cfg.G + RK_MAXC - 1) / RK_MAXC) * sizeof(double)));
     HIPCHK(hipMemset(h->dZsumK, 0, (size_t)h->cfg.N * h->cfg.G * sizeof(int32_t)));
     HIPCHK(hipMemset(h->dZsumG, 0, (size_t)h->cfg.K * h->cfg.N * sizeof(int32_t)));
     h->side_valid = false; h->flags_valid = false; h->z_gate_next = 0; h->z_gated_for = 0; h->gate_f0 = 1;

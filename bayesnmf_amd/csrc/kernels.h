@@ -305,26 +305,31 @@ __global__ __launch_bounds__(ES_T) void k_edraw(Dev d, uint32_t t, int from_prio
 
 // ---- k_draw: k_pdraw and k_edraw of the steady-state fixed-rank sweep in ONE launch (large problems: api.hip gate_enabled) ----
 // Workgroups [0, N): factor n's column of P (k_pdraw's work), Psum[n] stored write-through, the last of them raises the flag pd.
-// Workgroups [N, ..): E, DW lanes each: the Gamma(shape, 1) part of the draw needs nothing from P; then the workgroup waits for
-// the flag (one lane polls; the P workgroups have the lowest indices, so they are resident before any E workgroup) and divides
-// by the rate — the same operations in the same order as rgamma(shape, rate).  The kernel waits for nothing outside itself: the
-// allocation kernel before it has waited (one lane, at its end) for the hyper sweep of this iteration.
-// ASSUMPTION (stated, not enforced): the dispatcher starts the workgroups of a launch in index order, so the N P workgroups are running
-// before an E workgroup can hold a slot they need.  If that ever failed (other chains filling the CUs in between), the E workgroups'
-// bounded wait would time out: the call fails with BNMF_EHIP and the handle is poisoned — an error, never a wrong draw.  Covered with
-// other chains on the device by tests/test_gpu_configs.py::test_four_different_chains_at_once_match_their_solo_runs (K G = 768,000).
+// Workgroups [N, ..): E, DW lanes each: the Gamma(shape, 1) part of the draw needs nothing from P; then one lane waits for the
+// flag pd and the workgroup divides by the rate — the same operations in the same order as rgamma(shape, rate).
+// A column of P is OWNED by whoever first writes this launch's sequence number into its word of own[] (one atomic exchange): its
+// workgroup b < N when it starts — or an E workgroup that has waited for the flag for a while and finds the word still old.
+// In-order dispatch makes the second a path never taken (the P workgroups have marked their columns long before an E workgroup
+// gets to its wait), but forward progress no longer rests on it: if E workgroups ever held every slot before a P workgroup had
+// started (round 3: "assumption, stated, not enforced"), they would draw the columns themselves instead of timing out, and the
+// late P workgroup finds its column taken and leaves.  Which workgroup draws a column changes no bit of it (the elements' own
+// streams).  seq grows by one per launch of this kernel on the handle, so the words never need a reset.  no_p (tests):
+// workgroups [0, N) leave without taking their columns.
+// The kernel waits for nothing outside itself: the allocation kernel before it has waited (one lane, at its end) for the hyper
+// sweep of this iteration.
 constexpr int DW = 1024;
 // The E workgroups also run the E-side hyper sweep of iteration t + 1 (hyper_elem<1>: element-wise, it needs nothing but the
 // element's own E_t): beside the allocation kernel that sweep got one wave per SIMD and the leftover issue slots (85 us for
 // ~20 us of work, and the allocation kernel's gate waited for it); here it runs at full occupancy.  rec_next: ring slots of
 // t + 1 for the prior parameters; ed: the E-side flag of the hand-off protocol (k_side raises it when it does this work).
-__global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, SideDone pd, SideWait pw, RecDst rec_next, SideDone ed) {
+__global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, SideDone pd, SideWait pw, RecDst rec_next, SideDone ed, unsigned* own /* [N] */, unsigned seq, int no_p) {
   __shared__ double Pn[DW];
   __shared__ double lutS[3 * ALUT_N];                     // E workgroups: ralpha_fast's table (its look-ups are dependent loads inside the Newton and attempt loops)
+  __shared__ int jobS;
   const int tid = threadIdx.x, N = d.N, K = d.K;
   const int BW = blockDim.x;                              // <= DW: chosen by the host so that the E workgroups fill the CUs once
-  if ((int)blockIdx.x < N) {
-    const int n = blockIdx.x;
+  // column n of P by this workgroup (sample_Pn_poisson R/sample_Pn.R:98-120), Psum[n], and its share of the flag pd
+  auto p_column = [&](int n) __attribute__((always_inline)) {
     const double a_n = d.A[n];
     const double Esum = d.Esum[n];
     for (int k = tid; k < K; k += BW) {
@@ -353,8 +358,40 @@ __global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, Side
       if (tid == 0) st_wt(&d.Psum[n], acc);
     }
     side_done(pd, tid);
+  };
+  auto take = [&](int n) __attribute__((always_inline)) -> bool {                        // one lane: true if column n is now this workgroup's
+    return __hip_atomic_exchange(own + n, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq;
+  };
+  if ((int)blockIdx.x < N) {
+    if (no_p) return;
+    if (tid == 0) jobS = take((int)blockIdx.x) ? (int)blockIdx.x : -1;
+    __syncthreads();
+    if (jobS >= 0) p_column(jobS);
     return;
   }
+  // lane 0 waits for the flag pd; after a while it looks for a column of P that nobody has taken (see the head of the kernel).
+  // Returns the column this workgroup has to draw, or -1: P is complete.
+  auto wait_p = [&]() __attribute__((always_inline)) -> int {
+    if (tid == 0) {
+      int job = -1;
+      unsigned spins = 0;
+      while (__hip_atomic_load(pw.f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pw.epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 24)) { __hip_atomic_store(pw.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if ((spins & 7u) == 0u) {
+          for (int c = 0; c < N && job < 0; ++c)
+            if (__hip_atomic_load(own + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq && take(c)) job = c;
+          if (job >= 0) break;
+        }
+      }
+      jobS = job;
+    }
+    __syncthreads();
+    return jobS;
+  };
+  // the E role of the workgroup; returns a column of P to draw first (then the role is run again from its start: the same streams,
+  // the same bits — so that no draw has to be kept in registers across the column's code), or -1 when done
+  auto e_role = [&]() __attribute__((always_inline)) -> int {
   const long e = (long)((int)blockIdx.x - N) * BW + tid;
   const bool live = e < (long)d.lenE;
   DRSTAMP(0);
@@ -378,10 +415,11 @@ __global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, Side
     hpre = hyper_pre<1>(d, (int)e, t + 1);
   }
   // the Alpha table: behind the draws (the waves arrive here one by one, so its loads overlap the others' arithmetic; at the head of
-  // the kernel every wave sat through them at once), visible after side_wait's barrier
+  // the kernel every wave sat through them at once), visible after wait_p's barrier
   if (d.prior == BNMF_GAMMA) for (int i = tid; i < 3 * ALUT_N; i += BW) lutS[i] = g_alut[i];
   DRSTAMP(1);
-  side_wait<false>(pw, tid);
+  const int job = wait_p();
+  if (job >= 0) return job;
   DRSTAMP(2);
   if (live) {
     if (scaled) {
@@ -405,6 +443,14 @@ __global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, Side
 #endif
   }
   side_done(ed, tid);
+  return -1;
+  };
+  int job = e_role();
+  if (__builtin_expect(job >= 0, 0)) {                    // never taken under in-order dispatch
+    do { __syncthreads(); p_column(job); __syncthreads(); job = wait_p(); } while (job >= 0);
+    __syncthreads();
+    e_role();                                             // P is complete: runs through
+  }
 }
 
 // log-prior of column n of P_t under iteration t's prior parameters: canonical W = 64 over k, as in k_pdraw

@@ -60,7 +60,7 @@ __global__ void k_rank_Aprior(Dev d, uint32_t t) {
 }
 
 // ---- the rank sweep: sample_An for n = 1..N in ONE persistent launch ----
-// Every decision needs a sum over ALL cells, so the factors are separated by a grid-wide barrier (hand-written:
+// Every decision needs a sum over ALL cells, so the factors are separated by a grid-wide exchange (hand-written:
 // tagged-granule all-gather, bounded spin; the grid is sized to be co-resident: 512-lane workgroups, one per CU,
 // which also keeps the waves' compute time even).  Stream spec: Mhat fresh at the start of the sweep, then maintained per cell; for factor n only
 // the alternative state alt = Mhat -/+ P[k,n] E[n,g] is evaluated, the log-likelihood of the current state is carried.
@@ -69,6 +69,8 @@ __global__ void k_rank_Aprior(Dev d, uint32_t t) {
 // and takes the same tempered Bernoulli decision.
 constexpr int RK_T = 512;
 constexpr int RK_W = RK_T / 64;
+constexpr int RK_REP = 8;                                // copies of the granule buffers (see rank_publish)
+constexpr int RK_CW = RK_W - 1;                          // waves that evaluate cells; the last wave of a workgroup gathers, sums and decides
 constexpr int RK_MAXC = 8;                                // columns per block = columns per wave kept in registers (REG variant)
 constexpr unsigned RK_SPIN_LIMIT = 1u << 22;
 
@@ -89,73 +91,127 @@ BNMF_DEV double rank_cell_ll_t(int m, double c, double sg, double lgf) {   // ra
     return (-0.91893853320467274178 - dlog(sd)) - 0.5 * (z * z);
   }
   const double h = c < 1e-6 ? 1e-6 : c;
-  return ((double)m * dlog(h) - h) - lgf;
+  // h >= 1e-6: dlog's special cases reduce to "not finite" (dlog(inf) = inf, dlog(NaN) = NaN: h itself); for every other h the branch-free
+  // dlog_fin is the same operations, hence the same bits, and twelve of them interleave
+  const double lh = (h <= 1.7976931348623157e308) ? dlog_fin(h) : h;
+  return ((double)m * lh - h) - lgf;
 }
 BNMF_DEV double rank_lgf(const Dev& d, int m) { return d.lgfact[m < 0 ? 0 : (m > d.maxM ? d.maxM : m)]; }
 // All-gather of the block sums without a separate barrier: a value is published as two 8-byte granules
 // {tag, low word}, {tag, high word} (one agent-scope relaxed store each: write-through, never torn), tag = a number
-// unique to (iteration, phase).  Every workgroup sweeps all granules with agent-scope relaxed loads (which bypass
-// its L1) until every tag matches, and rebuilds the doubles in LDS: the data is its own flag, no fences needed.
-// Bounded: a time-out sets *err and makes every workgroup leave.
-BNMF_DEV void rank_publish(unsigned long long* gran, int b, unsigned tag, double v) {
+// unique to (iteration, phase).  The DECISION WAVE of every workgroup (below) sweeps all granules with agent-scope relaxed
+// loads (which bypass its L1) until every tag matches: the data is its own flag, no fences needed.  Bounded: a time-out
+// sets *err and makes every workgroup leave.
+// Every workgroup reads every block sum at every factor: with ONE copy of the buffer all (179 at G = 10,000) decision waves ask the
+// same few memory channels for the same 20 KB at the same time, and the gather took 4.3 us however the loads were issued (8- or
+// 16-byte, one or two rounds).  So a block sum is published RK_REP times (lanes 0 .. RK_REP - 1 of the publishing wave, one copy
+// each, in ONE store instruction per granule) and a workgroup reads copy blockIdx % RK_REP.
+BNMF_DEV void rank_publish(unsigned long long* gran /* this lane's copy */, int b, unsigned tag, double v) {
   const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
   __hip_atomic_store(gran + 2 * (size_t)b, ((unsigned long long)tag << 32) | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(gran + 2 * (size_t)b + 1, ((unsigned long long)tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// A lane's granules are requested GB blocks at a time (one round trip to the memory side for all of them instead of one per
-// block).  rank_request issues the loads of the lane's first GB blocks; rank_gather takes them (pre != nullptr) or loads them
-// itself, polls every block whose tags do not match yet, and handles the blocks beyond the first GB in the same way.
-constexpr int RK_GB = 3;
-struct RankPre { unsigned long long g0[RK_GB], g1[RK_GB]; };
-BNMF_DEV void rank_request(const unsigned long long* gran, int NB, int tid, RankPre& pre) {
+// The gather and the canonical W = 1024 sum of the NB block sums by ONE wave, without LDS and without a workgroup barrier:
+// lane l owns accumulators l + 64 j (j = 0..15) — accumulator i adds x[i], x[i + 1024], ... in order —, so tree levels
+// 512 .. 64 are additions inside the lane (i + 512 is j + 8, ...) and levels 32 .. 1 are wave_tree64: the same additions in
+// the same order as canon_sum(x, NB, 1024).  The granules of a lane's first 32 blocks are requested together (one round trip
+// to the memory side; two in a row — 16 blocks at a time — took 4.1 us per factor) and only those whose tags do not match yet are asked for again.  The sum is valid on lane 0.
+typedef unsigned int __attribute__((ext_vector_type(4))) rk_uv4;
+BNMF_DEV bool rank_gather_sum(const unsigned long long* gran, int NB, unsigned tag, int* err, int lane, double& sum, unsigned& rounds) {
+  constexpr int GB = 32;                                  // blocks per lane and round (NB <= 2,048: ONE round trip)
+  // a block's two granules in ONE 16-byte load (agent scope: sc1, as the 8-byte atomic loads; each granule carries its own tag, so
+  // the two halves may be torn against each other).  The buffer descriptor bounds the loads: a lane beyond the last block reads
+  // zeros — tag 0 is never used, the value +0.0 adds nothing — so the first round is straight-line code: the requests back to back,
+  // one wait, ONE accumulated tag check (vector instructions only), the additions.
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)gran, 0, NB * 16, 0x00020000);
+  double acc[16];
 #pragma unroll
-  for (int i = 0; i < RK_GB; ++i) {
-    const int b = tid + i * RK_T;
-    pre.g0[i] = pre.g1[i] = 0ull;                         // tag 0 is never used: an unrequested block fails the match and is polled
-    if (b < NB) {
-      pre.g0[i] = __hip_atomic_load(gran + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      pre.g1[i] = __hip_atomic_load(gran + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-BNMF_DEV bool rank_gather(const unsigned long long* gran, int NB, unsigned tag, double* vals /* LDS [NB] */, int* err, int tid, const RankPre* pre = nullptr) {
-  __shared__ int bad_s;
-  if (tid == 0) bad_s = 0;
-  __syncthreads();
+  for (int j = 0; j < 16; ++j) acc[j] = 0.0;
   bool bad = false;
-  for (int b0 = tid; b0 < NB && !bad; b0 += RK_GB * RK_T) {
-    RankPre cur;
-    if (pre && b0 == tid) cur = *pre; else rank_request(gran + 2 * (size_t)(b0 - tid), NB - (b0 - tid), tid, cur);
+  for (int base = 0; base < NB && !bad; base += 64 * GB) {
+    rk_uv4 hv[GB];
+    const int nj = min(GB, (NB - base + 63) >> 6);        // wave-uniform: rounds of 64 blocks that hold a block at all
+    const bool lastv = base + lane + 64 * (nj - 1) < NB;  // the lane holds a block in the last round (every lane does in the others)
+    unsigned spins = 0;
+    while (true) {
 #pragma unroll
-    for (int i = 0; i < RK_GB; ++i) {
-      const int b = b0 + i * RK_T;
-      if (b >= NB || bad) continue;
-      unsigned long long h0 = cur.g0[i], h1 = cur.g1[i];
-      unsigned spins = 0;
-      while ((unsigned)(h0 >> 32) != tag || (unsigned)(h1 >> 32) != tag) {
-        if (spins) __builtin_amdgcn_s_sleep(1);
-        if (++spins > RK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { bad = true; break; }
-        h0 = __hip_atomic_load(gran + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        h1 = __hip_atomic_load(gran + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int j = 0; j < GB; ++j) {
+        hv[j] = rk_uv4{tag, tag, tag, tag};               // (not requested: passes the check; its value is replaced by +0.0 below)
+        if (j < nj) hv[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (base + lane + 64 * j) * 16, 0, 16 /* sc1 */);
       }
-      if (!bad) vals[b] = __longlong_as_double((long long)((h0 & 0xFFFFFFFFull) | (h1 << 32)));
+      unsigned miss = 0u;
+#pragma unroll
+      for (int j = 0; j < GB; ++j) {
+        const unsigned m = (hv[j].y ^ tag) | (hv[j].w ^ tag);
+        miss |= (j == nj - 1 && !lastv) ? 0u : m;
+      }
+      rounds += 1u;
+      if (__builtin_amdgcn_ballot_w64(miss != 0u) == 0ull) break;
+      // a block has not arrived: the whole round again (the requests cost one round trip however many they are)
+      __builtin_amdgcn_s_sleep(1);
+      ++spins;
+      const bool giveup = spins > RK_SPIN_LIMIT || ((spins & 1023u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+      if (__builtin_amdgcn_ballot_w64(giveup) != 0ull) { bad = true; break; }
+    }
+    if (bad) break;
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {                        // accumulator l + 64 (j & 15) takes its blocks in ascending order (no block: + 0.0)
+      const double x = __longlong_as_double((long long)(((unsigned long long)hv[j].z << 32) | hv[j].x));
+      acc[j & 15] = acc[j & 15] + ((j < nj) ? x : 0.0);
     }
   }
-  if (bad) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bad_s = 1; }
-  __syncthreads();
-  return bad_s == 0;
+  if (bad) { if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+#pragma unroll
+  for (int h = 8; h >= 1; h >>= 1)
+#pragma unroll
+    for (int j = 0; j < h; ++j) acc[j] = acc[j] + acc[j + h];
+  sum = wave_tree64(acc[0]);
+  return true;
 }
-// canonical W = 1024 sum of x[0..L) by a 512-lane workgroup: lane i owns accumulators i and i + 512
-BNMF_DEV double canon1024_by512(const double* x, long L, double* buf, int tid) {
-  double a0 = 0.0, a1 = 0.0;
-  for (long i = tid; i < L; i += 1024) {
-    a0 = a0 + x[i];
-    if (i + 512 < L) a1 = a1 + x[i + 512];
+// Eight canonical W = 64 trees at once (lane i adds lane i + h, h = 32 .. 1: the same additions as eight wave_tree64).  After
+// the first level only half of the lanes of a column hold live values, so two columns share a register (v_permlane32_swap
+// brings both columns' upper halves down in one exchange), after the second level four (v_permlane16_swap), and the DPP
+// row shifts of levels 8 .. 1 work on four columns per instruction: 42 instructions instead of 160.  Results: column c of
+// v[] in lane (c & 1) * 32 + ((c >> 1) & 1) * 16 of r[c >> 2].
+BNMF_DEV void wave_tree64x8(const double* v, double* r) {
+  auto sw32 = [](double& a, double& b) {                  // a <- {a.lo, b.lo}, b <- {a.hi, b.hi}
+    const unsigned alo = (unsigned)__double_as_longlong(a), ahi = (unsigned)(__double_as_longlong(a) >> 32);
+    const unsigned blo = (unsigned)__double_as_longlong(b), bhi = (unsigned)(__double_as_longlong(b) >> 32);
+    const auto x = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    const auto y = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    a = __longlong_as_double(((long long)y[0] << 32) | (unsigned)x[0]);
+    b = __longlong_as_double(((long long)y[1] << 32) | (unsigned)x[1]);
+  };
+  auto sw16 = [](double& a, double& b) {                  // a <- {a.r0, b.r0, a.r2, b.r2}, b <- {a.r1, b.r1, a.r3, b.r3}
+    const unsigned alo = (unsigned)__double_as_longlong(a), ahi = (unsigned)(__double_as_longlong(a) >> 32);
+    const unsigned blo = (unsigned)__double_as_longlong(b), bhi = (unsigned)(__double_as_longlong(b) >> 32);
+    const auto x = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    const auto y = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    a = __longlong_as_double(((long long)y[0] << 32) | (unsigned)x[0]);
+    b = __longlong_as_double(((long long)y[1] << 32) | (unsigned)x[1]);
+  };
+  double p[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { double a = v[2 * i], b = v[2 * i + 1]; sw32(a, b); p[i] = a + b; }   // lanes 0..31: column 2i, 32..63: column 2i + 1
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    double a = p[2 * i], b = p[2 * i + 1];
+    sw16(a, b);
+    double q = a + b;                                     // rows: columns 4i, 4i + 2, 4i + 1, 4i + 3
+#define BNMF_TREE_STEP(CTRL)                                                                                       \
+    {                                                                                                              \
+      int lo = (int)__double_as_longlong(q), hi = (int)(__double_as_longlong(q) >> 32);                            \
+      lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true); \
+      q = q + __longlong_as_double(((long long)hi << 32) | (unsigned)lo);                                          \
+    }
+    BNMF_TREE_STEP(0x108) BNMF_TREE_STEP(0x104) BNMF_TREE_STEP(0x102) BNMF_TREE_STEP(0x101)   // row_shl:8, 4, 2, 1
+#undef BNMF_TREE_STEP
+    r[i] = q;
   }
-  a0 = a0 + a1;                                           // tree level h = 512
-  const double r = block_tree<RK_T>(a0, buf, tid);        // valid on thread 0
-  __syncthreads();
-  return r;
+}
+BNMF_DEV double lane_of(double v, int l) {                // lane l's value (wave-uniform l) through the scalar unit
+  const int lo = __builtin_amdgcn_readlane((int)__double_as_longlong(v), l), hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(v) >> 32), l);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 // tempered Bernoulli of sample_An :108-166 from the two log-likelihoods (the sweep's constants are hoisted by the caller)
 struct RankConst { double l1mp, lpi, lgG, T; };
@@ -179,23 +235,32 @@ BNMF_DEV double rank_decide(const Dev& d, double u /* the factor's uniform: bloc
   return (u < p) ? 1.0 : 0.0;
 }
 
-// REG (K <= 96): one block of 8 columns per wave, its cells in registers for the whole sweep: rows 0..63 of every
-// column (slot 0: lane = row), and rows 64..95 of TWO columns per register (slot 1: lanes 0..31 column 2p, lanes 32..63
-// column 2p + 1, row 64 + (lane & 31)), so that no lane idles on a half-empty second pass; the upper half's terms are
-// brought down with v_permlane32_swap before they are added to their column's accumulators (lane i = rows i, i + 64, as
-// the canonical sum demands).  Otherwise a wave walks its blocks b = w, w + Wt, ... and Mhat lives in the global scratch.
+// REG (K <= 96): one block of 8 columns per COMPUTE wave (waves 0 .. RK_CW - 1), its cells in registers for the whole sweep:
+// rows 0..63 of every column (slot 0: lane = row), and rows 64..95 of TWO columns per register (slot 1: lanes 0..31 column 2p,
+// lanes 32..63 column 2p + 1, row 64 + (lane & 31)), so that no lane idles on a half-empty second pass; the upper half's terms
+// are brought down with v_permlane32_swap before they are added to their column's accumulators (lane i = rows i, i + 64, as
+// the canonical sum demands).  Otherwise a compute wave walks its blocks b = w, w + Wt, ... and Mhat lives in the global scratch.
+// The last wave of every workgroup is its DECISION WAVE (round 4): it gathers the block sums of factor n, adds them
+// canonically and takes the tempered Bernoulli decision WHILE the compute waves evaluate the alternative of factor n + 1
+// (before: 4.1 us of evaluation, then 2.1 us of gather, then 1.2 us of tree and decision, one after the other, per factor).
+// One workgroup barrier per factor hands the decision over.
 template <bool REG, bool NORMAL>
-__global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsigned long long* granbuf /* [4][2 NB] */, int NB, int* err, double* mhg, unsigned long long* dbg,
+__global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsigned long long* granbuf /* [RK_REP][4][2 NB] */, int NB, int* err, double* mhg, unsigned long long* dbg,
                                                          int row /* metrics row, or -1 */, double* recA, double* recR) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ double buf[RK_T];
   __shared__ double bc[2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ double dst[6];
+  // the wave's number in a scalar register and the lane from the execution mask: the thread index itself need not stay in a register
+  // through the sweep (at 256 registers it was the one value spilled)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int tid = wave * 64 + lane;
   const int K = d.K, G = d.G, N = d.N;
   const int KR = (K + 63) >> 6;
-  // block (REG) / first block (otherwise) of this wave: wave-major, so that a grid wider than NB / RK_W spreads the
-  // blocks over all CUs (about one busy wave per SIMD instead of two on 60 % of the CUs)
-  const int wg = wave * gridDim.x + blockIdx.x, Wt = gridDim.x * RK_W;
+  const bool decider = wave == RK_CW;
+  // block (REG) / first block (otherwise) of this wave: wave-major, so that a grid wider than NB / RK_CW spreads the
+  // blocks over all CUs
+  const int wg = wave * gridDim.x + blockIdx.x, Wt = gridDim.x * RK_CW;
   constexpr bool normal = NORMAL;
   // tags of this launch, unique over the chain: tag0 + 1 = log-likelihood of the current state, tag0 + 2 + 2n + redo = the
   // alternative of factor n (redo = 1: evaluated again after factor n-1 flipped, see the factor loop)
@@ -203,15 +268,14 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
   // the workgroup's own copy of A: every workgroup takes every decision itself, so A is never read across
   // workgroups inside the launch (the global A is written for the kernels that follow)
   double* Ash = (double*)smem;                           // [N]
-  double* vals = Ash + N;                                // [NB] gathered block sums
-  double* wR = vals + NB;                                // [N+1] weights of sample_R
+  double* wR = Ash + N;                                  // [N+1] weights of sample_R
   double* uA = wR + (N + 1);                             // [N] the factors' uniforms (sample_An's rbinom), drawn up front by N lanes
   __shared__ int Rsh;
   for (int j = tid; j < N; j += RK_T) { Ash[j] = d.A[j]; Stream sa(d.k0, d.k1, BNMF_V_A, (uint32_t)j, t); uA[j] = runif(sa); }
   __syncthreads();
   // sample_R :217-241 (was a launch of its own): every workgroup draws the same R from the same stream; the N+1 weights
-  // are evaluated one per lane of wave 0, then added and scanned in r order by its lane 0
-  if (wave == 0) {
+  // are evaluated one per lane of the decision wave, then added and scanned in r order by its lane 0
+  if (decider) {
     Stream s(d.k0, d.k1, BNMF_V_R, 0u, t);
     const double u = runif(s);
     const double T = temp_at(d, t);
@@ -234,14 +298,74 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
       if (blockIdx.x == 0) *d.R = pick;
     }
   }
+#define RKSTAMP(i) if (dbg && lane == 0 && n < 16) dbg[(blockIdx.x * 16 + n) * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
+  const size_t rstride = (size_t)4 * 2 * NB;               // granules per copy
+  unsigned long long* const mycopy = granbuf + (size_t)(blockIdx.x % RK_REP) * rstride;       // the copy this workgroup reads
+  unsigned long long* const pubcopy = granbuf + (size_t)(lane % RK_REP) * rstride;            // the copy this lane writes when it publishes
+  auto gbuf = [&](int n) { return (size_t)((n + 1) & 3) * 2 * NB; };
+  auto tagof = [&](int n, unsigned redo) { return tag0 + 2u + 2u * (unsigned)n + redo; };
+  if (decider) {
+    // ---------------------------------------------------------------- the decision wave
+    double ll_cur = 0.0;
+    // few instructions against the compute waves' long fp64 chains, but every other wave of the workgroup waits for their result
+    __builtin_amdgcn_s_setprio(3);
+    unsigned rounds0 = 0u;
+    bool ok = rank_gather_sum(mycopy, NB, tag0 + 1u, err, lane, ll_cur, rounds0);   // buffer 0: the current state (lane 0 carries it)
+    // lane 0's state between the factors lives in LDS (dst: ll_cur, sumA, the sweep's constants): nothing but addresses stays in
+    // registers across the gather, whose 32 blocks per lane are 128 of them
+    if (lane == 0) {
+      const double pi1 = prior_prob_1((double)Rsh, (double)N);   // written by this lane above
+      double sumA = 0.0;
+      for (int j = 0; j < N; ++j) sumA = sumA + Ash[j];
+      dst[0] = ll_cur; dst[1] = sumA; dst[2] = dlog(1.0 - pi1); dst[3] = dlog(pi1); dst[4] = dlog((double)G); dst[5] = temp_at(d, t);
+    }
+    unsigned redo = 0;                                     // which publication of factor n's alternative is the valid one
+    for (int n = 0; n < N; ++n) {
+      RKSTAMP(0);
+      double ll_alt = 0.0;
+      unsigned rounds = 0u;
+      if (ok) ok = rank_gather_sum(mycopy + gbuf(n), NB, tagof(n, redo), err, lane, ll_alt, rounds);
+      RKSTAMP(2);
+      if (dbg && lane == 0 && n < 16) dbg[(blockIdx.x * 16 + n) * 8 + 5] = rounds;
+      const double a_old = Ash[n];
+      double a_new = -1.0;                                 // -1: the exchange timed out, every wave leaves
+      if (ok && lane == 0) {
+        const double ll_cur_ = dst[0], sumA = dst[1];
+        const RankConst rc{dst[2], dst[3], dst[4], dst[5]};
+        const double ll0 = (a_old == 1.0) ? ll_alt : ll_cur_, ll1 = (a_old == 1.0) ? ll_cur_ : ll_alt;
+        a_new = rank_decide(d, uA[n], ll0, ll1, a_old, sumA, rc);
+        if (a_new != a_old) { dst[0] = ll_alt; dst[1] = (sumA - a_old) + a_new; }
+      }
+      if (lane == 0) bc[n & 1] = a_new;
+      RKSTAMP(3);
+      wg_lds_barrier();
+      a_new = wave_bcast0(a_new);
+      if (a_new < 0.0) return;
+      redo = (a_new != a_old) ? 1u : 0u;
+      if (lane == 0) { Ash[n] = a_new; if (blockIdx.x == 0) d.A[n] = a_new; }
+    }
+  } else {
+  // ---------------------------------------------------------------- the compute waves
   constexpr int RK_P = RK_MAXC / 2;                       // column pairs of the second row slot
   double mh0[REG ? RK_MAXC : 1], mh1[REG ? RK_P : 1], sgc[(REG && NORMAL) ? RK_MAXC : 1];
   double lg0[(REG && !NORMAL) ? RK_MAXC : 1], lg1[(REG && !NORMAL) ? RK_P : 1];   // lgamma(M + 1) of the wave's cells
   int mm0[REG ? RK_MAXC : 1], mm1[REG ? RK_P : 1];
   const int half = lane >> 5, row1 = 64 + (lane & 31);    // slot 1: this lane's column of the pair and its row
   const bool lowv1 = lane < 32 && 64 + lane < K;          // lanes that own an accumulator with a second row
+  // block sum of the wave's 8 columns from the lanes' accumulators: 8 canonical trees, then columns in ascending order (lane 0)
+  auto block_sum = [&](const double* accv) {
+    double r[2];
+    wave_tree64x8(accv, r);
+    double bs = 0.0;
+#pragma unroll
+    for (int c = 0; c < RK_MAXC; ++c) {
+      const double tr = lane_of(r[c >> 2], (c & 1) * 32 + ((c >> 1) & 1) * 16);
+      bs = (wg * RK_MAXC + c < G) ? bs + tr : bs;
+    }
+    return bs;
+  };
   // ---- phase 0: fresh Mhat and the log-likelihood of the current state
-  unsigned long long* gran = granbuf;                    // buffer 0 of 4
+  unsigned long long* gran = pubcopy;                    // buffer 0 of 4
   const unsigned phase = 1;
   if (REG) {
     double accv[RK_MAXC];
@@ -277,10 +401,8 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
       if (lowv1 && wg * RK_MAXC + 2 * p < G) accv[2 * p] = accv[2 * p] + v;
       if (lowv1 && wg * RK_MAXC + 2 * p + 1 < G) accv[2 * p + 1] = accv[2 * p + 1] + w;
     }
-    double bs = 0.0;
-#pragma unroll
-    for (int c = 0; c < RK_MAXC; ++c) { const double tr = wave_tree64(accv[c]); if (wg * RK_MAXC + c < G) bs = bs + tr; }   // lane 0: block sum, columns in ascending order
-    if (lane == 0 && wg < NB) rank_publish(gran, wg, tag0 + phase, bs);
+    const double bs = block_sum(accv);
+    if (lane < RK_REP && wg < NB) rank_publish(gran, wg, tag0 + phase, bs);
   } else {
     for (int b = wg; b < NB; b += Wt) {
       double bs = 0.0;
@@ -301,19 +423,17 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
         }
         bs = bs + wave_tree64(acc);
       }
-      if (lane == 0) rank_publish(gran, b, tag0 + phase, bs);
+      bs = wave_bcast0(bs);
+      if (lane < RK_REP) rank_publish(gran, b, tag0 + phase, bs);
     }
   }
   // ---- factors in order, one step ahead of the decisions.  The alternative log-likelihood of factor n+1 depends on the
-  // decision for factor n only through Mhat, and most decisions leave A[n] as it was.  So a workgroup evaluates and publishes
-  // the alternative of factor n+1 BEFORE it gathers the block sums of factor n: by the time it has finished, every other
-  // workgroup's sums of factor n (published one step earlier) have arrived, and the gather is a read instead of a wait for the
-  // slowest publisher.  When factor n does flip, Mhat is updated and the alternative of n+1 is evaluated and published again
-  // under the `redo` tag; every workgroup takes the same decision, so all of them know which tag to gather.  Same values,
-  // same order of operations, same draws as the one-factor-at-a-time sweep.
+  // decision for factor n only through Mhat, and most decisions leave A[n] as it was.  So the compute waves evaluate and
+  // publish the alternative of factor n+1 WHILE the decision wave gathers the block sums of factor n (published one step
+  // earlier by every workgroup) and decides.  When factor n does flip, Mhat is updated and the alternative of n+1 is
+  // evaluated and published again under the `redo` tag; every workgroup takes the same decision, so all of them know which
+  // tag to gather.  Same values, same order of operations, same draws as the one-factor-at-a-time sweep.
   // Four granule buffers: a workgroup in step n writes buffer (n+2)&3 while the slowest one may still read (n-1)&3 .. (n+1)&3.
-  auto gbuf = [&](int n) { return granbuf + (size_t)((n + 1) & 3) * 2 * NB; };
-  auto tagof = [&](int n, unsigned redo) { return tag0 + 2u + 2u * (unsigned)n + redo; };
   // REG: column n of P and row n of E (this wave's 8 columns) are requested one factor ahead of their use
   double np0 = 0.0, np1 = 0.0, nen[REG ? RK_MAXC : 1];
   auto prefetch = [&](int n) {
@@ -332,36 +452,31 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
   // evaluate the alternative of factor f (A[f] flipped) on the current Mhat and publish this wave's block sums
   auto publish_alt = [&](int f, unsigned redo) {
     const double a_f = Ash[f];
-    unsigned long long* gr = gbuf(f);
+    unsigned long long* gr = pubcopy + gbuf(f);
     const unsigned tg = tagof(f, redo);
     if (REG) {
-      // straight-line code: the 16 cell terms and then the 8 column trees are independent chains the scheduler can
-      // interleave (per-column / per-cell branches kept them apart: 5.3 us of pure latency per factor); cells beyond K and
+      // straight-line code: the 12 cell terms are independent chains the scheduler can interleave; cells beyond K and
       // columns beyond G hold harmless values and are never added
+      // Mhat - t is Mhat + (-t), and (-p) e is -(p e): the sign goes onto the column of P once per factor
+      const double q0 = (a_f == 1.0) ? -p0 : p0, q1 = (a_f == 1.0) ? -p1 : p1;
       double accv[RK_MAXC];
 #pragma unroll
       for (int c = 0; c < RK_MAXC; ++c) {                 // slot 0
-        const double tt = p0 * en_[c];
-        const double alt = (a_f == 1.0) ? mh0[c] - tt : mh0[c] + tt;
+        const double alt = mh0[c] + q0 * en_[c];
         const double ll = rank_cell_ll_t<NORMAL>(mm0[c], alt, NORMAL ? sgc[NORMAL ? c : 0] : 1.0, NORMAL ? 0.0 : lg0[NORMAL ? 0 : c]);
         accv[c] = (lane < K) ? 0.0 + ll : 0.0;
       }
 #pragma unroll
       for (int p = 0; p < RK_P; ++p) {                    // slot 1: two columns per register
-        const double tt = p1 * (half ? en_[2 * p + 1] : en_[2 * p]);
-        const double alt = (a_f == 1.0) ? mh1[p] - tt : mh1[p] + tt;
+        const double alt = mh1[p] + q1 * (half ? en_[2 * p + 1] : en_[2 * p]);
         const double sg = NORMAL ? (half ? sgc[NORMAL ? 2 * p + 1 : 0] : sgc[NORMAL ? 2 * p : 0]) : 1.0;
         const double v = rank_cell_ll_t<NORMAL>(mm1[p], alt, sg, NORMAL ? 0.0 : lg1[NORMAL ? 0 : p]);
         const double w = down32(v);
         accv[2 * p] = lowv1 ? accv[2 * p] + v : accv[2 * p];
         accv[2 * p + 1] = lowv1 ? accv[2 * p + 1] + w : accv[2 * p + 1];
       }
-#pragma unroll
-      for (int c = 0; c < RK_MAXC; ++c) accv[c] = wave_tree64(accv[c]);
-      double bs = 0.0;
-#pragma unroll
-      for (int c = 0; c < RK_MAXC; ++c) bs = (wg * RK_MAXC + c < G) ? bs + accv[c] : bs;   // lane 0: block sum, columns in ascending order
-      if (lane == 0 && wg < NB) rank_publish(gr, wg, tg, bs);
+      const double bs = block_sum(accv);
+      if (lane < RK_REP && wg < NB) rank_publish(gr, wg, tg, bs);
     } else {
       const double* Pf = d.P + (size_t)K * f;
       for (int b = wg; b < NB; b += Wt) {
@@ -384,7 +499,8 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
           }
           bs = bs + wave_tree64(acc);
         }
-        if (lane == 0) rank_publish(gr, b, tg, bs);
+        bs = wave_bcast0(bs);
+        if (lane < RK_REP) rank_publish(gr, b, tg, bs);
       }
     }
   };
@@ -420,48 +536,26 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
   };
   if (REG) { prefetch(0); take_prefetched(1); }
   publish_alt(0, 0u);                                      // alternative of factor 0: needs no decision
-  if (!rank_gather(gran, NB, tag0 + phase, vals, err, tid)) return;
-  double ll_cur = canon1024_by512(vals, NB, buf, tid);  // valid on thread 0, which carries it
-  RankConst rc{};
-  double sumA = 0.0;
-  if (tid == 0) {
-    const double pi1 = prior_prob_1((double)Rsh, (double)N);   // written by this thread (wave 0, lane 0) above
-    rc.l1mp = dlog(1.0 - pi1); rc.lpi = dlog(pi1); rc.lgG = dlog((double)G); rc.T = temp_at(d, t);
-    for (int j = 0; j < N; ++j) sumA = sumA + Ash[j];
-  }
-  unsigned redo = 0;                                       // which publication of factor n's alternative is the valid one
   for (int n = 0; n < N; ++n) {
     const double a_old = Ash[n];
-#define RKSTAMP(i) if (dbg && tid == 0 && n < 16) dbg[(blockIdx.x * 16 + n) * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
-    RKSTAMP(0);
-    RankPre pre;                                           // factor n's sums were published a step ago: their loads fly under the
-    rank_request(gbuf(n), NB, tid, pre);                   // evaluation below (after a flip they are not there yet and are polled)
     if (n + 1 < N) {                                       // one step ahead: factor n+1 on the Mhat as it is
       if (REG) take_prefetched(n + 2);
       publish_alt(n + 1, 0u);
     }
-    RKSTAMP(1);
-    if (!rank_gather(gbuf(n), NB, tagof(n, redo), vals, err, tid, &pre)) return;
-    RKSTAMP(2);
-    const double ll_alt = canon1024_by512(vals, NB, buf, tid);
-    if (tid == 0) {
-      const double ll0 = (a_old == 1.0) ? ll_alt : ll_cur, ll1 = (a_old == 1.0) ? ll_cur : ll_alt;
-      const double a_new = rank_decide(d, uA[n], ll0, ll1, a_old, sumA, rc);
-      if (a_new != a_old) { ll_cur = ll_alt; sumA = (sumA - a_old) + a_new; }
-      bc[0] = a_new;
-    }
-    RKSTAMP(3);
-    __syncthreads();
-    const double a_new = bc[0];
-    redo = 0;
+    if (wave == 0) { RKSTAMP(1); }
+    if (wave == RK_CW - 1) { RKSTAMP(7); }                // the youngest compute wave: two waves of a SIMD finish one after the other
+    wg_lds_barrier();                                      // the decision of factor n (LDS only: the prefetches and publications stay in flight)
+    const double a_new = bc[n & 1];
+    if (a_new < 0.0) return;                               // the exchange timed out (the decision wave has set *err)
     if (a_new != a_old) {                                  // the step ahead was taken on a stale Mhat: again
       flip_mhat(n, a_old);                                 // (general variant: a lane re-reads only the Mhat cells it wrote itself)
-      if (n + 1 < N) { publish_alt(n + 1, 1u); redo = 1; }
+      if (n + 1 < N) publish_alt(n + 1, 1u);
     }
-    if (tid == 0) { Ash[n] = a_new; if (blockIdx.x == 0) d.A[n] = a_new; }
-    __syncthreads();
-    RKSTAMP(4);
+    if (wave == 0) { RKSTAMP(4); }
   }
+  }
+#undef RKSTAMP
+  __syncthreads();
   // what k_sumA did in a launch of its own (Gibbs sweep): A, R into the ring, sum(A) into the raw metrics row
   if (blockIdx.x == 0 && row >= 0) {
     if (recA) for (int j = tid; j < N; j += RK_T) recA[j] = Ash[j];

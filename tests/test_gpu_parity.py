@@ -630,6 +630,65 @@ def test_late_p_side_sweep_after_init_is_waited_for(monkeypatch):
     e.close()
 
 
+def test_draw_kernel_columns_of_P_drawn_by_E_workgroups(monkeypatch):
+    """forward progress of the merged draw kernel must not rest on the dispatcher starting its P workgroups
+    first.  A column of P belongs to whoever first marks its owner word (kernels.h k_draw): BNMF_DEBUG_DRAW_NO_P makes the P
+    workgroups leave without taking their columns — as if they had never been given a slot — so the E workgroups, waiting for
+    the flag, find the columns unowned and draw them themselves, then make their own draws again.  No time-out, and P, E, the
+    Z statistics, the prior parameters and the metrics stay bit-identical to the oracle."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    monkeypatch.setenv("BNMF_GATE", "1")
+    monkeypatch.setenv("BNMF_DEBUG_DRAW_NO_P", "1")
+    M, _, _ = synth_counts(96, 900, 4, 43)
+    N = 12
+    o = O.Oracle(M, N, prior="gamma", seed=6, nthreads=8)
+    e = Engine(M, N, prior="gamma", seed=6, window=4)
+    for c in (o, e):
+        apply_hyperprior_params(c, "gamma", M, N)
+    o.init(); e.init()
+    for step, n_it in enumerate((4, 3)):
+        mo, me = o.run(n_it), e.run(n_it)
+        for nm in ("P", "E", "ZsumK", "ZsumG", "Alpha_p", "Beta_p", "Alpha_e", "Beta_e"):
+            a, b = np.ascontiguousarray(o.get(nm), dtype=np.float64), np.ascontiguousarray(e.get(nm), dtype=np.float64)
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (nm, step)
+        assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), step
+    e.close()
+
+
+def test_draw_kernel_beside_a_second_gated_chain():
+    """the merged draw kernel of one chain beside a second gated chain on the same device at G >= 8,000
+    (both chains' E workgroups compete for the CUs while each waits for its own P columns): each chain ends bit-identical to
+    its solo run, no time-out."""
+    import threading
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    M, _, _ = synth_counts(96, 8000, 8, 47)
+    N = 20
+
+    def run(seed, out, key):
+        e = Engine(M, N, prior="gamma", seed=seed, window=0)
+        apply_hyperprior_params(e, "gamma", M, N)
+        e.init()
+        for _ in range(6):
+            e.run(25, metrics=False)
+        out[key] = (e.get("P").copy(), e.get("E").copy(), e.get("ZsumG").copy())
+        e.close()
+
+    solo, both = {}, {}
+    for sd in (3, 4):
+        run(sd, solo, sd)
+    th = [threading.Thread(target=run, args=(sd, both, sd)) for sd in (3, 4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for sd in (3, 4):
+        for a, b in zip(solo[sd], both[sd]):
+            assert np.array_equal(np.ascontiguousarray(a, dtype=np.float64).view(np.uint64), np.ascontiguousarray(b, dtype=np.float64).view(np.uint64)), sd
+
+
 def _match_cosine(P, Pt):
     """Best one-to-one cosine match of the columns of P to the columns of Pt (assignment problem)."""
     from scipy.optimize import linear_sum_assignment
