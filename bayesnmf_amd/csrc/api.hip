@@ -79,6 +79,7 @@ struct bnmf_handle {
   bool z_tile = false, z_lean = false; ZTGeom ztg{}; double* dMhatZ = nullptr;   // k_zalloc_tile (zalloc_tile.h): N > 24 / large K
   // k_zalloc_sort (zalloc_sort.h): stats mode, N <= 24 — the static schedule built from M at bnmf_create
   bool z_sort = false, zs_pk = false; ZSGeom zsg{}; int zs_nblk = 0, zs_w = 0; size_t zs_lds = 0; int32_t* dZsM = nullptr;
+  uint32_t* dZsRec = nullptr; int zx_cols = 0; size_t zx_lds = 0;   // save_Z on the sorted schedule: the items' records, k_zexpand's columns per pass and LDS bytes
   uint32_t* dZsItems = nullptr; ZSBlock* dZsBlocks = nullptr; int* dZsCols = nullptr; unsigned long long* dZsProf = nullptr;
   // k_zalloc_step (zalloc_step.h): stats mode, 25 <= N <= 100, any K — the static schedule built from M at bnmf_create
   bool z_step = false; ZPGeom zpg{}; int zp_ns = 0 /* waves per workgroup */, zp_gbp = 0; size_t zp_lds = 0;
@@ -237,7 +238,9 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   const bnmf_config& c = h->cfg;
   const size_t K = c.K, G = c.G, N = c.N;
   h->z_sort = false;
-  if (c.save_Z || !h->z_reg || N > (size_t)ZS_NMAX - 1 || K > 1024) return 0;
+  if (!h->z_reg || N > (size_t)ZS_NMAX - 1 || K > 1024) return 0;
+  // save_Z: a cell's counts per factor meet as 16-bit halves in k_zexpand's slab
+  if (c.save_Z && h->maxM > 65535) return 0;
   if (const char* e = getenv("BNMF_ZSORT")) if (atoi(e) == 0) return 0;          // diagnostics / tests: the register kernel
   // an item word holds 16 bits of fragment index (k | gl << 10 | f << 16), and f = 65535 with k = 1023, gl = 63 is the empty-lane
   // sentinel: a cell above 65,534 fragments of 4 ZS_QMAX counts stays with the register kernel
@@ -326,6 +329,15 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   HIPCHK(hipMemcpy(h->dZsCols, cols.data(), cols.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMalloc(&h->dZsM, Mblk.size() * sizeof(int32_t)));
   HIPCHK(hipMemcpy(h->dZsM, Mblk.data(), Mblk.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (c.save_Z) {
+    const size_t hw = (N + 1) / 2;
+    HIPCHK(hipMalloc(&h->dZsRec, items.size() * hw * sizeof(uint32_t)));
+    const size_t lds_max = 160 * 1024;
+    h->zx_cols = std::max(1, std::min(GBc, zexpand_cols((int)K, (int)N, lds_max)));
+    h->zx_lds = ((size_t)h->zx_cols * N * ((K + 1) / 2) * 4 + 15) & ~(size_t)15;
+    if (h->zx_lds > lds_max) return fail(BNMF_EINVAL, "bnmf_create: K = %zu, N = %zu: a column of Z does not fit the LDS of k_zexpand", K, N);
+    HIPCHK(hipFuncSetAttribute((const void*)k_zexpand, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  }
   h->zsg = ZSGeom{KP, GBc, (int)nb};
   h->zs_nblk = nblk; h->zs_w = W; h->zs_pk = pk;
   h->zs_lds = (zsort_shared_bytes((int)K, (int)N, KP, GBc, pk) + (size_t)W * zsort_wave_bytes(nblk, (int)N) + 15) & ~(size_t)15;
@@ -700,7 +712,7 @@ int bnmf_destroy(bnmf_handle* h) {
   if (h->dMhatZ) hipFree(h->dMhatZ);
   if (h->zpg.prof) hipFree(h->zpg.prof);
   if (h->dZpItems) hipFree(h->dZpItems); if (h->dZpWgs) hipFree(h->dZpWgs); if (h->dZpBatches) hipFree(h->dZpBatches); if (h->dZpSteps) hipFree(h->dZpSteps); if (h->dZpCols) hipFree(h->dZpCols);
-  if (h->dZsItems) hipFree(h->dZsItems); if (h->dZsBlocks) hipFree(h->dZsBlocks); if (h->dZsCols) hipFree(h->dZsCols); if (h->dZsProf) hipFree(h->dZsProf); if (h->dZsM) hipFree(h->dZsM);
+  if (h->dZsItems) hipFree(h->dZsItems); if (h->dZsBlocks) hipFree(h->dZsBlocks); if (h->dZsCols) hipFree(h->dZsCols); if (h->dZsProf) hipFree(h->dZsProf); if (h->dZsM) hipFree(h->dZsM); if (h->dZsRec) hipFree(h->dZsRec);
   if (h->dMhat) hipFree(h->dMhat); if (h->dAccPn) hipFree(h->dAccPn); if (h->dAccEpart) hipFree(h->dAccEpart); if (h->dNzE) hipFree(h->dNzE);
   if (h->dEt) hipFree(h->dEt); if (h->dMt) hipFree(h->dMt); if (h->zring) hipFree(h->zring);
   if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_rank) hipEventDestroy(h->ev_rank); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); if (h->side) hipStreamDestroy(h->side); if (h->side2) hipStreamDestroy(h->side2);
@@ -1069,7 +1081,7 @@ static int launch_zalloc_t(bnmf_handle* h, uint32_t t) {
 }
 template <int ZT_>
 static int launch_zsort_t(bnmf_handle* h, uint32_t t) {
-  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->dZsProf};
+  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->dZsRec, h->dZsProf};
   auto go = [&](auto kern) -> int {
     if (h->z_attr_kernel != (const void*)kern) {
       HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1115,7 +1127,14 @@ static int launch_zstep(bnmf_handle* h, uint32_t t) {
   return h->zp_gbp == 40 ? go(k_zalloc_step<4, 40, 8>) : go(k_zalloc_step<4, 32, 8>);
 }
 static int launch_zalloc(bnmf_handle* h, uint32_t t) {
-  if (h->z_sort) return launch_zsort(h, t);
+  if (h->z_sort) {
+    if (int rc = launch_zsort(h, t)) return rc;
+    if (h->cfg.save_Z) {                                   // the items' records -> the columns of Z (zalloc_sort.h k_zexpand)
+      const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->dZsRec, h->dZsProf};
+      hipLaunchKernelGGL(k_zexpand, dim3(h->zsg.nblocks), dim3(ZX_T), h->zx_lds, h->stream, sa, h->zx_cols);
+    }
+    return 0;
+  }
   if (h->z_step) return launch_zstep(h, t);
   const bool sz = h->cfg.save_Z != 0;
   switch (h->z_zw) {

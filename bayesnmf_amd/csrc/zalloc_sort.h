@@ -15,6 +15,12 @@
 // block's zG[n][k] / zK[n][column] (LDS atomics), those once per block into ZsumG (global integer atomics: exact,
 // order-independent) and ZsumK (plain stores: a column belongs to one block).  The per-column metric terms need the
 // canonical W = 64 order over the rows: they are separate small tasks (lane = row) at the end of the block's task list.
+// save_Z (round 4; samples$Z, R/sample_params.R:80-84, R/bayesNMF_sampler.R:245-252): the same kernel with s.rec set.  A lane's
+// histogram is its item's share of Z[k, ., g]; the flush also writes it — packed as the flush packs it, two 16-bit counts per
+// word — to the record buffer rec[task][word][lane]: one coalesced 256-byte store per word and task.  k_zexpand then turns a
+// block's records into its columns of Z: the records are added into an LDS slab [column][factor][row] (16-bit halves; the
+// fragments of a cell above 128 counts meet there), which leaves as whole 16-byte stores of Z[k .. k + 3 + K (n + N g)].  No
+// scattered global store, no zero fill: 38 MB of records written and read beside the 77 MB of Z at the metric configuration.
 // (sample_Zkg R/sample_params.R:253-265; metrics R/utils.R:412-471)
 #pragma once
 
@@ -31,6 +37,7 @@ struct ZSArgs {
   const ZSBlock* blocks;
   const int* cols;
   const int32_t* Mblk;               // M with its columns in block order: column col0 + gl of Mblk = column cols[col0 + gl] of M
+  uint32_t* rec;                     // save_Z: [item slot / 64][(N + 1) / 2][64] the items' histograms, two 16-bit counts per word; else null
   unsigned long long* prof;          // -DZSPROF builds only: per-section s_memtime ticks summed over the waves (diagnostics)
 };
 // -DZSPROF: section timers.  [0] block set-up, [1] thresholds, [2] quad loops, [3] histogram flush, [4] metric tasks,
@@ -278,6 +285,10 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
     ZSTOC(2);
     ZSTIC(3);
     // flush the lane's histogram into the block's tables
+    if (s.rec) {                       // save_Z: the item's record (lanes without counts write zeros: their histogram is clear)
+      uint32_t* rt = s.rec + ((size_t)(bk.item0 >> 6) + (size_t)task) * (size_t)HW * 64 + lane;
+      for (int w = 0; w < HW; ++w) rt[(size_t)w * 64] = hist[(2 * w) * 64 + lane] | (hist[(2 * w + 1) * 64 + lane] << 16);
+    }
     if (nq > 0) {
       const uint32_t zgb = lds_off(zG) + ((uint32_t)k << 2), zkb = lds_off(zK) + ((uint32_t)gl << 2);
       for (int w = 0; w < HW; ++w) {
@@ -328,6 +339,58 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
       __builtin_amdgcn_s_sleep(2);
       if (++spins > (1u << 24)) { __hip_atomic_store(d.gate_err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
+  }
+}
+
+// ---- k_zexpand: Z of a block's columns from the records of its items (save_Z on the sorted schedule, see the head of the file) ----
+// One workgroup per block of the schedule.  The slab holds as many of the block's columns as fit the LDS (all of them at the
+// metric configuration: 40 x 20 x 48 words = 150 KB); with more, the records are walked once per group of columns.
+constexpr int ZX_T = 1024;
+BNMF_HD int zexpand_cols(int K, int N, size_t lds_bytes) { return (int)(lds_bytes / ((size_t)N * (size_t)((K + 1) / 2) * 4)); }
+__global__ __launch_bounds__(ZX_T) void k_zexpand(ZSArgs s, int cols_per_pass) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* slab = (uint32_t*)smem;                        // [column of the pass][N][KH]: rows 2 j, 2 j + 1 in the halves of word j
+  const ZArgs& d = s.a;
+  const int tid = threadIdx.x, K = d.K, N = d.N, KH = (K + 1) >> 1, HW = (N + 1) >> 1;
+  const ZSBlock bk = s.blocks[blockIdx.x];
+  const int nslots = bk.ntask * 64;
+  for (int c0 = 0; c0 < bk.ncols; c0 += cols_per_pass) {
+    const int nc = min(cols_per_pass, bk.ncols - c0);
+    for (int i = tid; i < nc * N * KH; i += ZX_T) slab[i] = 0u;
+    __syncthreads();
+    for (int i = tid; i < nslots; i += ZX_T) {             // lane = item slot, as in the allocation kernel: the records are read as they were written
+      const uint32_t it = s.items[(size_t)bk.item0 + i];
+      if (it == 0xFFFFFFFFu) continue;
+      const int k = (int)(it & 1023u), gl = (int)((it >> 10) & 63u) - c0;
+      if (gl < 0 || gl >= nc) continue;
+      const uint32_t* rt = s.rec + ((size_t)((bk.item0 + i) >> 6)) * (size_t)HW * 64 + (i & 63);
+      uint32_t* sc = slab + (size_t)gl * N * KH + (k >> 1);
+      const int sh = (k & 1) << 4;
+      for (int w = 0; w < HW; ++w) {
+        const uint32_t v = rt[(size_t)w * 64];
+        if (v & 0xFFFFu) atomicAdd(sc + (size_t)(2 * w) * KH, (v & 0xFFFFu) << sh);          // (2 w + 1 < N whenever the upper half is set)
+        if (v >> 16) atomicAdd(sc + (size_t)(2 * w + 1) * KH, (v >> 16) << sh);
+      }
+    }
+    __syncthreads();
+    // Z[k + K (n + N g)]: a column's K N entries are contiguous; four rows (two slab words) per 16-byte store when K is a multiple of 4
+    for (int gl = 0; gl < nc; ++gl) {
+      int32_t* zc = d.Z + (size_t)K * N * (size_t)s.cols[bk.col0 + c0 + gl];
+      const uint32_t* sc = slab + (size_t)gl * N * KH;
+      if ((K & 3) == 0) {
+        for (int i = tid; i < N * (K >> 2); i += ZX_T) {
+          const int n = i / (K >> 2), j = i - n * (K >> 2);
+          const uint32_t a = sc[(size_t)n * KH + 2 * j], b = sc[(size_t)n * KH + 2 * j + 1];
+          *(int4*)(zc + (size_t)K * n + 4 * j) = int4{(int)(a & 0xFFFFu), (int)(a >> 16), (int)(b & 0xFFFFu), (int)(b >> 16)};
+        }
+      } else {
+        for (int i = tid; i < N * K; i += ZX_T) {
+          const int n = i / K, k = i - n * K;
+          zc[i] = (int32_t)((sc[(size_t)n * KH + (k >> 1)] >> ((k & 1) << 4)) & 0xFFFFu);
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 

@@ -95,7 +95,7 @@ def roofline_of(chain, K, G, N, save_Z, total_counts, n_iter, kernel=None, devic
     philox_peak, copy_gbs = ceilings(device)
     draws = total_counts / (z_ms * 1e-3) if z_ms > 0 else 0.0
     if kernel is None:
-        kernel = "k_zalloc_reg<save_Z>" if save_Z else "k_zalloc_sort"
+        kernel = "k_zalloc_sort with save_Z (+ the zero fill of Z in front of it)" if save_Z else "k_zalloc_sort"
     traffic, traffic_src = pmc_traffic(save_Z)
     try:
         import torch
@@ -117,7 +117,7 @@ def roofline_of(chain, K, G, N, save_Z, total_counts, n_iter, kernel=None, devic
                           "note": "peak = Philox4x32-7 (the generator of the count-allocation words) alone at 8 waves/SIMD, measured on this box (bnmf_ubench); the kernel also "
                                   "searches 19 thresholds and updates two tables per word"},
                   "note": "stats mode moves 6.3 MB per 40 M categorical draws: the kernel is VALU/Philox-bound, not HBM-bound (DESIGN.md 5)"
-                          if not save_Z else "full mode: Z (K x N x G int32) written every iteration"}
+                          if not save_Z else "full mode: Z (K x N x G int32) written every iteration: a coalesced zero fill, then the non-zero entries from the lanes that hold them"}
 
 
 def make_chain(M, N, seed, chain_id, device, save_Z=False, window=MAP_OVER, prior="gamma", **kw):
@@ -346,6 +346,13 @@ def main():
     if dist is not None:
         from bayesnmf_amd.multichain import gather_rows
         gathered = gather_rows(met[-1:], dist, device=tdev)     # RCCL: gather the chains' last metrics rows
+        # ... and (SURVEY 8e ii) the chains' MAP window statistics: mode of A and the renormalised window means of P and E from
+        # bnmf_map on every rank (N + K N + N G doubles per chain), all-gathered like the launcher does at a MAP check
+        mp = chain.map(min(args.window, 200), None) if args.window > 0 else None
+        gathered_map = None
+        if mp is not None:
+            vec = np.concatenate([np.ravel(mp["A"]), np.ravel(mp["P"], order="F"), np.ravel(mp["E"], order="F")]).reshape(1, -1)
+            gathered_map = gather_rows(vec, dist, device=tdev)
     tmed = float(np.median(rep_dt))
 
     out = None
@@ -380,7 +387,8 @@ def main():
             cz.close()
         if gathered is not None:
             out["chains_final_logposterior"] = [float(g[0][4]) for g in gathered]
-            out["collectives"] = {"backend": "gloo" if rehearse else "nccl (RCCL)", "world": world, "forced_on_one_rank": bool(args.force_dist and world == 1)}
+            out["collectives"] = {"backend": "gloo" if rehearse else "nccl (RCCL)", "world": world, "forced_on_one_rank": bool(args.force_dist and world == 1),
+                                  "gathered": ["last metrics row per chain"] + ([f"MAP window statistics per chain ({gathered_map.shape[2]} doubles)"] if gathered_map is not None else [])}
     chain.close()
     if rank == 0:
         if world == 1 and not args.no_secondary:

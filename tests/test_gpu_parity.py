@@ -839,3 +839,35 @@ def test_sorted_schedule_kernel_matches_register_kernel(K, G, N, packed, monkeyp
             assert np.array_equal(e0.get(nm).view(np.uint64), e1.get(nm).view(np.uint64)), (nm, it)
     assert (e1.get("ZsumK").sum(0) == M.sum(0)).all()
     e0.close(); e1.close()
+
+
+@pytest.mark.parametrize("K,G,N", [(96, 3000, 20), (200, 130, 7), (96, 64, 24), (33, 700, 3), (24, 501, 5), (120, 301, 12)])
+def test_sorted_schedule_kernel_save_Z_matches_register_kernel(K, G, N, monkeypatch):
+    """save_Z on the sorted schedule (round 4: an item is a whole cell, the lane's histogram is the cell's Z, non-zero entries stored
+    over a zero fill) against k_zalloc_reg<save_Z> (BNMF_ZSORT=0) on the same chain: Z itself, ZsumK, ZsumG, metrics, P, E bit for
+    bit on the six shapes of the stats-mode test (one cell of 3,000 counts: 750 quads in one lane), and Z against M."""
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import apply_hyperprior_params
+    rng = np.random.default_rng(K + G)
+    M = rng.poisson(rng.gamma(0.7, 60.0, size=(K, G))).astype(np.int32)
+    M[rng.uniform(size=M.shape) < 0.05] = 0
+    M[0, 0] = 3000
+
+    def mk(zs):
+        monkeypatch.setenv("BNMF_ZSORT", zs)
+        e = Engine(M, N, prior="gamma", seed=5, save_Z=True)
+        apply_hyperprior_params(e, "gamma", M, N)
+        return e
+    e0, e1 = mk("0"), mk("1")
+    r0, r1 = e0.init(), e1.init()
+    assert np.array_equal(r0[:9].view(np.uint64), r1[:9].view(np.uint64))
+    for it in range(3):
+        m0, m1 = e0.run(2), e1.run(2)
+        assert np.array_equal(m0[:, :9].view(np.uint64), m1[:, :9].view(np.uint64)), it
+        for nm in ("Z", "ZsumK", "ZsumG"):
+            assert np.array_equal(e0.get(nm), e1.get(nm)), (nm, it)
+        for nm in ("P", "E"):
+            assert np.array_equal(e0.get(nm).view(np.uint64), e1.get(nm).view(np.uint64)), (nm, it)
+    Z = e1.get("Z")
+    assert (Z.sum(1) == M).all() and (Z.sum(0) == e1.get("ZsumK")).all() and (Z.sum(2) == e1.get("ZsumG")).all()
+    e0.close(); e1.close()

@@ -19,7 +19,7 @@ def test_run_rank_over_a_world_of_one_nccl_rank(tmp_path):
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 1000), RANK="0", WORLD_SIZE="1",
                           HSA_ENABLE_IPC_MODE_LEGACY="0")
         import numpy as np, torch, torch.distributed as dist
-        from bayesnmf_amd.multichain import run_rank, gather_rows, all_converged
+        from bayesnmf_amd.multichain import run_rank, gather_rows, all_converged, gather_window
         from bayesnmf_amd.convergence import new_convergence_control
         from bayesnmf_amd.setup import synth_counts
         torch.cuda.set_device(0)
@@ -33,6 +33,13 @@ def test_run_rank_over_a_world_of_one_nccl_rank(tmp_path):
         got = sync.metrics(0)[:, :9]
         assert got.shape == own.shape and np.array_equal(np.nan_to_num(got), np.nan_to_num(own)), "rows gathered over RCCL differ from the chain's own"
         assert sync.n_collectives >= 5 and sync.done == [True]
+        # SURVEY 8e (ii) / (iii) over RCCL: the chain's MAP at every check and at its end, and its last samples
+        assert len(sync.maps[0]) == len(s.state["MAP_metrics"]) + 1 and sync.maps[0][-1]["iter"] == s.state["iter"]
+        keep = np.asarray(s.MAP["keep_sigs"], dtype=int)
+        assert np.array_equal(sync.maps[0][-1]["P"][:, keep], np.asarray(s.MAP["P"])) and np.array_equal(sync.maps[0][-1]["E"][keep, :], np.asarray(s.MAP["E"]))
+        win = gather_window(s, dist, what=("P", "E"), last_n=4, device="cuda")
+        assert win["P"].shape == (1, 4, 96, 3) and win["E"].shape == (1, 4, 3, 400)
+        assert np.array_equal(win["E"][0, -1], np.asarray(s._chain.window("E", 1)[0]))
         g = gather_rows(np.arange(6.0).reshape(2, 3), dist, device="cuda")
         assert g.shape == (1, 2, 3) and np.array_equal(g[0], np.arange(6.0).reshape(2, 3))
         t = torch.tensor([3.5], dtype=torch.float64, device="cuda")

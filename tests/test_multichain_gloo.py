@@ -26,7 +26,7 @@ def _worker(rank, world, port, out, tmp):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
-    from bayesnmf_amd.multichain import run_rank, chain_seed, gather_rows, all_converged
+    from bayesnmf_amd.multichain import run_rank, chain_seed, gather_rows, all_converged, gather_window
     from test_abi_host import _OracleChain
     dist.init_process_group("gloo", rank=rank, world_size=world)
     M, _, _ = _data()
@@ -36,11 +36,24 @@ def _worker(rank, world, port, out, tmp):
     own = s.state["sample_metrics"].to_numpy()[1:, :]                       # rows of iterations 2.. (9 columns)
     flag = all_converged(s.state["converged"], dist)
     g = gather_rows(np.full((1, 2), float(rank)), dist)
+    win = gather_window(s, dist, what=("P", "E"), last_n=5)                   # the chains' last samples on every rank
+    own_win = np.stack([np.asarray(x, dtype=np.float64) for x in s._chain.window("P", 5)])
+
+    def full(mp):                                                            # a MAP with excluded signatures as zero columns / rows
+        keep = np.asarray(mp["keep_sigs"], dtype=int)
+        P = np.zeros((s.dims["K"], s.dims["N"])); P[:, keep] = mp["P"]
+        E = np.zeros((s.dims["N"], s.dims["G"])); E[keep, :] = mp["E"]
+        return P, E
+    n_checks = len(s.state["MAP_metrics"])
     if rank == 0:
         out.put(dict(own=own, mine=sync.metrics(0), other=sync.metrics(1), iters=[s.state["iter"]], conv=list(sync.converged),
-                     done=list(sync.done), n_coll=sync.n_collectives, flag=flag, g=g, seeds=(chain_seed(7, 0), chain_seed(7, 1))))
+                     done=list(sync.done), n_coll=sync.n_collectives, flag=flag, g=g, seeds=(chain_seed(7, 0), chain_seed(7, 1)),
+                     n_checks0=n_checks, map_iters=[[m["iter"] for m in sync.maps[c]] for c in range(2)], own_final=full(s.MAP),
+                     held_final=[(sync.maps[c][-1]["P"], sync.maps[c][-1]["E"], sync.maps[c][-1]["A"]) for c in range(2)],
+                     win_P=win["P"], own_win=own_win))
     else:
-        out.put(dict(rank1_own=own, n_coll=sync.n_collectives, iters=[s.state["iter"]]))
+        out.put(dict(rank1_own=own, n_coll=sync.n_collectives, iters=[s.state["iter"]], n_checks1=n_checks, rank1_final=full(s.MAP),
+                     rank1_win=own_win, rank1_held0=sync.maps[0][-1]["P"]))
     dist.barrier()
     dist.destroy_process_group()
     s.close()
@@ -65,6 +78,17 @@ def test_two_chains_through_the_launcher(tmp_path):
     assert not np.array_equal(r0["mine"][:5, 1], r0["other"][:5, 1])       # different chain_id -> different chains
     assert r0["g"].shape == (2, 1, 2) and r0["g"][1, 0, 0] == 1.0
     assert r0["seeds"][0] != r0["seeds"][1]
+    # rank 0 holds BOTH chains' MAPs (mode of A, window means of P and E) — one per check of each chain plus the
+    # final one that travels with its `done` message — and they are the chains' own
+    assert len(r0["map_iters"][0]) == r0["n_checks0"] + 1 and len(r0["map_iters"][1]) == r1["n_checks1"] + 1
+    assert r0["map_iters"][0][-1] == 120 and r0["map_iters"][1][-1] == 200
+    for c, (P, E) in ((0, r0["own_final"]), (1, r1["rank1_final"])):
+        assert np.array_equal(r0["held_final"][c][0], P) and np.array_equal(r0["held_final"][c][1], E)
+        assert r0["held_final"][c][2].shape == (2,) and set(np.unique(r0["held_final"][c][2])) <= {0.0, 1.0}
+    assert np.array_equal(r1["rank1_held0"], r0["own_final"][0])            # ... and so does every other rank
+    # the final samples of both chains on rank 0
+    assert r0["win_P"].shape == (2, 5, 24, 2)
+    assert np.array_equal(r0["win_P"][0], r0["own_win"]) and np.array_equal(r0["win_P"][1], r1["rank1_win"])
 
 
 def test_chains_in_one_process_threads(tmp_path):
