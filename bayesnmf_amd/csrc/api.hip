@@ -3,6 +3,7 @@
 // (R/bayesNMF_sampler.R:273-285) and of the constructor draws (:232-257).  There is no CPU path.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -12,6 +13,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "kernels.h"
 #include "zalloc_reg.h"
@@ -33,7 +35,8 @@ static int fail(int code, const char* fmt, ...) {
 enum { KN_PDRAW = 0, KN_EDRAW = 1, KN_ZALLOC = 2, KN_REDUCE = 3, KN_SIDE = 4, KN_RANK = 5, KN_MH = 6, KN_OTHER = 7 };
 static const char* k_names[BNMF_NKERNEL] = {"k_pdraw", "k_edraw", "k_zalloc", "k_reduce", "k_side", "k_rank", "k_mh", "other"};
 
-struct Arr { double* d = nullptr; size_t n = 0; int stride = 1; bool set = false; std::vector<int> redraw; double* ring = nullptr; };
+struct Arr { double* d = nullptr; size_t n = 0; int stride = 1; bool set = false; std::vector<int> redraw; double* ring = nullptr;
+             bool slab = false; };   // slab: d points into the handle's block of scalars (a broadcast hyper-prior value), not an allocation of its own
 
 struct bnmf_handle {
   bnmf_config cfg{};
@@ -45,6 +48,7 @@ struct bnmf_handle {
   bool side_valid = false;             // k_side of iteration iter+1 has been issued
   int gate_forced = -1;                // BNMF_GATE at bnmf_create: 0 / 1 forces the merged draw kernel off / on, else by size
   int draw_bw = 0;                     // lanes per workgroup of the merged draw kernel (chosen at the first launch)
+  double* dScal = nullptr;              // [BNMF_ID_MAX] broadcast scalars of bnmf_set_array (hyper-prior values given as one number)
   unsigned* dDrawOwn = nullptr; unsigned draw_seq = 0;   // k_draw: owner word per column of P, launch sequence number (kernels.h)
   int dbg_draw_no_p = 0;               // BNMF_DEBUG_DRAW_NO_P (tests): the P workgroups of k_draw leave without claiming their columns
   int dbg_side_delay_us = 0;           // BNMF_DEBUG_SIDE_DELAY_US (tests): a delay kernel in front of the P-side hyper sweep of launch_side_merged
@@ -287,37 +291,55 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   std::vector<ZSBlock> blocks(nb);
   std::vector<int> cols;
   std::vector<uint32_t> items;
-  std::vector<std::pair<int, uint32_t>> tmp;
   // two factors per word in the block's zG / zK tables (16-bit halves): only if no half can overflow, i.e. every column total
   // (bound of a ZsumK entry) and every row total over a block's columns (bound of the block's share of a ZsumG entry) < 2^16
   bool pk = ctot[order[0]] < 65536;
-  for (int b = 0; b < nb && pk; ++b)
-    for (size_t k = 0; k < K && pk; ++k) { long r = 0; for (int g : bcols[b]) r += M[k + K * (size_t)g]; if (r >= 65536) pk = false; }
+  // the blocks are independent: their item lists are built by a few host threads (the schedule was 20 of the 50 ms of bnmf_create
+  // at the metric configuration)
+  std::vector<std::vector<uint32_t>> bitems(nb);
+  std::vector<char> bpk(nb, 1);
+  auto build_blocks = [&](long b0, long b1) {
+    std::vector<std::pair<int, uint32_t>> tmp;
+    for (long b = b0; b < b1; ++b) {
+      std::sort(bcols[b].begin(), bcols[b].end());
+      for (size_t k = 0; k < K && bpk[b]; ++k) { long r = 0; for (int g : bcols[b]) r += M[k + K * (size_t)g]; if (r >= 65536) bpk[b] = 0; }
+      tmp.clear();
+      for (size_t gl = 0; gl < bcols[b].size(); ++gl) {
+        const size_t g = (size_t)bcols[b][gl];
+        for (size_t k = 0; k < K; ++k) {
+          const int m = M[k + K * g];
+          if (m <= 0) continue;
+          const int qt = (m + 3) >> 2;
+          for (int f = 0; f * ZS_QMAX < qt; ++f)
+            tmp.push_back({std::min(ZS_QMAX, qt - f * ZS_QMAX), (uint32_t)k | ((uint32_t)gl << 10) | ((uint32_t)f << 16)});
+        }
+      }
+      std::stable_sort(tmp.begin(), tmp.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+      // inside a task (64 consecutive items) the order is free: ascending row, so that neighbouring lanes read neighbouring
+      // rows of the LDS copy of P and add to neighbouring words of the block's ZsumG table (few bank conflicts)
+      for (size_t i0 = 0; i0 < tmp.size(); i0 += 64)
+        std::sort(tmp.begin() + i0, tmp.begin() + std::min(tmp.size(), i0 + 64), [](const auto& a, const auto& b) { return (a.second & 1023u) < (b.second & 1023u); });
+      std::vector<uint32_t>& it = bitems[b];
+      it.reserve(tmp.size() + 64);
+      for (const auto& x : tmp) it.push_back(x.second);
+      while (it.size() % 64) it.push_back(0xFFFFFFFFu);
+    }
+  };
+  {
+    const long nthr = std::max<long>(1, std::min<long>({(long)std::thread::hardware_concurrency(), 16L, nb}));
+    std::vector<std::thread> pool;
+    for (long i = 1; i < nthr; ++i) pool.emplace_back(build_blocks, nb * i / nthr, nb * (i + 1) / nthr);
+    build_blocks(0, nb / nthr);
+    for (auto& th : pool) th.join();
+  }
+  for (int b = 0; b < nb; ++b) pk = pk && bpk[b];
   if (const char* e = getenv("BNMF_ZSPK")) pk = pk && atoi(e) != 0;                 // diagnostics / tests: 0 = one factor per word
   std::vector<int32_t> Mblk(K * G);
   for (int b = 0; b < nb; ++b) {
-    std::sort(bcols[b].begin(), bcols[b].end());
-    tmp.clear();
-    for (size_t gl = 0; gl < bcols[b].size(); ++gl) {
-      const size_t g = (size_t)bcols[b][gl];
-      for (size_t k = 0; k < K; ++k) {
-        const int m = M[k + K * g];
-        if (m <= 0) continue;
-        const int qt = (m + 3) >> 2;
-        for (int f = 0; f * ZS_QMAX < qt; ++f)
-          tmp.push_back({std::min(ZS_QMAX, qt - f * ZS_QMAX), (uint32_t)k | ((uint32_t)gl << 10) | ((uint32_t)f << 16)});
-      }
-    }
-    std::stable_sort(tmp.begin(), tmp.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
     ZSBlock& bk = blocks[b];
     bk.item0 = (int)items.size(); bk.col0 = (int)cols.size(); bk.ncols = (int)bcols[b].size();
-    // inside a task (64 consecutive items) the order is free: ascending row, so that neighbouring lanes read neighbouring
-    // rows of the LDS copy of P and add to neighbouring words of the block's ZsumG table (few bank conflicts)
-    for (size_t i0 = 0; i0 < tmp.size(); i0 += 64)
-      std::sort(tmp.begin() + i0, tmp.begin() + std::min(tmp.size(), i0 + 64), [](const auto& a, const auto& b) { return (a.second & 1023u) < (b.second & 1023u); });
-    for (const auto& it : tmp) items.push_back(it.second);
-    while (items.size() % 64) items.push_back(0xFFFFFFFFu);
-    bk.ntask = (int)((items.size() - (size_t)bk.item0) / 64);
+    items.insert(items.end(), bitems[b].begin(), bitems[b].end());
+    bk.ntask = (int)(bitems[b].size() / 64);
     for (int g : bcols[b]) { memcpy(Mblk.data() + K * cols.size(), M + K * (size_t)g, K * sizeof(int32_t)); cols.push_back(g); }
   }
   if (items.empty()) items.push_back(0xFFFFFFFFu);
@@ -461,11 +483,70 @@ static int build_zstep(bnmf_handle* h, const int32_t* M, int n_cu) {
   return 0;
 }
 
+// BNMF_TIMING=1 (diagnostics): wall-clock marks of bnmf_create on stderr
+struct CreateClock {
+  bool on = getenv("BNMF_TIMING") != nullptr; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void mark(const char* what) { if (!on) return; const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[bnmf_create] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count()); t0 = t; }
+};
+// A handle's three streams come from a per-device pool and go back to it at bnmf_destroy: creating a stream and bringing its
+// hardware queue up at the first submission cost 15-30 ms of a 50 ms bnmf_create (a BIC sweep creates one handle per rank).
+static std::mutex g_stream_mtx;
+static std::vector<hipStream_t> g_stream_pool[64];
+static int take_stream(int device, hipStream_t* out) {
+  {
+    std::lock_guard<std::mutex> lock(g_stream_mtx);
+    auto& v = g_stream_pool[device];
+    if (!v.empty()) { *out = v.back(); v.pop_back(); return 0; }
+  }
+  HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+  return 0;
+}
+static void give_stream(int device, hipStream_t st) {
+  if (!st) return;
+  std::lock_guard<std::mutex> lock(g_stream_mtx);
+  g_stream_pool[device].push_back(st);
+}
+// The record_sample rings (gigabytes per handle) go back to a per-device cache at bnmf_destroy and are handed to the next handle
+// that asks for the same size: releasing them and mapping new ones stalled the first kernel of the next bnmf_create by 20-30 ms (a
+// BIC sweep, or bayesNMF() called in a loop, creates handle after handle of the same shape).  At most BNMF_RING_CACHE_GB (default
+// 32, 0 = off) stay cached per device, oldest out first.
+struct CachedBuf { void* p; size_t bytes; };
+static std::mutex g_ring_mtx;
+static std::vector<CachedBuf> g_ring_cache[64];
+static size_t ring_cache_cap() { const char* e = getenv("BNMF_RING_CACHE_GB"); return (size_t)((e ? atof(e) : 32.0) * 1e9); }
+static int ring_alloc(int device, size_t bytes, double** out) {
+  {
+    std::lock_guard<std::mutex> lock(g_ring_mtx);
+    auto& v = g_ring_cache[device];
+    for (size_t i = v.size(); i-- > 0;) if (v[i].bytes == bytes) { *out = (double*)v[i].p; v.erase(v.begin() + (long)i); return 0; }
+  }
+  HIPCHK(hipMalloc(out, bytes));
+  return 0;
+}
+static void ring_release(int device, void* p, size_t bytes) {
+  if (!p) return;
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> lock(g_ring_mtx);
+    auto& v = g_ring_cache[device];
+    const size_t cap = ring_cache_cap();
+    if (bytes > cap || bytes < ((size_t)1 << 20)) drop.push_back(p);        // small rings are not worth keeping
+    else {
+      v.push_back({p, bytes});
+      size_t tot = 0;
+      for (const auto& c : v) tot += c.bytes;
+      while (tot > cap && !v.empty()) { tot -= v.front().bytes; drop.push_back(v.front().p); v.erase(v.begin()); }
+    }
+  }
+  for (void* q : drop) hipFree(q);
+}
 static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h) {
   const size_t K = cfg->K, G = cfg->G, N = cfg->N;
-  HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+  CreateClock clk;
+  if (int rc = take_stream(h->device, &h->stream)) return rc;
+  if (int rc = take_stream(h->device, &h->side)) return rc;
+  if (int rc = take_stream(h->device, &h->side2)) return rc;
+  clk.mark("streams");
   HIPCHK(hipEventCreateWithFlags(&h->ev_draw, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_sideP, hipEventDisableTiming));
@@ -473,8 +554,10 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   HIPCHK(hipEventCreateWithFlags(&h->ev_rank, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_z, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_red, hipEventDisableTiming));
+  clk.mark("events");
   HIPCHK(hipMalloc(&h->dM, K * G * sizeof(int32_t)));
   HIPCHK(hipMemcpy(h->dM, M, K * G * sizeof(int32_t), hipMemcpyHostToDevice));
+  clk.mark("M to the device");
   int mx = 0;
   for (size_t i = 0; i < K * G; ++i) { if (M[i] < 0) return fail(BNMF_EINVAL, "bnmf_create: negative count in M"); if (M[i] > mx) mx = M[i]; }
   h->maxM = mx;
@@ -496,6 +579,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   }
   HIPCHK(hipMalloc(&h->dFlags, 64));
   HIPCHK(hipMemset(h->dFlags, 0, 64));
+  HIPCHK(hipMalloc(&h->dScal, BNMF_ID_MAX * sizeof(double)));
   HIPCHK(hipMalloc(&h->dDrawOwn, N * sizeof(unsigned)));
   HIPCHK(hipMemset(h->dDrawOwn, 0, N * sizeof(unsigned)));
   HIPCHK(hipHostMalloc((void**)&h->hErr, 64, hipHostMallocMapped));
@@ -577,6 +661,11 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   HIPCHK(hipMalloc(&h->dRaw, h->metrics_rows * 8 * sizeof(double)));
   hipLaunchKernelGGL(k_luts, dim3((mx + 256) / 256), dim3(256), 0, h->stream, h->dLut, h->dLut + (mx + 1), mx);
   HIPCHK(hipGetLastError());
+  clk.mark("small buffers, tables");
+  // wait for the tables now: left to the end of this function, the wait cost 20-25 ms on every bnmf_create after the first of a
+  // process (the launch sat unsubmitted behind the allocations and copies of the schedule)
+  HIPCHK(hipStreamSynchronize(h->stream));
+  clk.mark("tables kernel done");
   // Allocation-kernel geometry: independent waves, one LDS slab per wave, zacc (and P) shared per workgroup.
   // N <= 24 takes k_zalloc_reg (zalloc_reg.h), larger N the general LDS-search kernel k_zalloc (kernels.h).
   {
@@ -693,8 +782,10 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
     if (const char* e = getenv("BNMF_ABLATE")) h->z_ablate = atoi(e);       // diagnostics only
     if (!h->z_tile && !h->z_step && !h->z_ablate) if (int rc = build_zsort(h, M, prop.multiProcessorCount)) return rc;
   }
+  clk.mark("allocation-kernel schedule");
   HIPCHK(hipStreamSynchronize(h->stream));
   refresh_dev(h);
+  clk.mark("drain");
   return 0;
 }
 
@@ -704,7 +795,11 @@ int bnmf_destroy(bnmf_handle* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->side) hipStreamSynchronize(h->side);
   if (h->side2) hipStreamSynchronize(h->side2);
-  for (auto& a : h->arr) { if (a.d) hipFree(a.d); if (a.ring) hipFree(a.ring); }
+  for (int id = 0; id < BNMF_ID_MAX; ++id) {
+    Arr& a = h->arr[id];
+    if (a.d && !a.slab) hipFree(a.d);
+    if (a.ring) ring_release(h->device, a.ring, (size_t)h->wcap * id_len(h, id) * sizeof(double));
+  }
   hipFree(h->dM); hipFree(h->dZsumK); hipFree(h->dZsumG); if (h->dZ) hipFree(h->dZ);
   hipFree(h->dR); hipFree(h->dRedraw); hipFree(h->dEsum); hipFree(h->dPsum); hipFree(h->dlpPn);
   hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); if (h->hMetrics) hipHostFree(h->hMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol); if (h->dRankMhat) hipFree(h->dRankMhat); if (h->dRankSync) hipFree(h->dRankSync);
@@ -715,12 +810,12 @@ int bnmf_destroy(bnmf_handle* h) {
   if (h->dZsItems) hipFree(h->dZsItems); if (h->dZsBlocks) hipFree(h->dZsBlocks); if (h->dZsCols) hipFree(h->dZsCols); if (h->dZsProf) hipFree(h->dZsProf); if (h->dZsM) hipFree(h->dZsM); if (h->dZsRec) hipFree(h->dZsRec);
   if (h->dMhat) hipFree(h->dMhat); if (h->dAccPn) hipFree(h->dAccPn); if (h->dAccEpart) hipFree(h->dAccEpart); if (h->dNzE) hipFree(h->dNzE);
   if (h->dEt) hipFree(h->dEt); if (h->dMt) hipFree(h->dMt); if (h->zring) hipFree(h->zring);
-  if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_rank) hipEventDestroy(h->ev_rank); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); if (h->side) hipStreamDestroy(h->side); if (h->side2) hipStreamDestroy(h->side2);
+  if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_rank) hipEventDestroy(h->ev_rank); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); give_stream(h->device, h->side); give_stream(h->device, h->side2);
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
   if (h->dMap) hipFree(h->dMap);
   if (h->dAsg) hipFree(h->dAsg);
-  if (h->dFlags) hipFree(h->dFlags); if (h->dDrawOwn) hipFree(h->dDrawOwn); if (h->hErr) hipHostFree(h->hErr);
-  if (h->stream) hipStreamDestroy(h->stream);
+  if (h->dFlags) hipFree(h->dFlags); if (h->dDrawOwn) hipFree(h->dDrawOwn); if (h->dScal) hipFree(h->dScal); if (h->hErr) hipHostFree(h->hErr);
+  give_stream(h->device, h->stream);                    // synchronised at the top of this function
   delete h;
   return 0;
 }
@@ -747,8 +842,10 @@ int bnmf_set_array(bnmf_handle* h, int id, const double* x, size_t n) {
   }
   Arr& a = h->arr[id];
   if (is_hyper(id) && n == 1) {
-    if (a.d) { HIPCHK(hipFree(a.d)); a.d = nullptr; }
-    HIPCHK(hipMalloc(&a.d, sizeof(double)));
+    // a broadcast scalar lives in the handle's block of scalars: the eight device allocations of the default hyper-prior values
+    // were 20 ms of a bayesNMF() call
+    if (a.d && !a.slab) HIPCHK(hipFree(a.d));
+    a.d = h->dScal + id; a.slab = true;
     HIPCHK(hipMemcpy(a.d, x, sizeof(double), hipMemcpyHostToDevice));
     a.n = 1; a.stride = 0; a.set = true;
     refresh_dev(h);
@@ -756,7 +853,7 @@ int bnmf_set_array(bnmf_handle* h, int id, const double* x, size_t n) {
   }
   if (n != len) return fail(BNMF_ESIZE, "bnmf_set_array: id %d expects %zu values, got %zu", id, len, n);
   const size_t nslot = is_prior_param(id) ? 2 : 1;
-  if (a.d && a.n != len) { HIPCHK(hipFree(a.d)); a.d = nullptr; }
+  if (a.d && (a.n != len || a.slab)) { if (!a.slab) HIPCHK(hipFree(a.d)); a.d = nullptr; a.slab = false; }
   if (!a.d) HIPCHK(hipMalloc(&a.d, nslot * len * sizeof(double)));
   HIPCHK(hipMemcpy(a.d + (nslot == 2 ? (size_t)cur_slot(h) * len : 0), x, len * sizeof(double), hipMemcpyHostToDevice));
   a.n = len; a.stride = 1; a.set = true;
@@ -1175,7 +1272,7 @@ static int ensure_rings(bnmf_handle* h) {
   h->wcap = h->cfg.window + 1;
   for (int id : recorded_ids(h)) {
     Arr& a = h->arr[id];
-    if (!a.ring) HIPCHK(hipMalloc(&a.ring, (size_t)h->wcap * id_len(h, id) * sizeof(double)));
+    if (!a.ring) if (int rc = ring_alloc(h->device, (size_t)h->wcap * id_len(h, id) * sizeof(double), &a.ring)) return rc;
   }
   if (h->dZ && !h->zring) {                                // samples$Z (R/bayesNMF_sampler.R:245-252): K*N*G ints per kept sample
     const double gb = (double)h->wcap * (double)id_len(h, BNMF_Z) * 4.0 / 1e9;
@@ -1681,9 +1778,13 @@ int bnmf_map(bnmf_handle* h, int last_n, double ci, double* P_mean, double* E_me
     const double hl = (nu - 1) * plo, hh = (nu - 1) * phi;
     jlo = (int)std::floor(hl); glo = hl - jlo; jhi = (int)std::floor(hh); ghi = hh - jhi;
     kt = std::min(nu, std::max(jlo + 2, nu - jhi));
-    if ((size_t)kt * 2 * 64 * sizeof(double) > 160 * 1024)
-      return fail(BNMF_EINVAL, "bnmf_map: credible_interval %.3g over %d samples needs %d order statistics per element (device limit 160): take the window with bnmf_window", ci, nu, kt);
   }
+  // the bounds by sorting (k_map_quant) when the samples of 8 elements fit the LDS; else by the kt smallest / largest per lane
+  int qS = 0;
+  if (want_ci) { qS = ((nu + 63) / 64) * 64; if ((size_t)qS * MQ_E * sizeof(double) > 128 * 1024) qS = 0; }
+  if (want_ci && !qS && (size_t)kt * 2 * 64 * sizeof(double) > 160 * 1024)
+    return fail(BNMF_EINVAL, "bnmf_map: credible_interval %.3g over %d samples needs %d order statistics per element (device limit 160): take the window with bnmf_window", ci, nu, kt);
+  if (qS) kt = 0;                                          // k_map_stats then computes the means only
   const size_t words = (size_t)nu * N + 3 * (lenP + lenE) + 2 * (size_t)G + N + ((size_t)nu + 1) / 2 + 8;
   if (words > h->map_words) { if (h->dMap) HIPCHK(hipFree(h->dMap)); h->dMap = nullptr; HIPCHK(hipMalloc(&h->dMap, words * sizeof(double))); h->map_words = words; }
   double* cs = h->dMap; double* mP = cs + (size_t)nu * N; double* loP = mP + lenP; double* hiP = loP + lenP;
@@ -1701,6 +1802,17 @@ int bnmf_map(bnmf_handle* h, int last_n, double ci, double* P_mean, double* E_me
                      (const int*)dslots, nu, (const double*)cs, kt, jlo, glo, jhi, ghi, mP, loP, hiP);
   hipLaunchKernelGGL(k_map_stats<1>, dim3((unsigned)((lenE + 63) / 64)), dim3(64), lds, h->stream, (const double*)h->arr[BNMF_E].ring, lenE, K, N,
                      (const int*)dslots, nu, (const double*)cs, kt, jlo, glo, jhi, ghi, mE, loE, hiE);
+  if (qS) {
+    const size_t qlds = (size_t)qS * MQ_E * sizeof(double);
+    if (qlds > 64 * 1024) {
+      HIPCHK(hipFuncSetAttribute((const void*)k_map_quant<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)k_map_quant<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    }
+    hipLaunchKernelGGL(k_map_quant<0>, dim3((unsigned)((lenP + MQ_E - 1) / MQ_E)), dim3(MQ_T), qlds, h->stream, (const double*)h->arr[BNMF_P].ring, lenP, K, N,
+                       (const int*)dslots, nu, qS, (const double*)cs, jlo, glo, jhi, ghi, loP, hiP);
+    hipLaunchKernelGGL(k_map_quant<1>, dim3((unsigned)((lenE + MQ_E - 1) / MQ_E)), dim3(MQ_T), qlds, h->stream, (const double*)h->arr[BNMF_E].ring, lenE, K, N,
+                       (const int*)dslots, nu, qS, (const double*)cs, jlo, glo, jhi, ghi, loE, hiE);
+  }
   hipLaunchKernelGGL(k_map_fit, dim3((G + 3) / 4), dim3(256), 0, h->stream, (const int32_t*)h->dM, (const double*)mP, (const double*)dA, (const double*)mE, K, N, G, colsse, colkl);
   HIPCHK(hipGetLastError());
   if (P_mean) HIPCHK(hipMemcpyAsync(P_mean, mP, lenP * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -893,6 +893,107 @@ __global__ __launch_bounds__(64) void k_map_stats(const double* ring, size_t len
     upper[e] = (1.0 - ghi) * hi[(jhi - base) * 64] + ghi * hi[(jh1 - base) * 64];
   }
 }
+// ---- k_map_quant: the credible bounds of get_MAP_ (R/utils.R:269-284, quantile type 7) by a wave per element (round 4) ----
+// k_map_stats keeps the kt smallest / largest values of an element per LANE, and some lane of the wave replaces one at nearly
+// every sample: the whole wave then walks the kt-entry scan (7.5 ms for 202,000 elements x 1,000 samples).  Here a workgroup
+// takes 8 consecutive elements: their samples are read as whole 64-byte lines (sample s: elements e0 .. e0 + 7), renormalised
+// (the same expression as k_map_stats) and laid out [element][S] in LDS (S: n_used rounded up to whole rounds of 64).  A wave
+// takes two of the elements in turn: lane l sorts its own samples l, l + 64, ... (a column of <= 32 values), then the order
+// statistics needed — a few dozen from each end at the default interval — are drawn one by one as the minimum (maximum) over the
+// lanes' column heads.  The same values, the same interpolation.
+constexpr int MQ_T = 256, MQ_E = 8;
+// minimum / maximum over the wave on every lane: wave_tree64's exchanges (v_permlane32_swap, v_permlane16_swap, DPP row shifts: no
+// LDS crossbar, a tenth of the latency of six ds_bpermute round trips) with min / max for +, then lane 0's value through the scalar unit
+#define BNMF_WAVE_EXTREMUM(NAME, PICK)                                                                             \
+BNMF_DEV double NAME(double v) {                                                                                   \
+  {                                                                                                                \
+    const unsigned lo = (unsigned)__double_as_longlong(v), hi = (unsigned)(__double_as_longlong(v) >> 32);         \
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);                                         \
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);                                         \
+    const double w = __longlong_as_double(((long long)b[1] << 32) | (unsigned)a[1]);                               \
+    v = PICK;                                                                                                      \
+  }                                                                                                                \
+  {                                                                                                                \
+    const unsigned lo = (unsigned)__double_as_longlong(v), hi = (unsigned)(__double_as_longlong(v) >> 32);         \
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);                                         \
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);                                         \
+    const double w = __longlong_as_double(((long long)b[1] << 32) | (unsigned)a[1]);                               \
+    v = PICK;                                                                                                      \
+  }                                                                                                                \
+  _Pragma("unroll")                                                                                                \
+  for (int st = 0; st < 4; ++st) {                                                                                 \
+    int lo = (int)__double_as_longlong(v), hi = (int)(__double_as_longlong(v) >> 32);                              \
+    if (st == 0) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x108, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x108, 0xf, 0xf, false); } \
+    if (st == 1) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x104, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x104, 0xf, 0xf, false); } \
+    if (st == 2) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x102, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x102, 0xf, 0xf, false); } \
+    if (st == 3) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x101, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x101, 0xf, 0xf, false); } \
+    const double w = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);                                   \
+    v = PICK;                                                                                                      \
+  }                                                                                                                \
+  return wave_bcast0(v);                                                                                           \
+}
+BNMF_WAVE_EXTREMUM(wave_min_all, (w < v ? w : v))
+BNMF_WAVE_EXTREMUM(wave_max_all, (w > v ? w : v))
+#undef BNMF_WAVE_EXTREMUM
+template <int SIDE>
+__global__ __launch_bounds__(MQ_T) void k_map_quant(const double* ring, size_t len, int K, int N, const int* slots, int n_used, int S,
+                                                    const double* cs, int jlo, double glo, int jhi, double ghi, double* lower, double* upper) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* tile = (double*)smem;                           // [MQ_E][S]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t e0 = (size_t)blockIdx.x * MQ_E;
+  {
+    const int j = tid & (MQ_E - 1);
+    const size_t e = e0 + j;
+    const bool live = e < len;
+    const int n = live ? (SIDE ? (int)(e % (size_t)N) : (int)(e / (size_t)K)) : 0;
+    for (int s = tid >> 3; s < n_used; s += MQ_T / MQ_E) {
+      double x = 0.0;
+      if (live) {
+        const double v = ring[(size_t)slots[s] * len + e], c = cs[(size_t)s * N + n];
+        x = SIDE ? v * c : v / c;
+      }
+      tile[(size_t)j * S + s] = x;
+    }
+  }
+  __syncthreads();
+  const int cnt = lane < n_used ? (n_used - lane + 63) >> 6 : 0;      // samples of this lane's column
+  const int jl1 = min(jlo + 1, n_used - 1), jh1 = min(jhi + 1, n_used - 1);
+  for (int q = 0; q < MQ_E / (MQ_T / 64); ++q) {
+    const int j = wave * (MQ_E / (MQ_T / 64)) + q;
+    if (e0 + j >= len) break;                             // wave-uniform
+    double* a = tile + (size_t)j * S + lane;              // a[64 r]: the lane's column
+    lane_sort(a, cnt);
+    wave_lds_fence();
+    double x0 = 0.0, x1 = 0.0, y0 = 0.0, y1 = 0.0;
+    {
+      int p = 0;
+      double hv = cnt > 0 ? a[0] : __builtin_inf();
+      for (int c = 0; c <= jl1; ++c) {                    // order statistics 0 .. jl1 in ascending order
+        const double m = wave_min_all(hv);
+        if (c == jlo) x0 = m;
+        if (c == jl1) x1 = m;
+        const unsigned long long eq = __builtin_amdgcn_ballot_w64(hv == m);
+        if (eq && lane == (int)__builtin_ctzll(eq)) { ++p; hv = p < cnt ? a[64 * p] : __builtin_inf(); }
+      }
+    }
+    {
+      int p = cnt - 1;
+      double hv = cnt > 0 ? a[64 * p] : -__builtin_inf();
+      for (int c = n_used - 1; c >= jhi; --c) {           // order statistics n_used - 1 .. jhi in descending order
+        const double m = wave_max_all(hv);
+        if (c == jh1) y1 = m;
+        if (c == jhi) y0 = m;
+        const unsigned long long eq = __builtin_amdgcn_ballot_w64(hv == m);
+        if (eq && lane == (int)__builtin_ctzll(eq)) { --p; hv = p >= 0 ? a[64 * p] : -__builtin_inf(); }
+      }
+    }
+    if (lane == 0) {
+      lower[e0 + j] = (1.0 - glo) * x0 + glo * x1;
+      upper[e0 + j] = (1.0 - ghi) * y0 + ghi * y1;
+    }
+  }
+}
 // compute_metrics_(P = MAP$P, A = MAP$A, E = MAP$E, MAP = TRUE) (R/utils.R:412-455): per-column squared error and
 // padded KL of Mhat = P diag(A) E; one wave per column
 __global__ __launch_bounds__(256) void k_map_fit(const int32_t* M, const double* P, const double* A, const double* E, int K, int N, int G,

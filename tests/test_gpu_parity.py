@@ -350,11 +350,13 @@ def test_general_allocation_kernels(shape, force, kernel, monkeypatch):
         e.close()
 
 
-@pytest.mark.parametrize("N,excluded", [(30, [0, 29]), (50, list(range(3, 50))), (100, [n for n in range(100) if n % 7]), (64, list(range(64)))])
+@pytest.mark.parametrize("N,excluded", [(30, [0, 29]), (50, list(range(3, 50))), (50, list(range(0, 50, 3)) + list(range(1, 50, 3))), (100, [n for n in range(100) if n % 7]),
+                                        (64, list(range(64)))])
 def test_step_kernel_walks_included_factors_only(N, excluded):
     """k_zalloc_step stages and walks only the factors with A[n] != 0 (an excluded factor adds +0.0 to the running sum and repeats
-    the threshold before it): first and last factor excluded, all but three, six of seven, and every factor excluded (Z = 0,
-    R/sample_params.R:257-261) — ZsumK, ZsumG, P, E and the metric rows bit-exact against the oracle, which walks all N."""
+    the threshold before it): first and last factor excluded, all but three, two of three (16 left: four threshold blocks), six of
+    seven, and every factor excluded (Z = 0, R/sample_params.R:257-261) — ZsumK, ZsumG, P, E and the metric rows bit-exact against
+    the oracle, which walks all N."""
     import oracle as O
     from bayesnmf_amd import Engine
     from bayesnmf_amd.setup import apply_hyperprior_params
