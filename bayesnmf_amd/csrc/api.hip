@@ -168,6 +168,13 @@ static void refresh_dev(bnmf_handle* h) {
   d.lenP = (size_t)c.K * c.N; d.lenE = (size_t)c.N * c.G;
 }
 
+// BNMF_TIMING=1 (diagnostics): wall-clock marks of bnmf_create on stderr
+struct CreateClock {
+  bool on = getenv("BNMF_TIMING") != nullptr; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void mark(const char* what) { if (!on) return; const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[bnmf_create] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count()); t0 = t; }
+};
+__global__ void k_set_scalar(double* p, double v) { *p = v; }
+
 extern "C" {
 
 int bnmf_destroy(bnmf_handle* h);
@@ -483,11 +490,6 @@ static int build_zstep(bnmf_handle* h, const int32_t* M, int n_cu) {
   return 0;
 }
 
-// BNMF_TIMING=1 (diagnostics): wall-clock marks of bnmf_create on stderr
-struct CreateClock {
-  bool on = getenv("BNMF_TIMING") != nullptr; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-  void mark(const char* what) { if (!on) return; const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[bnmf_create] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count()); t0 = t; }
-};
 // A handle's three streams come from a per-device pool and go back to it at bnmf_destroy: creating a stream and bringing its
 // hardware queue up at the first submission cost 15-30 ms of a 50 ms bnmf_create (a BIC sweep creates one handle per rank).
 static std::mutex g_stream_mtx;
@@ -825,9 +827,13 @@ int bnmf_set_array(bnmf_handle* h, int id, const double* x, size_t n) {
   const size_t len = id_len(h, id);
   if (len == 0) return fail(BNMF_EINVAL, "bnmf_set_array: unknown id %d", id);
   HIPCHK(hipSetDevice(h->device));
+  CreateClock clk;
   HIPCHK(hipStreamSynchronize(h->stream));
+  clk.mark("set_array: sync main");
   HIPCHK(hipStreamSynchronize(h->side));
+  clk.mark("set_array: sync side");
   HIPCHK(hipStreamSynchronize(h->side2));
+  clk.mark("set_array: sync side2");
   h->side_valid = false;                 // state changed: the pre-issued k_side must be redone
   h->mh_prep_valid = false;
   if (id == BNMF_R) { int r = (int)x[0]; HIPCHK(hipMemcpy(h->dR, &r, sizeof(int), hipMemcpyHostToDevice)); h->arr[BNMF_R].set = true; return 0; }
@@ -846,7 +852,11 @@ int bnmf_set_array(bnmf_handle* h, int id, const double* x, size_t n) {
     // were 20 ms of a bayesNMF() call
     if (a.d && !a.slab) HIPCHK(hipFree(a.d));
     a.d = h->dScal + id; a.slab = true;
-    HIPCHK(hipMemcpy(a.d, x, sizeof(double), hipMemcpyHostToDevice));
+    // the value travels as a kernel argument: the first small host-to-device copy of a handle created after another one had been
+    // destroyed took 13-24 ms (BNMF_TIMING marks), every time
+    hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, h->stream, a.d, x[0]);
+    HIPCHK(hipGetLastError());
+    clk.mark("set_array: a scalar");
     a.n = 1; a.stride = 0; a.set = true;
     refresh_dev(h);
     return 0;
