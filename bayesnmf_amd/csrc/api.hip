@@ -71,7 +71,7 @@ struct bnmf_handle {
   double* hMetrics = nullptr;          // the metric rows live in mapped host memory (dMetrics is its device address): k_compose writes them
                                        // where the host reads them, no device-to-host copy at the end of a call
   double *dLut = nullptr, *dTemp = nullptr, *dMetrics = nullptr, *dRaw = nullptr, *dRankCol = nullptr, *dRankMhat = nullptr;
-  uint32_t* dRankSync = nullptr; int rank_grid = 0; bool rank_reg = false; void* dRankDbg = nullptr;
+  uint32_t* dRankSync = nullptr; int rank_grid = 0; bool rank_reg = false, rank_half = false; void* dRankDbg = nullptr;
   int32_t* dMt = nullptr; double* dEt = nullptr;
   int32_t* zring = nullptr;            // save_Z with a window: samples$Z, [wcap][K*N*G] int32 (only if it fits BNMF_ZRING_GB, default 32)
   double *dMhat = nullptr, *dAccPn = nullptr, *dAccEpart = nullptr; int* dNzE = nullptr; int mh_S = 1; size_t mhe_lds = 0; int mhe_gw = 0;
@@ -622,10 +622,14 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
     const long cap_reg = (long)fit(nrm0 ? (const void*)k_rank_sweep<true, true> : (const void*)k_rank_sweep<true, false>) * prop0.multiProcessorCount;
     const long cap_gen = (long)fit(nrm0 ? (const void*)k_rank_sweep<false, true> : (const void*)k_rank_sweep<false, false>) * prop0.multiProcessorCount;
     h->rank_reg = K <= 96 && wg_needed <= cap_reg;       // register variant: rows 64..95 of two columns share a register (rank.h)
+    // ... with HALF a block per compute wave where the grid of ten-half-block workgroups is co-resident too (704 lanes, one per CU)
+    const long wg_half = (NB + RK_CWH / 2 - 1) / (RK_CWH / 2);
+    h->rank_half = h->rank_reg && wg_half <= (long)prop0.multiProcessorCount;
+    if (const char* e = getenv("BNMF_RANKHALF")) h->rank_half = h->rank_half && atoi(e) != 0;   // diagnostics / tests: 0 = whole blocks
     // (a wider grid with the blocks dealt wave-major over all CUs was measured: no gain, the sweep is bound by the
     // per-factor exchange, not by VALU contention)
-    h->rank_grid = (int)std::min<long>(wg_needed, h->rank_reg ? cap_reg : cap_gen);
-    if (const char* e = getenv("BNMF_RANKGRID")) { const long v = atol(e); if (v >= wg_needed && v <= (h->rank_reg ? cap_reg : cap_gen)) h->rank_grid = (int)v; }   // diagnostics only
+    h->rank_grid = h->rank_half ? (int)wg_half : (int)std::min<long>(wg_needed, h->rank_reg ? cap_reg : cap_gen);
+    if (const char* e = getenv("BNMF_RANKGRID")) { const long v = atol(e); if (!h->rank_half && v >= wg_needed && v <= (h->rank_reg ? cap_reg : cap_gen)) h->rank_grid = (int)v; }   // diagnostics only
     if (!h->rank_reg) HIPCHK(hipMalloc(&h->dRankMhat, K * G * sizeof(double)));
     if (getenv("BNMF_RANKDBG")) { HIPCHK(hipMalloc(&h->dRankDbg, (size_t)h->rank_grid * 16 * 8 * 8)); HIPCHK(hipMemset(h->dRankDbg, 0, (size_t)h->rank_grid * 16 * 8 * 8)); }   // diagnostics only
   }
@@ -1261,10 +1265,11 @@ static void launch_rank(bnmf_handle* h, uint32_t t, hipEvent_t stop = nullptr, i
   const size_t lds = (3 * (size_t)N + 1) * sizeof(double);            // A, sample_R weights, sample_An uniforms
   const RecDst rr = row >= 0 ? rec_at(h, t, fused_rec(h)) : RecDst{};
   auto go = [&](auto kern) {
-    hipExtLaunchKernelGGL(kern, dim3(h->rank_grid), dim3(RK_T), (uint32_t)lds, h->stream, nullptr, stop, 0, h->dev, t, (unsigned long long*)h->dRankCol, NB, h->dErr + 1, h->dRankMhat, (unsigned long long*)h->dRankDbg, row, rr.A, rr.R);
+    hipExtLaunchKernelGGL(kern, dim3(h->rank_grid), dim3(h->rank_half ? RK_TH : RK_T), (uint32_t)lds, h->stream, nullptr, stop, 0, h->dev, t, (unsigned long long*)h->dRankCol, NB, h->dErr + 1, h->dRankMhat, (unsigned long long*)h->dRankDbg, row, rr.A, rr.R);
   };
   const bool nrm = h->cfg.likelihood == BNMF_NORMAL;
-  if (h->rank_reg) { if (nrm) go(k_rank_sweep<true, true>); else go(k_rank_sweep<true, false>); }
+  if (h->rank_half) { if (nrm) go(k_rank_sweep<true, true, true>); else go(k_rank_sweep<true, false, true>); }
+  else if (h->rank_reg) { if (nrm) go(k_rank_sweep<true, true>); else go(k_rank_sweep<true, false>); }
   else { if (nrm) go(k_rank_sweep<false, true>); else go(k_rank_sweep<false, false>); }
 }
 // ids recorded per iteration (names(self$params) + names(self$prior_params), R/bayesNMF_sampler.R:245-252)

@@ -69,7 +69,7 @@ __global__ void k_rank_Aprior(Dev d, uint32_t t) {
 // and takes the same tempered Bernoulli decision.
 constexpr int RK_T = 512;
 constexpr int RK_W = RK_T / 64;
-constexpr int RK_REP = 8;                                // copies of the granule buffers (see rank_publish)
+constexpr int RK_REP = 1;                                // copies of the granule buffers (see rank_publish)
 constexpr int RK_CW = RK_W - 1;                          // waves that evaluate cells; the last wave of a workgroup gathers, sums and decides
 constexpr int RK_MAXC = 8;                                // columns per block = columns per wave kept in registers (REG variant)
 constexpr unsigned RK_SPIN_LIMIT = 1u << 22;
@@ -117,8 +117,9 @@ BNMF_DEV void rank_publish(unsigned long long* gran /* this lane's copy */, int 
 // the same order as canon_sum(x, NB, 1024).  The granules of a lane's first 32 blocks are requested together (one round trip
 // to the memory side; two in a row — 16 blocks at a time — took 4.1 us per factor) and only those whose tags do not match yet are asked for again.  The sum is valid on lane 0.
 typedef unsigned int __attribute__((ext_vector_type(4))) rk_uv4;
+template <int GB /* blocks per lane and round: 32 (NB <= 2,048: ONE round trip), or 24 where registers are short (NB <= 1,536) */>
 BNMF_DEV bool rank_gather_sum(const unsigned long long* gran, int NB, unsigned tag, int* err, int lane, double& sum, unsigned& rounds) {
-  constexpr int GB = 32;                                  // blocks per lane and round (NB <= 2,048: ONE round trip)
+  static_assert(GB == 32 || GB == 24, "blocks per round");
   // a block's two granules in ONE 16-byte load (agent scope: sc1, as the 8-byte atomic loads; each granule carries its own tag, so
   // the two halves may be torn against each other).  The buffer descriptor bounds the loads: a lane beyond the last block reads
   // zeros — tag 0 is never used, the value +0.0 adds nothing — so the first round is straight-line code: the requests back to back,
@@ -128,6 +129,7 @@ BNMF_DEV bool rank_gather_sum(const unsigned long long* gran, int NB, unsigned t
 #pragma unroll
   for (int j = 0; j < 16; ++j) acc[j] = 0.0;
   bool bad = false;
+  int rot = 0;
   for (int base = 0; base < NB && !bad; base += 64 * GB) {
     rk_uv4 hv[GB];
     const int nj = min(GB, (NB - base + 63) >> 6);        // wave-uniform: rounds of 64 blocks that hold a block at all
@@ -159,6 +161,15 @@ BNMF_DEV bool rank_gather_sum(const unsigned long long* gran, int NB, unsigned t
       const double x = __longlong_as_double((long long)(((unsigned long long)hv[j].z << 32) | hv[j].x));
       acc[j & 15] = acc[j & 15] + ((j < nj) ? x : 0.0);
     }
+    if (GB == 24) {                                       // a round of 1,536 blocks ends half-way through the 1,024 accumulators: the next round's
+      rot ^= 1;                                           // block j belongs to accumulator (j + 8) & 15 — turn the array instead of the indices
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const double x = acc[j]; acc[j] = acc[j + 8]; acc[j + 8] = x; }
+    }
+  }
+  if (GB == 24 && rot) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const double x = acc[j]; acc[j] = acc[j + 8]; acc[j + 8] = x; }
   }
   if (bad) { if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
 #pragma unroll
@@ -209,6 +220,36 @@ BNMF_DEV void wave_tree64x8(const double* v, double* r) {
     r[i] = q;
   }
 }
+// ... and four trees (a half block): column c of v[] in lane (c & 1) * 32 + (c >> 1) * 16 of the result
+BNMF_DEV double wave_tree64x4(const double* v) {
+  auto sw = [](double& a, double& b, bool half32) {
+    const unsigned alo = (unsigned)__double_as_longlong(a), ahi = (unsigned)(__double_as_longlong(a) >> 32);
+    const unsigned blo = (unsigned)__double_as_longlong(b), bhi = (unsigned)(__double_as_longlong(b) >> 32);
+    if (half32) {
+      const auto x = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+      const auto y = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+      a = __longlong_as_double(((long long)y[0] << 32) | (unsigned)x[0]); b = __longlong_as_double(((long long)y[1] << 32) | (unsigned)x[1]);
+    } else {
+      const auto x = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+      const auto y = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+      a = __longlong_as_double(((long long)y[0] << 32) | (unsigned)x[0]); b = __longlong_as_double(((long long)y[1] << 32) | (unsigned)x[1]);
+    }
+  };
+  double a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
+  sw(a0, b0, true); sw(a1, b1, true);
+  double p0 = a0 + b0, p1 = a1 + b1;                      // lanes 0..31: columns 0 / 2, lanes 32..63: columns 1 / 3
+  sw(p0, p1, false);
+  double q = p0 + p1;                                     // rows: columns 0, 2, 1, 3
+#define BNMF_TREE_STEP(CTRL)                                                                                       \
+  {                                                                                                                \
+    int lo = (int)__double_as_longlong(q), hi = (int)(__double_as_longlong(q) >> 32);                              \
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true); \
+    q = q + __longlong_as_double(((long long)hi << 32) | (unsigned)lo);                                            \
+  }
+  BNMF_TREE_STEP(0x108) BNMF_TREE_STEP(0x104) BNMF_TREE_STEP(0x102) BNMF_TREE_STEP(0x101)
+#undef BNMF_TREE_STEP
+  return q;
+}
 BNMF_DEV double lane_of(double v, int l) {                // lane l's value (wave-uniform l) through the scalar unit
   const int lo = __builtin_amdgcn_readlane((int)__double_as_longlong(v), l), hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(v) >> 32), l);
   return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
@@ -244,12 +285,25 @@ BNMF_DEV double rank_decide(const Dev& d, double u /* the factor's uniform: bloc
 // canonically and takes the tempered Bernoulli decision WHILE the compute waves evaluate the alternative of factor n + 1
 // (before: 4.1 us of evaluation, then 2.1 us of gather, then 1.2 us of tree and decision, one after the other, per factor).
 // One workgroup barrier per factor hands the decision over.
-template <bool REG, bool NORMAL>
-__global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsigned long long* granbuf /* [RK_REP][4][2 NB] */, int NB, int* err, double* mhg, unsigned long long* dbg,
+// HALF (REG only; round 4): a compute wave holds HALF a block — 4 columns — and the two waves of a block chain its sum through LDS (the first
+// adds its four column sums from +0.0, the second continues with its own: the same additions in the same order as one wave adding
+// eight).  Ten half-block waves and the decision wave per workgroup (704 lanes, <= 168 registers): five blocks per CU instead of seven, on 250
+// CUs instead of 179 at G = 10,000, and at most three half-block waves on a SIMD where two whole-block waves finished one after the other.
+constexpr int RK_TH = 704, RK_CWH = 10;
+template <bool REG, bool NORMAL, bool HALF = false>
+__global__ __launch_bounds__(HALF ? RK_TH : RK_T) void k_rank_sweep(Dev d, uint32_t t, unsigned long long* granbuf /* [RK_REP][4][2 NB] */, int NB, int* err, double* mhg, unsigned long long* dbg,
                                                          int row /* metrics row, or -1 */, double* recA, double* recR) {
+  static_assert(!HALF || REG, "half blocks: register variant only");
+  constexpr int T = HALF ? RK_TH : RK_T, CW = HALF ? RK_CWH : RK_CW;   // lanes, compute waves
+  constexpr int CPW = HALF ? RK_MAXC / 2 : RK_MAXC;                     // columns per compute wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double bc[2];
   __shared__ double dst[6];
+  // HALF: the first half block's running sum, per block of the workgroup, and the number of the publication it belongs to.  Two slots
+  // (publication number & 1): between two workgroup barriers a wave publishes at most twice (the redo of a flipped factor, then the next
+  // factor's step ahead), so the first half is never more than two publications ahead of the second
+  __shared__ double xchv[RK_CWH / 2][2];
+  __shared__ unsigned xcht[RK_CWH / 2][2];
   // the wave's number in a scalar register and the lane from the execution mask: the thread index itself need not stay in a register
   // through the sweep (at 256 registers it was the one value spilled)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -257,10 +311,12 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
   const int tid = wave * 64 + lane;
   const int K = d.K, G = d.G, N = d.N;
   const int KR = (K + 63) >> 6;
-  const bool decider = wave == RK_CW;
-  // block (REG) / first block (otherwise) of this wave: wave-major, so that a grid wider than NB / RK_CW spreads the
+  const bool decider = wave == CW;
+  // block (REG) / first block (otherwise) of this wave: wave-major, so that a grid wider than NB / CW spreads the
   // blocks over all CUs
-  const int wg = wave * gridDim.x + blockIdx.x, Wt = gridDim.x * RK_CW;
+  const int wblk = HALF ? (wave >> 1) : wave, whalf = HALF ? (wave & 1) : 0;
+  const int wg = wblk * gridDim.x + blockIdx.x, Wt = gridDim.x * CW;
+  const int cb = wg * RK_MAXC + whalf * CPW;               // the wave's first column (REG)
   constexpr bool normal = NORMAL;
   // tags of this launch, unique over the chain: tag0 + 1 = log-likelihood of the current state, tag0 + 2 + 2n + redo = the
   // alternative of factor n (redo = 1: evaluated again after factor n-1 flipped, see the factor loop)
@@ -271,7 +327,8 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
   double* wR = Ash + N;                                  // [N+1] weights of sample_R
   double* uA = wR + (N + 1);                             // [N] the factors' uniforms (sample_An's rbinom), drawn up front by N lanes
   __shared__ int Rsh;
-  for (int j = tid; j < N; j += RK_T) { Ash[j] = d.A[j]; Stream sa(d.k0, d.k1, BNMF_V_A, (uint32_t)j, t); uA[j] = runif(sa); }
+  for (int j = tid; j < N; j += T) { Ash[j] = d.A[j]; Stream sa(d.k0, d.k1, BNMF_V_A, (uint32_t)j, t); uA[j] = runif(sa); }
+  if (tid < RK_CWH) xcht[tid >> 1][tid & 1] = 0u;
   __syncthreads();
   // sample_R :217-241 (was a launch of its own): every workgroup draws the same R from the same stream; the N+1 weights
   // are evaluated one per lane of the decision wave, then added and scanned in r order by its lane 0
@@ -310,7 +367,7 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
     // few instructions against the compute waves' long fp64 chains, but every other wave of the workgroup waits for their result
     __builtin_amdgcn_s_setprio(3);
     unsigned rounds0 = 0u;
-    bool ok = rank_gather_sum(mycopy, NB, tag0 + 1u, err, lane, ll_cur, rounds0);   // buffer 0: the current state (lane 0 carries it)
+    bool ok = rank_gather_sum<HALF ? 24 : 32>(mycopy, NB, tag0 + 1u, err, lane, ll_cur, rounds0);   // buffer 0: the current state (lane 0 carries it)
     // lane 0's state between the factors lives in LDS (dst: ll_cur, sumA, the sweep's constants): nothing but addresses stays in
     // registers across the gather, whose 32 blocks per lane are 128 of them
     if (lane == 0) {
@@ -324,7 +381,7 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
       RKSTAMP(0);
       double ll_alt = 0.0;
       unsigned rounds = 0u;
-      if (ok) ok = rank_gather_sum(mycopy + gbuf(n), NB, tagof(n, redo), err, lane, ll_alt, rounds);
+      if (ok) ok = rank_gather_sum<HALF ? 24 : 32>(mycopy + gbuf(n), NB, tagof(n, redo), err, lane, ll_alt, rounds);
       RKSTAMP(2);
       if (dbg && lane == 0 && n < 16) dbg[(blockIdx.x * 16 + n) * 8 + 5] = rounds;
       const double a_old = Ash[n];
@@ -346,21 +403,41 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
     }
   } else {
   // ---------------------------------------------------------------- the compute waves
-  constexpr int RK_P = RK_MAXC / 2;                       // column pairs of the second row slot
-  double mh0[REG ? RK_MAXC : 1], mh1[REG ? RK_P : 1], sgc[(REG && NORMAL) ? RK_MAXC : 1];
-  double lg0[(REG && !NORMAL) ? RK_MAXC : 1], lg1[(REG && !NORMAL) ? RK_P : 1];   // lgamma(M + 1) of the wave's cells
-  int mm0[REG ? RK_MAXC : 1], mm1[REG ? RK_P : 1];
+  constexpr int RK_P = CPW / 2;                           // column pairs of the second row slot
+  double mh0[REG ? CPW : 1], mh1[REG ? RK_P : 1], sgc[(REG && NORMAL) ? CPW : 1];
+  double lg0[(REG && !NORMAL) ? CPW : 1], lg1[(REG && !NORMAL) ? RK_P : 1];   // lgamma(M + 1) of the wave's cells
+  int mm0[REG ? CPW : 1], mm1[REG ? RK_P : 1];
+  unsigned xc = 0u;                                        // HALF: publications so far (the same count in both waves of a block)
   const int half = lane >> 5, row1 = 64 + (lane & 31);    // slot 1: this lane's column of the pair and its row
   const bool lowv1 = lane < 32 && 64 + lane < K;          // lanes that own an accumulator with a second row
   // block sum of the wave's 8 columns from the lanes' accumulators: 8 canonical trees, then columns in ascending order (lane 0)
   auto block_sum = [&](const double* accv) {
-    double r[2];
-    wave_tree64x8(accv, r);
     double bs = 0.0;
+    if (!HALF) {
+      double r[2];
+      wave_tree64x8(accv, r);
 #pragma unroll
-    for (int c = 0; c < RK_MAXC; ++c) {
-      const double tr = lane_of(r[c >> 2], (c & 1) * 32 + ((c >> 1) & 1) * 16);
-      bs = (wg * RK_MAXC + c < G) ? bs + tr : bs;
+      for (int c = 0; c < RK_MAXC; ++c) {
+        const double tr = lane_of(r[c >> 2], (c & 1) * 32 + ((c >> 1) & 1) * 16);
+        bs = (cb + c < G) ? bs + tr : bs;
+      }
+    } else {
+      const double r = wave_tree64x4(accv);
+      ++xc;
+      if (whalf) {                                         // the second half continues the first half's sum
+        unsigned spins = 0;
+        while (__hip_atomic_load(&xcht[wblk][xc & 1u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != xc && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(0);
+        bs = xchv[wblk][xc & 1u];
+      }
+#pragma unroll
+      for (int c = 0; c < CPW; ++c) {
+        const double tr = lane_of(r, (c & 1) * 32 + (c >> 1) * 16);
+        bs = (cb + c < G) ? bs + tr : bs;
+      }
+      if (!whalf && lane == 0) {
+        xchv[wblk][xc & 1u] = bs;
+        __hip_atomic_store(&xcht[wblk][xc & 1u], xc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
     }
     return bs;
   };
@@ -368,7 +445,7 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
   unsigned long long* gran = pubcopy;                    // buffer 0 of 4
   const unsigned phase = 1;
   if (REG) {
-    double accv[RK_MAXC];
+    double accv[CPW];
     auto fresh = [&](int kk, int g, double sg, double& mhv, int& mv, double& lgv) {   // Mhat, M, lgamma(M+1) and the cell's term
       double cc = 0.0;
       for (int j = 0; j < N; ++j) cc = cc + (d.P[kk + (size_t)K * j] * Ash[j]) * d.E[j + (size_t)N * g];
@@ -378,8 +455,8 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
       return rank_cell_ll(d, m, cc, sg, lgf);
     };
 #pragma unroll
-    for (int c = 0; c < RK_MAXC; ++c) {                   // slot 0: rows 0..63 (cells beyond G / K: harmless values, never added)
-      const int g = wg * RK_MAXC + c;
+    for (int c = 0; c < CPW; ++c) {                       // slot 0: rows 0..63 (cells beyond G / K: harmless values, never added)
+      const int g = cb + c;
       if (NORMAL) sgc[c] = 1.0;
       mh0[c] = 0.0; mm0[c] = 0; accv[c] = 0.0;
       double lgv = 0.0;
@@ -392,17 +469,17 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
     }
 #pragma unroll
     for (int p = 0; p < RK_P; ++p) {                      // slot 1: rows 64..95 of columns 2p (lanes 0..31) and 2p + 1 (lanes 32..63)
-      const int g = wg * RK_MAXC + 2 * p + half;
+      const int g = cb + 2 * p + half;
       mh1[p] = 0.0; mm1[p] = 0;
       double lgv = 0.0, v = 0.0;
       if (g < G && row1 < K) v = fresh(row1, g, normal ? d.sigmasq[g] : 1.0, mh1[p], mm1[p], lgv);
       if (!NORMAL) lg1[NORMAL ? 0 : p] = lgv;
       const double w = down32(v);
-      if (lowv1 && wg * RK_MAXC + 2 * p < G) accv[2 * p] = accv[2 * p] + v;
-      if (lowv1 && wg * RK_MAXC + 2 * p + 1 < G) accv[2 * p + 1] = accv[2 * p + 1] + w;
+      if (lowv1 && cb + 2 * p < G) accv[2 * p] = accv[2 * p] + v;
+      if (lowv1 && cb + 2 * p + 1 < G) accv[2 * p + 1] = accv[2 * p + 1] + w;
     }
     const double bs = block_sum(accv);
-    if (lane < RK_REP && wg < NB) rank_publish(gran, wg, tag0 + phase, bs);
+    if (lane < RK_REP && wg < NB && (!HALF || whalf)) rank_publish(gran, wg, tag0 + phase, bs);
   } else {
     for (int b = wg; b < NB; b += Wt) {
       double bs = 0.0;
@@ -435,18 +512,18 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
   // tag to gather.  Same values, same order of operations, same draws as the one-factor-at-a-time sweep.
   // Four granule buffers: a workgroup in step n writes buffer (n+2)&3 while the slowest one may still read (n-1)&3 .. (n+1)&3.
   // REG: column n of P and row n of E (this wave's 8 columns) are requested one factor ahead of their use
-  double np0 = 0.0, np1 = 0.0, nen[REG ? RK_MAXC : 1];
+  double np0 = 0.0, np1 = 0.0, nen[REG ? CPW : 1];
   auto prefetch = [&](int n) {
     const double* Pq = d.P + (size_t)K * n;
     np0 = lane < K ? Pq[lane] : 0.0; np1 = row1 < K ? Pq[row1] : 0.0;   // slot 1: both half-waves hold rows 64 + (lane & 31)
 #pragma unroll
-    for (int c = 0; c < (REG ? RK_MAXC : 1); ++c) { const int g = wg * RK_MAXC + c; nen[c] = g < G ? d.E[n + (size_t)N * g] : 0.0; }
+    for (int c = 0; c < (REG ? CPW : 1); ++c) { const int g = cb + c; nen[c] = g < G ? d.E[n + (size_t)N * g] : 0.0; }
   };
-  double p0 = 0.0, p1 = 0.0, en_[REG ? RK_MAXC : 1];      // REG: the factor whose alternative is evaluated next
+  double p0 = 0.0, p1 = 0.0, en_[REG ? CPW : 1];          // REG: the factor whose alternative is evaluated next
   auto take_prefetched = [&](int n_next) {                 // current <- prefetched, request factor n_next
     p0 = np0; p1 = np1;
 #pragma unroll
-    for (int c = 0; c < (REG ? RK_MAXC : 1); ++c) en_[c] = nen[c];
+    for (int c = 0; c < (REG ? CPW : 1); ++c) en_[c] = nen[c];
     if (n_next < N) prefetch(n_next);
   };
   // evaluate the alternative of factor f (A[f] flipped) on the current Mhat and publish this wave's block sums
@@ -459,9 +536,9 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
       // columns beyond G hold harmless values and are never added
       // Mhat - t is Mhat + (-t), and (-p) e is -(p e): the sign goes onto the column of P once per factor
       const double q0 = (a_f == 1.0) ? -p0 : p0, q1 = (a_f == 1.0) ? -p1 : p1;
-      double accv[RK_MAXC];
+      double accv[CPW];
 #pragma unroll
-      for (int c = 0; c < RK_MAXC; ++c) {                 // slot 0
+      for (int c = 0; c < CPW; ++c) {                     // slot 0
         const double alt = mh0[c] + q0 * en_[c];
         const double ll = rank_cell_ll_t<NORMAL>(mm0[c], alt, NORMAL ? sgc[NORMAL ? c : 0] : 1.0, NORMAL ? 0.0 : lg0[NORMAL ? 0 : c]);
         accv[c] = (lane < K) ? 0.0 + ll : 0.0;
@@ -476,7 +553,7 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
         accv[2 * p + 1] = lowv1 ? accv[2 * p + 1] + w : accv[2 * p + 1];
       }
       const double bs = block_sum(accv);
-      if (lane < RK_REP && wg < NB) rank_publish(gr, wg, tg, bs);
+      if (lane < RK_REP && wg < NB && (!HALF || whalf)) rank_publish(gr, wg, tg, bs);
     } else {
       const double* Pf = d.P + (size_t)K * f;
       for (int b = wg; b < NB; b += Wt) {
@@ -510,14 +587,14 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
     if (REG) {
       const double q0 = lane < K ? Pf[lane] : 0.0, q1 = row1 < K ? Pf[row1] : 0.0;
 #pragma unroll
-      for (int c = 0; c < RK_MAXC; ++c) {
-        const int g = wg * RK_MAXC + c;
+      for (int c = 0; c < CPW; ++c) {
+        const int g = cb + c;
         const double tt = q0 * (g < G ? d.E[f + (size_t)N * g] : 0.0);
         mh0[c] = (a_was == 1.0) ? mh0[c] - tt : mh0[c] + tt;
       }
 #pragma unroll
       for (int p = 0; p < RK_P; ++p) {
-        const int g = wg * RK_MAXC + 2 * p + half;
+        const int g = cb + 2 * p + half;
         const double tt = q1 * (g < G ? d.E[f + (size_t)N * g] : 0.0);
         mh1[p] = (a_was == 1.0) ? mh1[p] - tt : mh1[p] + tt;
       }
@@ -543,7 +620,7 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
       publish_alt(n + 1, 0u);
     }
     if (wave == 0) { RKSTAMP(1); }
-    if (wave == RK_CW - 1) { RKSTAMP(7); }                // the youngest compute wave: two waves of a SIMD finish one after the other
+    if (wave == CW - 1) { RKSTAMP(7); }                // the youngest compute wave: two waves of a SIMD finish one after the other
     wg_lds_barrier();                                      // the decision of factor n (LDS only: the prefetches and publications stay in flight)
     const double a_new = bc[n & 1];
     if (a_new < 0.0) return;                               // the exchange timed out (the decision wave has set *err)
@@ -558,7 +635,7 @@ __global__ __launch_bounds__(RK_T, 2) void k_rank_sweep(Dev d, uint32_t t, unsig
   __syncthreads();
   // what k_sumA did in a launch of its own (Gibbs sweep): A, R into the ring, sum(A) into the raw metrics row
   if (blockIdx.x == 0 && row >= 0) {
-    if (recA) for (int j = tid; j < N; j += RK_T) recA[j] = Ash[j];
+    if (recA) for (int j = tid; j < N; j += T) recA[j] = Ash[j];
     if (tid == 0) {
       if (recR) *recR = (double)Rsh;
       double sA = 0.0;

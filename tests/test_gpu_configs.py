@@ -19,13 +19,16 @@ def _mk(cls, M, N, prior, **kw):
     return c
 
 
-def test_config4_learned_rank_N50_bitexact():
+@pytest.mark.parametrize("half_blocks", ["1", "0"])
+def test_config4_learned_rank_N50_bitexact(half_blocks, monkeypatch):
     """Config 4's model on its real kernel path: rank = 1:50 => N = 50 > 25, so the Z allocation runs on the
     general kernel k_zalloc with A containing zeros (R/sample_params.R:101-241, :253-265).  Bit-exact against
-    the oracle at a reduced number of columns."""
+    the oracle at a reduced number of columns.  The rank sweep in both register forms: half a block of columns per
+    compute wave (round 4, the default where its grid fits the device) and a whole block (BNMF_RANKHALF=0)."""
     import oracle as O
     from bayesnmf_amd import Engine
     from bayesnmf_amd.setup import synth_counts
+    monkeypatch.setenv("BNMF_RANKHALF", half_blocks)
     M, _, _ = synth_counts(96, 72, 5, 20250230)
     N = 50
     temp = _temp_schedule(200)

@@ -8,7 +8,7 @@ M, _, _ = synth_counts(96, 10000, 12, 20250222)
 e = Engine(M, 50, prior="gamma", seed=1, learning_rank=True, temperature=np.ones(8000), window=10)
 apply_hyperprior_params(e, "gamma", M, 50); e.init(); e.run(5, metrics=False)
 L = engine.lib(); L.bnmf_debug_rank.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]
-n = int(os.environ.get('BNMF_RANKGRID', '179')) * 16 * 8   # rank_grid workgroups (179 = ceil(ceil(G / 8) / 7) at G = 10,000: 7 compute waves per workgroup)
+n = int(os.environ.get('BNMF_RANKGRID', '250')) * 16 * 8   # rank_grid workgroups (250 = ceil(ceil(G / 8) / 5) at G = 10,000: five blocks per workgroup; 179 with BNMF_RANKHALF=0)
 buf = np.zeros(n, dtype=np.uint64)
 g = L.bnmf_debug_rank(e._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), n)
 d = buf[:g * 16 * 8].reshape(g, 16, 8).astype(np.float64) / 100.0   # us
