@@ -189,7 +189,13 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
       }
     }
   }
+#ifdef ZSPROF
+#define MHSTAMP(i) const unsigned long long mhs##i = __builtin_amdgcn_s_memrealtime()
+#else
+#define MHSTAMP(i)
+#endif
   for (int n = 0; n < N; ++n) {
+    MHSTAMP(0);
     const int e = k + K * n;
     const double a_n = anz[n];
     if (REG) {
@@ -241,13 +247,17 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
         }
       }
     }
+    MHSTAMP(1);
     wg_lds_barrier();
+    MHSTAMP(2);
     if (tid == 0) {
       double num1 = 0.0, den = 0.0;
       if (!allzero) for (int s = 0; s < S; ++s) { num1 = num1 + part[s]; den = den + part[S + s]; }
       bc[0] = mh_prior_or_cond_pre<0>(d, e, t, allzero, num1, den, pre_load(prq + PRE_W * n));
     }
+    MHSTAMP(3);
     wg_lds_barrier();
+    MHSTAMP(4);
     const double pr = bc[0];
     const double pnew = pr * a_n;
     bool take = true;
@@ -311,6 +321,13 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
       }
       if (tid == 0) { d.P[e] = pr; pa[n] = pnew; pcur[n] = pr; }
     }
+#ifdef ZSPROF
+    { MHSTAMP(5);
+      if (blockIdx.x == 0 && tid == 0 && n < 32) {
+        unsigned long long* o = &g_drprof[8 * (2048 + n)];
+        o[0] += mhs1 - mhs0; o[1] += mhs2 - mhs1; o[2] += mhs3 - mhs2; o[3] += mhs4 - mhs3; o[4] += mhs5 - mhs4; o[5] += mhs5 - mhs0; o[7] += 1ull;
+      } }
+#endif
     // no barrier here: the next factor's writers of `part` / `bc` are behind barriers that every wave reaches only after it has read
     // this factor's values (tid 0 reads `part` before the barrier that publishes bc; bc is rewritten only behind the next one)
   }
