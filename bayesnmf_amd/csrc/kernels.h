@@ -223,7 +223,9 @@ BNMF_DEV void side_body(const Dev& d, uint32_t t, int nbP, int blk, int nblocks,
   }
   side_done(sd, tid);
 }
-__global__ __launch_bounds__(RT, 4) void k_side(Dev d, uint32_t t, int nbP, int blk0, RecDst rec, SideDone sd) {
+// <= 152 registers: a wave of this kernel then still fits beside three waves of the allocation kernel on a SIMD (3 x 120 + 152 = 512;
+// round 3 capped it at 128 and paid 28 bytes of scratch per lane)
+__global__ __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(152))) void k_side(Dev d, uint32_t t, int nbP, int blk0, RecDst rec, SideDone sd) {
   __shared__ double buf[RT];
   side_body(d, t, nbP, blockIdx.x + blk0, gridDim.x, rec, sd, buf, threadIdx.x);   // one launch (blk0 = 0) or one launch per part
 }
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(ES_T) void k_lpe(Dev d, uint32_t t, const double* E
 // other; side_done counts the k_side workgroups only.
 struct SideExtra { int first, n_lpp, n_lpe; uint32_t t_lp; const double* Esrc; int count_all; };   // count_all: the log-prior workgroups count towards sd too
 static_assert(ES_T == RT, "k_side_lp: one block size for both kinds of workgroup");
-__global__ __launch_bounds__(RT, 4) void k_side_lp(Dev d, uint32_t t, int nbP, int blk0, RecDst rec, SideDone sd, SideExtra ex) {
+__global__ __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(152))) void k_side_lp(Dev d, uint32_t t, int nbP, int blk0, RecDst rec, SideDone sd, SideExtra ex) {
   __shared__ double buf[RT];
   const int j = (int)blockIdx.x - ex.first;
   if (j < 0) { side_body(d, t, nbP, blockIdx.x + blk0, ex.first, rec, sd, buf, threadIdx.x); return; }
