@@ -83,6 +83,7 @@ struct bnmf_handle {
   bool z_tile = false, z_lean = false; ZTGeom ztg{}; double* dMhatZ = nullptr;   // k_zalloc_tile (zalloc_tile.h): N > 24 / large K
   // k_zalloc_sort (zalloc_sort.h): stats mode, N <= 24 — the static schedule built from M at bnmf_create
   bool z_sort = false, zs_pk = false; ZSGeom zsg{}; int zs_nblk = 0, zs_w = 0; size_t zs_lds = 0; int32_t* dZsM = nullptr;
+  int zs_it16 = 0, zs_qmax = ZS_QMAX;   // 2-byte items; quads per item
   uint32_t* dZsRec = nullptr; int zx_cols = 0; size_t zx_lds = 0;   // save_Z on the sorted schedule: the items' records, k_zexpand's columns per pass and LDS bytes
   uint32_t* dZsItems = nullptr; ZSBlock* dZsBlocks = nullptr; int* dZsCols = nullptr; unsigned long long* dZsProf = nullptr;
   // k_zalloc_step (zalloc_step.h): stats mode, 25 <= N <= 100, any K — the static schedule built from M at bnmf_create
@@ -295,6 +296,10 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
       if ((int)bcols[top.second].size() < GBc) { heap.push_back(top); std::push_heap(heap.begin(), heap.end(), cmp); }
     }
   }
+  // 2-byte items where row, column-in-block and fragment index fit 7 + 6 + 3 bits (and 0xFFFF stays free for the empty lane)
+  bool it16 = K <= 127 && GBc <= 64 && (long long)h->maxM <= 8LL * 4 * ZS_QMAX16;
+  if (const char* e = getenv("BNMF_ZSIT16")) it16 = it16 && atoi(e) != 0;           // diagnostics / tests: 0 = 4-byte items
+  const int qmax = it16 ? ZS_QMAX16 : ZS_QMAX;
   std::vector<ZSBlock> blocks(nb);
   std::vector<int> cols;
   std::vector<uint32_t> items;
@@ -317,8 +322,8 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
           const int m = M[k + K * g];
           if (m <= 0) continue;
           const int qt = (m + 3) >> 2;
-          for (int f = 0; f * ZS_QMAX < qt; ++f)
-            tmp.push_back({std::min(ZS_QMAX, qt - f * ZS_QMAX), (uint32_t)k | ((uint32_t)gl << 10) | ((uint32_t)f << 16)});
+          for (int f = 0; f * qmax < qt; ++f)
+            tmp.push_back({std::min(qmax, qt - f * qmax), (uint32_t)k | ((uint32_t)gl << 10) | ((uint32_t)f << 16)});
         }
       }
       std::stable_sort(tmp.begin(), tmp.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
@@ -350,8 +355,19 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
     for (int g : bcols[b]) { memcpy(Mblk.data() + K * cols.size(), M + K * (size_t)g, K * sizeof(int32_t)); cols.push_back(g); }
   }
   if (items.empty()) items.push_back(0xFFFFFFFFu);
-  HIPCHK(hipMalloc(&h->dZsItems, items.size() * sizeof(uint32_t)));
-  HIPCHK(hipMemcpy(h->dZsItems, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  if (it16) {
+    std::vector<uint16_t> i16(items.size());
+    for (size_t i = 0; i < items.size(); ++i) {
+      const uint32_t v = items[i];
+      i16[i] = v == 0xFFFFFFFFu ? (uint16_t)0xFFFFu : (uint16_t)((v & 127u) | (((v >> 10) & 63u) << 7) | ((v >> 16) << 13));
+    }
+    HIPCHK(hipMalloc(&h->dZsItems, ((i16.size() * sizeof(uint16_t) + 3) & ~(size_t)3)));
+    HIPCHK(hipMemcpy(h->dZsItems, i16.data(), i16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  } else {
+    HIPCHK(hipMalloc(&h->dZsItems, items.size() * sizeof(uint32_t)));
+    HIPCHK(hipMemcpy(h->dZsItems, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  h->zs_it16 = it16 ? 1 : 0; h->zs_qmax = qmax;
   HIPCHK(hipMalloc(&h->dZsBlocks, blocks.size() * sizeof(ZSBlock)));
   HIPCHK(hipMemcpy(h->dZsBlocks, blocks.data(), blocks.size() * sizeof(ZSBlock), hipMemcpyHostToDevice));
   HIPCHK(hipMalloc(&h->dZsCols, cols.size() * sizeof(int)));
@@ -1192,7 +1208,7 @@ static int launch_zalloc_t(bnmf_handle* h, uint32_t t) {
 }
 template <int ZT_>
 static int launch_zsort_t(bnmf_handle* h, uint32_t t) {
-  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->dZsRec, h->dZsProf};
+  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->zs_it16, h->zs_qmax, h->dZsRec, h->dZsProf};
   auto go = [&](auto kern) -> int {
     if (h->z_attr_kernel != (const void*)kern) {
       HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1241,7 +1257,7 @@ static int launch_zalloc(bnmf_handle* h, uint32_t t) {
   if (h->z_sort) {
     if (int rc = launch_zsort(h, t)) return rc;
     if (h->cfg.save_Z) {                                   // the items' records -> the columns of Z (zalloc_sort.h k_zexpand)
-      const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->dZsRec, h->dZsProf};
+      const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->zs_it16, h->zs_qmax, h->dZsRec, h->dZsProf};
       hipLaunchKernelGGL(k_zexpand, dim3(h->zsg.nblocks), dim3(ZX_T), h->zx_lds, h->stream, sa, h->zx_cols);
     }
     return 0;

@@ -427,6 +427,8 @@ __global__ __launch_bounds__(HALF ? RK_TH : RK_T) void k_rank_sweep(Dev d, uint3
       if (whalf) {                                         // the second half continues the first half's sum
         unsigned spins = 0;
         while (__hip_atomic_load(&xcht[wblk][xc & 1u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != xc && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(0);
+        // bounded like every wait of the sweep: a first half that never arrives (it cannot, short of a fault) fails the launch, not the chain's bits
+        if (spins >= (1u << 26) && lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bs = xchv[wblk][xc & 1u];
       }
 #pragma unroll

@@ -27,16 +27,20 @@
 namespace bnmf {
 
 constexpr int ZS_QMAX = 32;          // quads per item (128 counts): larger cells are split
+constexpr int ZS_QMAX16 = 64;        // ... with 2-byte items (3 bits of fragment index: 8 x 256 counts)
 constexpr int ZS_NMAX = 25;          // 5 blocks of 4 thresholds + 4 pivots = 24 thresholds
 
 struct ZSBlock { int item0, ntask, col0, ncols; };   // items [item0, item0 + 64 ntask), columns cols[col0 .. col0 + ncols)
 struct ZSGeom { int KP, GBc, nblocks; };              // pitch of zG rows, column capacity of a block
 struct ZSArgs {
   ZArgs a;
-  const uint32_t* items;             // k | gl << 10 | fragment << 16; 0xFFFFFFFF = empty lane
+  const uint32_t* items;             // k | gl << 10 | fragment << 16; 0xFFFFFFFF = empty lane.  it16 (round 4; K <= 127, <= 64 columns per block, no cell above
+                                     // 2,048 counts — the metric configuration): 2-byte items k | gl << 7 | fragment << 13, 0xFFFF = empty lane: half the bytes
+                                     // of the one array the kernel reads beside M
   const ZSBlock* blocks;
   const int* cols;
   const int32_t* Mblk;               // M with its columns in block order: column col0 + gl of Mblk = column cols[col0 + gl] of M
+  int it16, qmax;                    // item format; quads per item (ZS_QMAX, or ZS_QMAX16 with 2-byte items)
   uint32_t* rec;                     // save_Z: [item slot / 64][(N + 1) / 2][64] the items' histograms, two 16-bit counts per word; else null
   unsigned long long* prof;          // -DZSPROF builds only: per-section s_memtime ticks summed over the waves (diagnostics)
 };
@@ -218,10 +222,14 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
     } else {
     // ---------------- item task: lane = item
     ZSTIC(1);
-    const uint32_t it = s.items[(size_t)bk.item0 + (size_t)task * 64 + lane];
+    uint32_t it;
+    if (s.it16) {                                          // wave-uniform: the same fields from half the bytes
+      const uint32_t r = ((const uint16_t*)s.items)[(size_t)bk.item0 + (size_t)task * 64 + lane];
+      it = r == 0xFFFFu ? 0xFFFFFFFFu : ((r & 127u) | (((r >> 7) & 63u) << 10) | ((r >> 13) << 16));
+    } else it = s.items[(size_t)bk.item0 + (size_t)task * 64 + lane];
     const bool valid = it != 0xFFFFFFFFu;
     const int k = valid ? (int)(it & 1023u) : 0, gl = valid ? (int)((it >> 10) & 63u) : 0;
-    const int q0 = valid ? (int)(it >> 16) * ZS_QMAX : 0;
+    const int q0 = valid ? (int)(it >> 16) * s.qmax : 0;
     const int m = Ms[k + (size_t)K * gl];
     const int g = colid[gl];
     int nq = 0, npad = 0;
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
       for (int n = 0; n < NC; ++n) { if (n < NMIN || n < N) c = c + Pk[(size_t)K * n] * ag[(size_t)n * GBc]; cs[n] = c; }
       if (valid && c > 0.0 && m > 0) {
         const int qt = (m + 3) >> 2;
-        nq = min(ZS_QMAX, qt - q0);
+        nq = min(s.qmax, qt - q0);
         npad = (q0 + nq == qt) ? ((4 - (m & 3)) & 3) : 0;
       }
       const double scale = 4294967296.0 / c;
@@ -359,7 +367,9 @@ __global__ __launch_bounds__(ZX_T) void k_zexpand(ZSArgs s, int cols_per_pass) {
     for (int i = tid; i < nc * N * KH; i += ZX_T) slab[i] = 0u;
     __syncthreads();
     for (int i = tid; i < nslots; i += ZX_T) {             // lane = item slot, as in the allocation kernel: the records are read as they were written
-      const uint32_t it = s.items[(size_t)bk.item0 + i];
+      uint32_t it;
+      if (s.it16) { const uint32_t r = ((const uint16_t*)s.items)[(size_t)bk.item0 + i]; it = r == 0xFFFFu ? 0xFFFFFFFFu : ((r & 127u) | (((r >> 7) & 63u) << 10)); }
+      else it = s.items[(size_t)bk.item0 + i];
       if (it == 0xFFFFFFFFu) continue;
       const int k = (int)(it & 1023u), gl = (int)((it >> 10) & 63u) - c0;
       if (gl < 0 || gl >= nc) continue;

@@ -809,19 +809,22 @@ def test_timeout_poisons_the_handle():
     e.close()
 
 
-@pytest.mark.parametrize("K,G,N", [(96, 3000, 20), (200, 130, 7), (96, 64, 24), (33, 700, 3), (24, 501, 5), (120, 301, 12)])
+@pytest.mark.parametrize("K,G,N,big", [(96, 3000, 20, 3000), (96, 3000, 20, 1900), (200, 130, 7, 3000), (96, 64, 24, 2048), (33, 700, 3, 3000), (24, 501, 5, 700),
+                                       (120, 301, 12, 1500)])
 @pytest.mark.parametrize("packed", ["1", "0"])
-def test_sorted_schedule_kernel_matches_register_kernel(K, G, N, packed, monkeypatch):
+def test_sorted_schedule_kernel_matches_register_kernel(K, G, N, big, packed, monkeypatch):
     """k_zalloc_sort (static count-sorted schedule, stats mode) against k_zalloc_reg (BNMF_ZSORT=0) on the same chain: ZsumK,
     ZsumG, metrics, P, E bit for bit; both layouts of the block tables (two factors per word / one), cells above 128 counts
     (several items per cell), N at both ends of the template range, and every shape of the metric tasks' last pass (K = 24: the only
-    pass and shared; K = 96, 200: shared; K = 33, 120: more than 32 rows, not shared)."""
+    pass and shared; K = 96, 200: shared; K = 33, 120: more than 32 rows, not shared).  `big` = the largest cell: up to 2,048 counts (and
+    K <= 127) the schedule uses 2-byte items with fragments of 256 counts (round 4), above it 4-byte items with fragments of 128."""
     from bayesnmf_amd import Engine
     from bayesnmf_amd.setup import apply_hyperprior_params
     rng = np.random.default_rng(K + G)
     M = rng.poisson(rng.gamma(0.7, 60.0, size=(K, G))).astype(np.int32)
     M[rng.uniform(size=M.shape) < 0.05] = 0
-    M[0, 0] = 3000
+    M = np.minimum(M, big)
+    M[0, 0] = big
 
     def mk(zs):
         monkeypatch.setenv("BNMF_ZSORT", zs)
