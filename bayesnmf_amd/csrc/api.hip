@@ -640,7 +640,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
     h->rank_reg = K <= 96 && wg_needed <= cap_reg;       // register variant: rows 64..95 of two columns share a register (rank.h)
     // ... with HALF a block per compute wave where the grid of ten-half-block workgroups is co-resident too (704 lanes, one per CU)
     const long wg_half = (NB + RK_CWH / 2 - 1) / (RK_CWH / 2);
-    h->rank_half = h->rank_reg && wg_half <= (long)prop0.multiProcessorCount;
+    h->rank_half = h->rank_reg && wg_half <= (long)prop0.multiProcessorCount && NB <= 1536;   // (1,536: one round of its decision wave's gather, rank.h)
     if (const char* e = getenv("BNMF_RANKHALF")) h->rank_half = h->rank_half && atoi(e) != 0;   // diagnostics / tests: 0 = whole blocks
     // (a wider grid with the blocks dealt wave-major over all CUs was measured: no gain, the sweep is bound by the
     // per-factor exchange, not by VALU contention)

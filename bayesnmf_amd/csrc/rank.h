@@ -117,7 +117,7 @@ BNMF_DEV void rank_publish(unsigned long long* gran /* this lane's copy */, int 
 // the same order as canon_sum(x, NB, 1024).  The granules of a lane's first 32 blocks are requested together (one round trip
 // to the memory side; two in a row — 16 blocks at a time — took 4.1 us per factor) and only those whose tags do not match yet are asked for again.  The sum is valid on lane 0.
 typedef unsigned int __attribute__((ext_vector_type(4))) rk_uv4;
-template <int GB /* blocks per lane and round: 32 (NB <= 2,048: ONE round trip), or 24 where registers are short (NB <= 1,536) */>
+template <int GB /* blocks per lane and round: 32 (NB <= 2,048: ONE round trip; more: a round per 2,048), or 24 where registers are short (NB <= 1,536 only) */>
 BNMF_DEV bool rank_gather_sum(const unsigned long long* gran, int NB, unsigned tag, int* err, int lane, double& sum, unsigned& rounds) {
   static_assert(GB == 32 || GB == 24, "blocks per round");
   // a block's two granules in ONE 16-byte load (agent scope: sc1, as the 8-byte atomic loads; each granule carries its own tag, so
@@ -129,7 +129,8 @@ BNMF_DEV bool rank_gather_sum(const unsigned long long* gran, int NB, unsigned t
 #pragma unroll
   for (int j = 0; j < 16; ++j) acc[j] = 0.0;
   bool bad = false;
-  int rot = 0;
+  // (GB = 24 serves NB <= 1,536 only — one round; api.hip takes the half-block sweep, its one user, for at most 5 blocks per CU —: a second
+  // round of 1,536 would start half-way through the 1,024 accumulators)
   for (int base = 0; base < NB && !bad; base += 64 * GB) {
     rk_uv4 hv[GB];
     const int nj = min(GB, (NB - base + 63) >> 6);        // wave-uniform: rounds of 64 blocks that hold a block at all
@@ -161,15 +162,6 @@ BNMF_DEV bool rank_gather_sum(const unsigned long long* gran, int NB, unsigned t
       const double x = __longlong_as_double((long long)(((unsigned long long)hv[j].z << 32) | hv[j].x));
       acc[j & 15] = acc[j & 15] + ((j < nj) ? x : 0.0);
     }
-    if (GB == 24) {                                       // a round of 1,536 blocks ends half-way through the 1,024 accumulators: the next round's
-      rot ^= 1;                                           // block j belongs to accumulator (j + 8) & 15 — turn the array instead of the indices
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const double x = acc[j]; acc[j] = acc[j + 8]; acc[j + 8] = x; }
-    }
-  }
-  if (GB == 24 && rot) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const double x = acc[j]; acc[j] = acc[j + 8]; acc[j + 8] = x; }
   }
   if (bad) { if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
 #pragma unroll

@@ -77,11 +77,12 @@ def test_rank_sweep_general_path_bitexact(K, G, N, lik, prior, MH):
     e.close()
 
 
-@pytest.mark.parametrize("K,G,N", [(8, 13000, 4), (100, 12500, 3)])
+@pytest.mark.parametrize("K,G,N", [(8, 13000, 4), (100, 12500, 3), (8, 17000, 3)])
 def test_rank_sweep_wide_G_bitexact(K, G, N):
-    """More than 3 x 512 column blocks (G > 12,288): a lane of the rank sweep then gathers its block sums in more than one
-    batch, and the sums of factor n+1 are published a step ahead of the decision for factor n (again after a flip).
-    K = 8: register-resident variant; K = 100: Mhat in global scratch."""
+    """Wide problems: G = 13,000 / 12,500: more column blocks than the half-block and whole-block register grids hold on 256 CUs
+    (K = 8: whole blocks in registers; K = 100: Mhat in global scratch); G = 17,000: 2,125 blocks, i.e. the decision wave gathers
+    the block sums in two rounds of 2,048.  The sums of factor n+1 are published a step ahead of the decision for factor n (again
+    after a flip)."""
     import oracle as O
     from bayesnmf_amd import Engine
     rng = np.random.default_rng(K + G)
