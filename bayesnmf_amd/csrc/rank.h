@@ -291,11 +291,13 @@ __global__ __launch_bounds__(HALF ? RK_TH : RK_T) void k_rank_sweep(Dev d, uint3
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double bc[2];
   __shared__ double dst[6];
-  // HALF: the first half block's running sum, per block of the workgroup, and the number of the publication it belongs to.  Two slots
-  // (publication number & 1): between two workgroup barriers a wave publishes at most twice (the redo of a flipped factor, then the next
-  // factor's step ahead), so the first half is never more than two publications ahead of the second
-  __shared__ double xchv[RK_CWH / 2][2];
-  __shared__ unsigned xcht[RK_CWH / 2][2];
+  // HALF: the first half block's running sum, per block of the workgroup, and the number of the publication it belongs to.  Four slots
+  // (publication number & 3): between two workgroup barriers a wave publishes at most three times — in front of the first barrier of the
+  // launch: the current state, the alternative of factor 0 and the step ahead for factor 1; later: the redo of a flipped factor and the next
+  // step ahead — so the first half is never more than three publications ahead of the second.  (With two slots the three publications at the
+  // start could overwrite a sum the second half had not read: a time-out once in a few hundred chains, found by tools/fuzz_parity.py.)
+  __shared__ double xchv[RK_CWH / 2][4];
+  __shared__ unsigned xcht[RK_CWH / 2][4];
   // the wave's number in a scalar register and the lane from the execution mask: the thread index itself need not stay in a register
   // through the sweep (at 256 registers it was the one value spilled)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(HALF ? RK_TH : RK_T) void k_rank_sweep(Dev d, uint3
   double* uA = wR + (N + 1);                             // [N] the factors' uniforms (sample_An's rbinom), drawn up front by N lanes
   __shared__ int Rsh;
   for (int j = tid; j < N; j += T) { Ash[j] = d.A[j]; Stream sa(d.k0, d.k1, BNMF_V_A, (uint32_t)j, t); uA[j] = runif(sa); }
-  if (tid < RK_CWH) xcht[tid >> 1][tid & 1] = 0u;
+  if (tid < 2 * RK_CWH) xcht[tid >> 2][tid & 3] = 0u;
   __syncthreads();
   // sample_R :217-241 (was a launch of its own): every workgroup draws the same R from the same stream; the N+1 weights
   // are evaluated one per lane of the decision wave, then added and scanned in r order by its lane 0
@@ -418,10 +420,10 @@ __global__ __launch_bounds__(HALF ? RK_TH : RK_T) void k_rank_sweep(Dev d, uint3
       ++xc;
       if (whalf) {                                         // the second half continues the first half's sum
         unsigned spins = 0;
-        while (__hip_atomic_load(&xcht[wblk][xc & 1u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != xc && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(0);
+        while (__hip_atomic_load(&xcht[wblk][xc & 3u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != xc && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(0);
         // bounded like every wait of the sweep: a first half that never arrives (it cannot, short of a fault) fails the launch, not the chain's bits
         if (spins >= (1u << 26) && lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bs = xchv[wblk][xc & 1u];
+        bs = xchv[wblk][xc & 3u];
       }
 #pragma unroll
       for (int c = 0; c < CPW; ++c) {
@@ -429,8 +431,8 @@ __global__ __launch_bounds__(HALF ? RK_TH : RK_T) void k_rank_sweep(Dev d, uint3
         bs = (cb + c < G) ? bs + tr : bs;
       }
       if (!whalf && lane == 0) {
-        xchv[wblk][xc & 1u] = bs;
-        __hip_atomic_store(&xcht[wblk][xc & 1u], xc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        xchv[wblk][xc & 3u] = bs;
+        __hip_atomic_store(&xcht[wblk][xc & 3u], xc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
     return bs;

@@ -22,11 +22,15 @@ for case in range(n_cases):
     G = int(rng.integers(1, int(os.environ.get("FUZZ_GMAX", "90"))))
     N = int(rng.choice([1, 2, 5, 9, 17, 21, 25, 26, 33, 50, 70]))
     lr = bool(rng.random() < 0.4) and N > 1
+    if os.environ.get("FUZZ_LR_ONLY"):                     # the persistent rank sweep only (register forms: K <= 96)
+        lr = True; N = max(N, 2); K = int(rng.choice([3, 12, 31, 64, 65, 96]))
     window = int(rng.choice([0, 3]))
     M = rng.poisson(rng.gamma(0.7, 10.0, size=(K, G))).astype(np.int32)
     if rng.random() < 0.3: M[:, rng.integers(0, G)] = 0
     if rng.random() < 0.3: M[rng.integers(0, K), :] = 0
     kw = dict(seed=int(rng.integers(1, 1000)), learning_rank=lr)
+    save_Z = bool(rng.random() < 0.4) and model in ("gamma", "exponential")      # full mode of the Gibbs sweep: Z itself is compared
+    if save_Z: kw["save_Z"] = True
     only = os.environ.get("FUZZ_ONLY")
     if only is not None and case != int(only): continue
     if lr: kw["temperature"] = np.linspace(0.1, 1.0, 12)
@@ -48,13 +52,13 @@ for case in range(n_cases):
                 dd = mo[:, :9].copy().view(np.uint64) != me[:, :9].copy().view(np.uint64)
                 print("conv", conv, "rows", np.where(dd.any(1))[0], "cols", np.where(dd.any(0))[0]); i = np.where(dd.any(1))[0][0]; print(mo[i, :9]); print(me[i, :9])
             ok = ok and same
-            for nm in ("P", "E", "A"):
+            for nm in ("P", "E", "A") + (("ZsumK", "ZsumG") if model in ("gamma", "exponential") else ()) + (("Z",) if save_Z else ()):
                 ok = ok and same_bits(o.get(nm), e.get(nm))
         e.close()
     except Exception as ex:
         ok = False; print("EXC", ex)
     if not ok:
         bad += 1
-        print("MISMATCH", case, model, K, G, N, lr, window, kw["seed"], flush=True)
+        print("MISMATCH", case, model, K, G, N, lr, window, kw["seed"], "save_Z" if save_Z else "", flush=True)
 print("cases %d, mismatches %d, %.0f s" % (n_cases, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
