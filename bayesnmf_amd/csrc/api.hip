@@ -46,6 +46,8 @@ struct bnmf_handle {
   hipStream_t side2 = nullptr;         // second side stream: k_side P part (starts right after k_pdraw) and Esum
   hipEvent_t ev_draw = nullptr, ev_side = nullptr, ev_sideP = nullptr, ev_p = nullptr, ev_z = nullptr, ev_red = nullptr, ev_rank = nullptr;
   bool side_valid = false;             // k_side of iteration iter+1 has been issued
+  bool side_main = false;              // ... on the main stream (MH / Normal sweeps: launch_side_main)
+  bool mh_side_main = true;            // BNMF_MHSIDE=0 (diagnostics / tests): the MH / Normal sweeps' hyper sweep on the side stream, as in round 3
   int gate_forced = -1;                // BNMF_GATE at bnmf_create: 0 / 1 forces the merged draw kernel off / on, else by size
   int draw_bw = 0;                     // lanes per workgroup of the merged draw kernel (chosen at the first launch)
   double* dScal = nullptr;              // [BNMF_ID_MAX] broadcast scalars of bnmf_set_array (hyper-prior values given as one number)
@@ -585,6 +587,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   HIPCHK(hipMemset(h->dZsumG, 0, K * N * sizeof(int32_t)));
   if (cfg->save_Z) HIPCHK(hipMalloc(&h->dZ, K * N * G * sizeof(int32_t)));
   if (const char* e = getenv("BNMF_GATE")) h->gate_forced = atoi(e) != 0 ? 1 : 0;   // diagnostics / tests
+  if (const char* e = getenv("BNMF_MHSIDE")) h->mh_side_main = atoi(e) != 0;
   if (const char* e = getenv("BNMF_DEBUG_DRAW_NO_P")) h->dbg_draw_no_p = atoi(e) != 0 ? 1 : 0;   // tests only
   if (const char* e = getenv("BNMF_DEBUG_SIDE_DELAY_US")) h->dbg_side_delay_us = std::max(0, std::min(20000, atoi(e)));   // tests only
   {
@@ -854,7 +857,7 @@ int bnmf_set_array(bnmf_handle* h, int id, const double* x, size_t n) {
   clk.mark("set_array: sync side");
   HIPCHK(hipStreamSynchronize(h->side2));
   clk.mark("set_array: sync side2");
-  h->side_valid = false;                 // state changed: the pre-issued k_side must be redone
+  h->side_valid = false; h->side_main = false;   // state changed: the pre-issued k_side must be redone
   h->mh_prep_valid = false;
   if (id == BNMF_R) { int r = (int)x[0]; HIPCHK(hipMemcpy(h->dR, &r, sizeof(int), hipMemcpyHostToDevice)); h->arr[BNMF_R].set = true; return 0; }
   if (id == BNMF_ZSUMK || id == BNMF_ZSUMG || id == BNMF_Z) {
@@ -1061,9 +1064,31 @@ static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm, bool publish = fa
   hipEventRecord(h->ev_sideP, h->side);
   h->side_ev_stale = false;
   h->side_valid = true;
+  h->side_main = false;
   // k_reduce of the PREVIOUS iteration: its inputs are complete once the draws of this iteration have run
   // (main-stream order), which ev_draw above implies, so the main stream needs no marker after k_zalloc
   if (h->red_pending) { issue_reduce(h, h->red_t, h->red_row, tm); h->red_pending = false; }
+}
+// MH / Normal sweeps, steady state (round 4): the hyper sweep of iteration t on the MAIN stream, between the column kernel of t-1 and
+// its tail kernel.  On the side stream it was released by the column kernel through an event (12 us late), ran 20 us beside a 12 us tail
+// kernel, and the next P-row kernel waited 13.6 us of its 101 for the flag (profiles/r04_cfg3_kernel_stats.csv, r04_mh_prow_stamps.txt);
+// alone on the device it is shorter than that wait, and the row kernel behind it needs neither flag nor event.
+static void launch_side_main(bnmf_handle* h, uint32_t t, Timer& tm) {
+  const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
+  const int nbE = (int)(((size_t)h->cfg.N * h->cfg.G + RT - 1) / RT);
+  tm.begin(KN_SIDE, h->stream);
+  hipLaunchKernelGGL(k_side, dim3(h->cfg.N + nbP + nbE), dim3(RT), 0, h->stream, h->dev, t, nbP, 0, rec_at(h, t, fused_rec(h)), SideDone{});
+  tm.end(KN_SIDE, h->stream);
+  h->flags_valid = false;
+  h->side_valid = true;
+  h->side_main = true;
+  // k_reduce of the PREVIOUS iteration stays on the side stream, behind everything issued on the main stream so far
+  if (h->red_pending) {
+    hipEventRecord(h->ev_draw, h->stream);
+    hipStreamWaitEvent(h->side, h->ev_draw, 0);
+    issue_reduce(h, h->red_t, h->red_row, tm);
+    h->red_pending = false;
+  }
 }
 // The same work in three launches, for the Gibbs sweep.  The P-side hyper sweep depends on P_{t-1} only and has
 // the longest per-lane latency (rejection sampling of Alpha): it starts right behind k_pdraw on its own stream.
@@ -1439,10 +1464,11 @@ static int sweep_mh(bnmf_handle* h, int row, int converged, Timer& tm) {
   if (!h->side_valid) launch_side(h, t, tm);
   // prior parameters of iteration t: in the steady state the P-row kernel polls the flag k_side publishes (a stream wait is a
   // barrier packet: ~16 us of bubble per iteration here); after init / set_array / in profile mode a stream wait
-  const bool poll = h->flags_valid && !tm.on && !h->serial;
-  if (!poll) { refresh_side_events(h); hipStreamWaitEvent(h->stream, h->ev_side, 0); hipStreamWaitEvent(h->stream, h->ev_sideP, 0); }
+  const bool on_main = h->side_main;                       // the hyper sweep of t ran on this stream (launch_side_main): nothing to wait for
+  const bool poll = !on_main && h->flags_valid && !tm.on && !h->serial;
+  if (!poll && !on_main) { refresh_side_events(h); hipStreamWaitEvent(h->stream, h->ev_side, 0); hipStreamWaitEvent(h->stream, h->ev_sideP, 0); }
   tm.begin(KN_MH, h->stream); launch_mh_PE(h, t, converged, poll); tm.end(KN_MH, h->stream);
-  launch_side(h, t + 1, tm, !tm.on);
+  if (h->mh_side_main) launch_side_main(h, t + 1, tm); else launch_side(h, t + 1, tm, !tm.on);
   if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
   // record_sample rides in k_mh_tail: after sample_sigmasq, like record_sample (:279) after sample_params (:276)
   tm.begin(KN_OTHER, h->stream); if (int rc = launch_mh_metrics(h, t, h->cfg.learning_rank != 0, true)) return rc; tm.end(KN_OTHER, h->stream);
@@ -1555,7 +1581,7 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
     if (h->dRankCol) HIPCHK(hipMemset(h->dRankCol, 0, (size_t)RK_REP * 4 * 2 * (((size_t)h->cfg.G + RK_MAXC - 1) / RK_MAXC) * sizeof(double)));
     HIPCHK(hipMemset(h->dZsumK, 0, (size_t)h->cfg.N * h->cfg.G * sizeof(int32_t)));
     HIPCHK(hipMemset(h->dZsumG, 0, (size_t)h->cfg.K * h->cfg.N * sizeof(int32_t)));
-    h->side_valid = false; h->flags_valid = false; h->z_gate_next = 0; h->z_gated_for = 0; h->gate_f0 = 1;
+    h->side_valid = false; h->side_main = false; h->flags_valid = false; h->z_gate_next = 0; h->z_gated_for = 0; h->gate_f0 = 1;
     h->side_ev_stale = false; h->red_on_side2 = false; h->red_pending = false; h->red_issued = false; h->mh_prep_valid = false;
     h->inited = false;
   }
