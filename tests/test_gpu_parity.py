@@ -430,9 +430,12 @@ def test_mh_chain_bitexact(prior, G, gw, monkeypatch):
     convergence, true accept/reject after (R/sample_Pn.R:199-248, R/sample_En.R:196-241).  P, E, prior
     parameters, acceptance matrices and metrics bit-exact against the oracle; G = 600 spans two
     320-column segments of the canonical row sums.  gw: lanes per column of the E-side kernel (k_mh_ecol16: 16 before
-    / 32 after convergence by default; both forced here in both phases)."""
+    / 32 after convergence by default; both forced here in both phases).  With gw = "16" the hyper sweep also runs on the side stream
+    with its flag (BNMF_MHSIDE=0, round 3's placement) instead of on the main stream."""
     if gw:
         monkeypatch.setenv("BNMF_MHE_GW", gw)
+    if gw == "16":
+        monkeypatch.setenv("BNMF_MHSIDE", "0")
     import oracle as O
     from bayesnmf_amd import Engine
     from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
