@@ -58,6 +58,21 @@ def test_map_fixed_rank(n, ci):
     e.close()
 
 
+def test_map_window_above_2048_samples():
+    """More than 2,048 samples in the window: the credible bounds then come from the per-lane running sets of the kt smallest / largest
+    values (k_map_stats; up to 2,048 samples a wave sorts an element's samples: k_map_quant, round 4) — same values either way."""
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    M, _, _ = synth_counts(96, 40, 3, 6)
+    e = Engine(M, 3, prior="gamma", seed=4, window=2100)
+    apply_hyperprior_params(e, "gamma", M, 3)
+    e.init()
+    e.run(2150, metrics=False)
+    _check(e, 2100, 0.95, M)
+    _check(e, 2048, 0.95, M)
+    e.close()
+
+
 def test_map_learned_rank_mode_of_A():
     """Several A patterns in the window: only the samples at the mode enter the means."""
     from bayesnmf_amd import Engine
