@@ -1998,36 +1998,6 @@ int bnmf_run_post_warmup(bnmf_handle* h, const bnmf_convergence_control* cc, bnm
   return 0;
 }
 
-// rectangular assignment problem, n rows <= m columns, minimising sum of cost[i][col(i)] (Hungarian algorithm with
-// potentials, O(n^2 m)); returns the column of every row
-static std::vector<int> hungarian_min(const std::vector<double>& cost, int n, int m) {
-  const double INF = 1e300;
-  std::vector<double> u(n + 1, 0.0), v(m + 1, 0.0);
-  std::vector<int> p(m + 1, 0), way(m + 1, 0);
-  for (int i = 1; i <= n; ++i) {
-    p[0] = i;
-    int j0 = 0;
-    std::vector<double> minv(m + 1, INF);
-    std::vector<char> usedc(m + 1, 0);
-    do {
-      usedc[j0] = 1;
-      const int i0 = p[j0];
-      double delta = INF;
-      int j1 = 0;
-      for (int j = 1; j <= m; ++j) if (!usedc[j]) {
-        const double cur = cost[(size_t)(i0 - 1) * m + (j - 1)] - u[i0] - v[j];
-        if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
-        if (minv[j] < delta) { delta = minv[j]; j1 = j; }
-      }
-      for (int j = 0; j <= m; ++j) { if (usedc[j]) { u[p[j]] += delta; v[j] -= delta; } else minv[j] -= delta; }
-      j0 = j1;
-    } while (p[j0] != 0);
-    do { const int j1 = way[j0]; p[j0] = p[j1]; j0 = j1; } while (j0);
-  }
-  std::vector<int> col(n, -1);
-  for (int j = 1; j <= m; ++j) if (p[j]) col[p[j] - 1] = j - 1;
-  return col;
-}
 static double quantile7(std::vector<double> x, double prob) {
   std::sort(x.begin(), x.end());
   const double hq = (x.size() - 1) * prob;
@@ -2060,7 +2030,7 @@ int bnmf_assign(bnmf_handle* h, int last_n, const int32_t* used, const double* r
   // one scratch allocation per handle, grown on demand (the ensemble assignment is called once per result, but BIC sweeps call it per rank)
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const size_t oRef = 0, oN2 = oRef + up(refT.size() * 8), oOut = oN2 + up((size_t)R * 8), oSl = oOut + up(nout * 8), oSig = oSl + up((size_t)nu * sizeof(int)),
-               need = oSig + up((size_t)nk * sizeof(int));
+               oCol = oSig + up((size_t)nk * sizeof(int)), need = oCol + up((size_t)nu * std::min(nk, R) * sizeof(int32_t));
   if (need > h->asg_bytes) {
     if (h->dAsg) { HIPCHK(hipFree(h->dAsg)); h->dAsg = nullptr; h->asg_bytes = 0; }
     HIPCHK(hipMalloc(&h->dAsg, need));
@@ -2068,30 +2038,34 @@ int bnmf_assign(bnmf_handle* h, int last_n, const int32_t* used, const double* r
   }
   double *dRef = (double*)(h->dAsg + oRef), *dN2 = (double*)(h->dAsg + oN2), *dOut = (double*)(h->dAsg + oOut);
   int *dSl = (int*)(h->dAsg + oSl), *dSig = (int*)(h->dAsg + oSig);
+  int32_t* dCol = (int32_t*)(h->dAsg + oCol);
   HIPCHK(hipMemcpy(dRef, refT.data(), refT.size() * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dN2, rn2.data(), R * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dSl, slots.data(), nu * sizeof(int), hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dSig, sig.data(), nk * sizeof(int), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_ref_cosine, dim3(nu, nk), dim3(128), 0, h->stream, (const double*)h->arr[BNMF_P].ring, (size_t)K * N, K, (const int*)dSl,
                      (const int*)dSig, nk, (const double*)dRef, (const double*)dN2, R, dOut);
   HIPCHK(hipGetLastError());
+  // one Hungarian assignment per sample (maximise the total cosine), one wave each; with more signatures than references the
+  // references are the rows
+  const bool tr = nk > R;
+  const int nrow = tr ? R : nk, ncol = tr ? nk : R;
+  const size_t hung_lds = (size_t)(ncol + 1) * (16 + 12) + (size_t)(nrow + 1) * 8;
+  if (hung_lds > 160 * 1024) return fail(BNMF_ESIZE, "bnmf_assign: %d x %d assignment problem exceeds the LDS of one workgroup", nrow, ncol);
+  HIPCHK(hipFuncSetAttribute((const void*)k_hungarian, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hung_lds));
+  HIPCHK(hipMemsetAsync(dCol, 0xff, (size_t)nu * nrow * sizeof(int32_t), h->stream));
+  hipLaunchKernelGGL(k_hungarian, dim3(nu), dim3(64), hung_lds, h->stream, (const double*)dOut, nk, R, tr ? 1 : 0, dCol);
+  HIPCHK(hipGetLastError());
   std::vector<double> cosv(nout);
+  std::vector<int32_t> col((size_t)nu * nrow);
   HIPCHK(hipMemcpyAsync(cosv.data(), dOut, nout * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(col.data(), dCol, col.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  // one Hungarian assignment per sample (maximise the total cosine); the cosine of a chosen pair is its vote
-  const bool tr = nk > R;                                  // more signatures than references: assign references to signatures
-  std::vector<double> cost;
+  // the cosine of a chosen pair is its vote; the votes are summed in sample order
   for (int s = 0; s < nu; ++s) {
     const double* c = cosv.data() + (size_t)s * nk * R;
-    if (!tr) {
-      cost.assign((size_t)nk * R, 0.0);
-      for (size_t i = 0; i < (size_t)nk * R; ++i) cost[i] = -c[i];
-      const std::vector<int> col = hungarian_min(cost, nk, R);
-      for (int i = 0; i < nk; ++i) votes[sig[i] + (size_t)N * col[i]] += c[(size_t)i * R + col[i]];
-    } else {
-      cost.assign((size_t)R * nk, 0.0);
-      for (int i = 0; i < nk; ++i) for (int j = 0; j < R; ++j) cost[(size_t)j * nk + i] = -c[(size_t)i * R + j];
-      const std::vector<int> row = hungarian_min(cost, R, nk);
-      for (int j = 0; j < R; ++j) votes[sig[row[j]] + (size_t)N * j] += c[(size_t)row[j] * R + j];
-    }
+    const int32_t* a = col.data() + (size_t)s * nrow;
+    for (int r = 0; r < nrow; ++r) if (a[r] < 0 || a[r] >= ncol) return fail(BNMF_ESTATE, "bnmf_assign: sample %d has no assignment (a cosine is not finite)", s);
+    if (!tr) for (int i = 0; i < nk; ++i) votes[sig[i] + (size_t)N * a[i]] += c[(size_t)i * R + a[i]];
+    else for (int j = 0; j < R; ++j) votes[sig[a[j]] + (size_t)N * j] += c[(size_t)a[j] * R + j];
   }
   for (int i = 0; i < nk; ++i) {                           // which.max(prop_votes): first maximum
     const int n = sig[i];

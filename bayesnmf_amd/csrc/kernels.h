@@ -1031,6 +1031,67 @@ __global__ __launch_bounds__(128) void k_ref_cosine(const double* ringP, size_t 
   }
 }
 
+// ---- hungarian_assignment of one sample (R/helpers.R:287-398: RcppHungarian::HungarianSolver(-sim)) — one wave per sample (round 4) ----
+// The rectangular assignment problem, n rows <= m columns, minimising sum cost[row][col(row)], by the shortest-augmenting-path method
+// with potentials (O(n^2 m)): the columns are spread over the lanes (the scan for the next column and the update of the potentials are
+// the two loops over m), ties go to the lowest column index, every floating-point operation is the one the sequential algorithm makes —
+// the assignment is the sequential algorithm's.  cost[row][col] = -cos[sig][ref]: rows are the kept signatures (tr = 0), or, with more
+// signatures than references, the references (tr = 1).  out[s][row] = column of the row.
+__global__ __launch_bounds__(64) void k_hungarian(const double* cosv /* [s][nk][R] */, int nk, int R, int tr, int32_t* out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int n = tr ? R : nk, m = tr ? nk : R;
+  const int lane = threadIdx.x;
+  const double* c = cosv + (size_t)blockIdx.x * nk * R;
+  double* v = (double*)smem;                               // [m + 1]
+  double* minv = v + (m + 1);                              // [m + 1]
+  double* u = minv + (m + 1);                              // [n + 1]
+  int* p = (int*)(u + (n + 1));                            // [m + 1] row matched to the column (0: none)
+  int* way = p + (m + 1);                                  // [m + 1]
+  int* usedc = way + (m + 1);                              // [m + 1]
+  const double INF = 1e300;
+  auto cost = [&](int row, int col) { return tr ? -c[(size_t)col * R + row] : -c[(size_t)row * R + col]; };
+  for (int j = lane; j <= m; j += 64) { v[j] = 0.0; p[j] = 0; way[j] = 0; }
+  for (int i = lane; i <= n; i += 64) u[i] = 0.0;
+  wave_lds_fence();
+  for (int i = 1; i <= n; ++i) {
+    if (lane == 0) p[0] = i;
+    for (int j = lane; j <= m; j += 64) { minv[j] = INF; usedc[j] = 0; }
+    wave_lds_fence();
+    int j0 = 0;
+    do {
+      if (lane == 0) usedc[j0] = 1;
+      wave_lds_fence();
+      const int i0 = p[j0];
+      const double ui0 = u[i0];
+      double delta = INF;
+      int j1 = 0x7fffffff;
+      for (int j = lane + 1; j <= m; j += 64)              // ascending j inside the lane: the first minimum stays
+        if (!usedc[j]) {
+          const double cur = (cost(i0 - 1, j - 1) - ui0) - v[j];
+          double mv = minv[j];
+          if (cur < mv) { mv = cur; minv[j] = cur; way[j] = j0; }
+          if (mv < delta) { delta = mv; j1 = j; }
+        }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {                  // the smallest value, the lowest column among equals
+        const double d2 = __shfl_xor(delta, o, 64);
+        const int k2 = __shfl_xor(j1, o, 64);
+        if (d2 < delta || (d2 == delta && k2 < j1)) { delta = d2; j1 = k2; }
+      }
+      for (int j = lane; j <= m; j += 64) {
+        if (usedc[j]) { u[p[j]] = u[p[j]] + delta; v[j] = v[j] - delta; }
+        else minv[j] = minv[j] - delta;
+      }
+      wave_lds_fence();
+      if (j1 > m) return;                                  // no finite reduced cost (a cosine is NaN): the rows stay -1, the host reports it
+      j0 = j1;
+    } while (p[j0] != 0);
+    if (lane == 0) { do { const int jn = way[j0]; p[j0] = p[jn]; j0 = jn; } while (j0); }
+    wave_lds_fence();
+  }
+  for (int j = lane + 1; j <= m; j += 64) if (p[j]) out[(size_t)blockIdx.x * n + (p[j] - 1)] = j - 1;
+}
+
 // ---- constructor draws of the prior parameters from the hyper-priors ----
 // init_prior_params_ R/sample_priors.R:15-141 (all three families are rgamma(shape, rate) draws
 // for the Gamma / Exponential priors).  redraw[n] != 0: column n (P side) / row n (E side) missing.

@@ -154,7 +154,7 @@ int bnmf_run_post_warmup(bnmf_handle* h, const bnmf_convergence_control* cc, bnm
 /* Posterior reference assignment (assign_signatures_ensemble_, R/postprocessing.R:175-341; hungarian_assignment,
  * pairwise_sim, R/helpers.R:218-398) over the recorded samples flagged in used[last_n] (MAP$idx; NULL = all):
  * cosine similarities of every sample's included signatures (keep[N] flags; NULL = all) with the reference catalogue
- * reference_P (K x R, column-major) on the device, one Hungarian assignment per sample maximising the total cosine,
+ * reference_P (K x R, column-major) and one Hungarian assignment per sample maximising the total cosine, both on the device,
  * votes[n + N*j] = sum over samples of the cosine of the pairs (n, j) chosen; assigned_ref[n] = which.max of the votes
  * (-1 for a signature that is not kept); MAP_P (K x N, may be NULL) -> MAP_cosine[n]; lower/upper_cosine[n] =
  * quantile(type 7) of the per-sample cosine between signature n and its assigned reference. */

@@ -36,15 +36,15 @@ def _np_assign(Ps, ref, keep, MAP_P, ci):
     return out
 
 
-@pytest.mark.parametrize("R,lr", [(79, False), (79, True), (3, False)])
-def test_assign_matches_scipy(R, lr):
+@pytest.mark.parametrize("R,lr,N", [(79, False, 5), (79, True, 5), (3, False, 5), (150, False, 5), (8, False, 12), (200, False, 20)])
+def test_assign_matches_scipy(R, lr, N):
+    """(150 / 200 references: several columns per lane of the assignment kernel; 3 and 8: more signatures than references)"""
     from bayesnmf_amd import Engine
     from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
     rng = np.random.default_rng(R)
     cosmic = np.load(os.path.join(GOLD, "cosmic_v3.3.1_sbs.npz"))["P"]
     ref = cosmic[:, :R] if R <= cosmic.shape[1] else rng.dirichlet(np.ones(96), size=R).T
     M, _, _ = synth_counts(96, 64, 4, 33)
-    N = 5
     temp = np.concatenate([np.zeros(3), 10.0 ** np.linspace(-6, 0, 60), np.ones(200)]) if lr else None
     e = Engine(M, N, prior="gamma", learning_rank=lr, seed=4, window=80, temperature=temp)
     apply_hyperprior_params(e, "gamma", M, N)
