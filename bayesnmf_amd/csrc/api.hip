@@ -1838,10 +1838,9 @@ int bnmf_map(bnmf_handle* h, int last_n, double ci, double* P_mean, double* E_me
   }
   // the bounds by sorting (k_map_quant) when the samples of 8 elements fit the LDS; else by the kt smallest / largest per lane
   int qS = 0;
-  if (want_ci) { qS = ((nu + 63) / 64) * 64; if ((size_t)qS * MQ_E * sizeof(double) > 128 * 1024) qS = 0; }
+  if (want_ci) { qS = ((nu + 63) / 64) * 64; if (qS > 2048) qS = 0; }
   if (want_ci && !qS && (size_t)kt * 2 * 64 * sizeof(double) > 160 * 1024)
     return fail(BNMF_EINVAL, "bnmf_map: credible_interval %.3g over %d samples needs %d order statistics per element (device limit 160): take the window with bnmf_window", ci, nu, kt);
-  if (qS) kt = 0;                                          // k_map_stats then computes the means only
   const size_t words = (size_t)nu * N + 3 * (lenP + lenE) + 2 * (size_t)G + N + ((size_t)nu + 1) / 2 + 8;
   if (words > h->map_words) { if (h->dMap) HIPCHK(hipFree(h->dMap)); h->dMap = nullptr; HIPCHK(hipMalloc(&h->dMap, words * sizeof(double))); h->map_words = words; }
   double* cs = h->dMap; double* mP = cs + (size_t)nu * N; double* loP = mP + lenP; double* hiP = loP + lenP;
@@ -1850,25 +1849,28 @@ int bnmf_map(bnmf_handle* h, int last_n, double ci, double* P_mean, double* E_me
   HIPCHK(hipMemcpyAsync(dslots, slots.data(), nu * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(dA, Am.data(), N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(k_map_colsum, dim3(nu, N), dim3(64), 0, h->stream, (const double*)h->arr[BNMF_P].ring, lenP, K, N, (const int*)dslots, cs);
-  const size_t lds = (size_t)kt * 2 * 64 * sizeof(double);
-  if (lds > 64 * 1024) {
-    HIPCHK(hipFuncSetAttribute((const void*)k_map_stats<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)k_map_stats<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  }
-  hipLaunchKernelGGL(k_map_stats<0>, dim3((unsigned)((lenP + 63) / 64)), dim3(64), lds, h->stream, (const double*)h->arr[BNMF_P].ring, lenP, K, N,
-                     (const int*)dslots, nu, (const double*)cs, kt, jlo, glo, jhi, ghi, mP, loP, hiP);
-  hipLaunchKernelGGL(k_map_stats<1>, dim3((unsigned)((lenE + 63) / 64)), dim3(64), lds, h->stream, (const double*)h->arr[BNMF_E].ring, lenE, K, N,
-                     (const int*)dslots, nu, (const double*)cs, kt, jlo, glo, jhi, ghi, mE, loE, hiE);
-  if (qS) {
-    const size_t qlds = (size_t)qS * MQ_E * sizeof(double);
-    if (qlds > 64 * 1024) {
-      HIPCHK(hipFuncSetAttribute((const void*)k_map_quant<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)k_map_quant<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  if (!qS) {                                              // means (and, beyond 2,048 samples, the bounds) by a lane per element
+    const size_t lds = (size_t)kt * 2 * 64 * sizeof(double);
+    if (lds > 64 * 1024) {
+      HIPCHK(hipFuncSetAttribute((const void*)k_map_stats<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)k_map_stats<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    hipLaunchKernelGGL(k_map_quant<0>, dim3((unsigned)((lenP + MQ_E - 1) / MQ_E)), dim3(MQ_T), qlds, h->stream, (const double*)h->arr[BNMF_P].ring, lenP, K, N,
-                       (const int*)dslots, nu, qS, (const double*)cs, jlo, glo, jhi, ghi, loP, hiP);
-    hipLaunchKernelGGL(k_map_quant<1>, dim3((unsigned)((lenE + MQ_E - 1) / MQ_E)), dim3(MQ_T), qlds, h->stream, (const double*)h->arr[BNMF_E].ring, lenE, K, N,
-                       (const int*)dslots, nu, qS, (const double*)cs, jlo, glo, jhi, ghi, loE, hiE);
+    hipLaunchKernelGGL(k_map_stats<0>, dim3((unsigned)((lenP + 63) / 64)), dim3(64), lds, h->stream, (const double*)h->arr[BNMF_P].ring, lenP, K, N,
+                       (const int*)dslots, nu, (const double*)cs, kt, jlo, glo, jhi, ghi, mP, loP, hiP);
+    hipLaunchKernelGGL(k_map_stats<1>, dim3((unsigned)((lenE + 63) / 64)), dim3(64), lds, h->stream, (const double*)h->arr[BNMF_E].ring, lenE, K, N,
+                       (const int*)dslots, nu, (const double*)cs, kt, jlo, glo, jhi, ghi, mE, loE, hiE);
+  }
+  if (qS) {
+    const bool r16 = qS <= 1024;                           // 16 or 32 samples per lane column
+    const size_t qS2 = r16 ? 1024 : 2048, qlds = qS2 * MQ_E * sizeof(double) + qS2 * sizeof(int);
+    auto go = [&](auto kern, const double* ring, size_t len, double* mn, double* lo, double* hi) {
+      if (qlds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds));
+      hipLaunchKernelGGL(kern, dim3((unsigned)((len + MQ_E - 1) / MQ_E)), dim3(MQ_T), qlds, h->stream, ring, len, K, N, (const int*)dslots, nu,
+                         (const double*)cs, jlo, glo, jhi, ghi, mn, lo, hi);
+      return 0;
+    };
+    if (r16) { if (int rc = go(k_map_quant<0, 16>, h->arr[BNMF_P].ring, lenP, mP, loP, hiP)) return rc; if (int rc = go(k_map_quant<1, 16>, h->arr[BNMF_E].ring, lenE, mE, loE, hiE)) return rc; }
+    else { if (int rc = go(k_map_quant<0, 32>, h->arr[BNMF_P].ring, lenP, mP, loP, hiP)) return rc; if (int rc = go(k_map_quant<1, 32>, h->arr[BNMF_E].ring, lenE, mE, loE, hiE)) return rc; }
   }
   hipLaunchKernelGGL(k_map_fit, dim3((G + 3) / 4), dim3(256), 0, h->stream, (const int32_t*)h->dM, (const double*)mP, (const double*)dA, (const double*)mE, K, N, G, colsse, colkl);
   HIPCHK(hipGetLastError());

@@ -898,101 +898,187 @@ __global__ __launch_bounds__(64) void k_map_stats(const double* ring, size_t len
 // ---- k_map_quant: the credible bounds of get_MAP_ (R/utils.R:269-284, quantile type 7) by a wave per element (round 4) ----
 // k_map_stats keeps the kt smallest / largest values of an element per LANE, and some lane of the wave replaces one at nearly
 // every sample: the whole wave then walks the kt-entry scan (7.5 ms for 202,000 elements x 1,000 samples).  Here a workgroup
-// takes 8 consecutive elements: their samples are read as whole 64-byte lines (sample s: elements e0 .. e0 + 7), renormalised
-// (the same expression as k_map_stats) and laid out [element][S] in LDS (S: n_used rounded up to whole rounds of 64).  A wave
-// takes two of the elements in turn: lane l sorts its own samples l, l + 64, ... (a column of <= 32 values), then the order
-// statistics needed — a few dozen from each end at the default interval — are drawn one by one as the minimum (maximum) over the
-// lanes' column heads.  The same values, the same interpolation.
-constexpr int MQ_T = 256, MQ_E = 8;
-// minimum / maximum over the wave on every lane: wave_tree64's exchanges (v_permlane32_swap, v_permlane16_swap, DPP row shifts: no
-// LDS crossbar, a tenth of the latency of six ds_bpermute round trips) with min / max for +, then lane 0's value through the scalar unit
-#define BNMF_WAVE_EXTREMUM(NAME, PICK)                                                                             \
-BNMF_DEV double NAME(double v) {                                                                                   \
-  {                                                                                                                \
-    const unsigned lo = (unsigned)__double_as_longlong(v), hi = (unsigned)(__double_as_longlong(v) >> 32);         \
-    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);                                         \
-    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);                                         \
-    const double w = __longlong_as_double(((long long)b[1] << 32) | (unsigned)a[1]);                               \
-    v = PICK;                                                                                                      \
-  }                                                                                                                \
-  {                                                                                                                \
-    const unsigned lo = (unsigned)__double_as_longlong(v), hi = (unsigned)(__double_as_longlong(v) >> 32);         \
-    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);                                         \
-    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);                                         \
-    const double w = __longlong_as_double(((long long)b[1] << 32) | (unsigned)a[1]);                               \
-    v = PICK;                                                                                                      \
-  }                                                                                                                \
-  _Pragma("unroll")                                                                                                \
-  for (int st = 0; st < 4; ++st) {                                                                                 \
-    int lo = (int)__double_as_longlong(v), hi = (int)(__double_as_longlong(v) >> 32);                              \
-    if (st == 0) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x108, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x108, 0xf, 0xf, false); } \
-    if (st == 1) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x104, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x104, 0xf, 0xf, false); } \
-    if (st == 2) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x102, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x102, 0xf, 0xf, false); } \
-    if (st == 3) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x101, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x101, 0xf, 0xf, false); } \
-    const double w = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);                                   \
-    v = PICK;                                                                                                      \
-  }                                                                                                                \
-  return wave_bcast0(v);                                                                                           \
+// takes 8 consecutive elements: their samples are read as whole 64-byte lines (sample s: elements e0 .. e0 + 7; the slot list sits
+// in LDS and a lane has 8 lines in flight), renormalised (the same expression as k_map_stats) and laid out [element][S] in LDS
+// (S = 64 R: n_used rounded up, the rest +inf).  A wave takes two of the elements: lane l sorts its own samples l, l + 64, ... (a
+// column of R values) in REGISTERS (a bitonic network of min / max pairs) and writes the column back; then the order statistics needed
+// — a few dozen from each end at the default interval — are drawn one by one as the minimum (maximum) over the lanes' column heads,
+// the four chains (two elements, two ends) side by side in one loop: each is a row of dependent wave reductions.  The same values, the
+// same interpolation.
+constexpr int MQ_T = 512, MQ_E = 8;
+// minimum / maximum over the wave, as a wave-uniform value: the GFX9 DPP reduction (row_shr 1, 2, 4, 8: lane 15 of a row holds the row's;
+// row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3: lane 63 holds the wave's), v_min_f64 / v_max_f64 issued as they are
+// (the compiler's fmin quiets both operands first); lanes a shift leaves without a source hold values no later step of lane 63's tree reads
+template <int CTRL, int ROWS>
+BNMF_DEV double dpp_mov_d(double v) {
+  const int lo = (int)__double_as_longlong(v), hi = (int)(__double_as_longlong(v) >> 32);
+  const int a = __builtin_amdgcn_mov_dpp(lo, CTRL, ROWS, 0xf, true), b = __builtin_amdgcn_mov_dpp(hi, CTRL, ROWS, 0xf, true);
+  return __longlong_as_double(((long long)b << 32) | (unsigned)a);
 }
-BNMF_WAVE_EXTREMUM(wave_min_all, (w < v ? w : v))
-BNMF_WAVE_EXTREMUM(wave_max_all, (w > v ? w : v))
+BNMF_DEV double vmin_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+BNMF_DEV double vmax_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+BNMF_DEV double wave_lane63(double v) {
+  const int lo = __builtin_amdgcn_readlane((int)__double_as_longlong(v), 63), hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(v) >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+#define BNMF_WAVE_EXTREMUM(NAME, OP)                                                                               \
+BNMF_DEV double NAME(double v) {                                                                                   \
+  v = OP(dpp_mov_d<0x111, 0xf>(v), v);                                                                             \
+  v = OP(dpp_mov_d<0x112, 0xf>(v), v);                                                                             \
+  v = OP(dpp_mov_d<0x114, 0xf>(v), v);                                                                             \
+  v = OP(dpp_mov_d<0x118, 0xf>(v), v);                                                                             \
+  v = OP(dpp_mov_d<0x142, 0xa>(v), v);                                                                             \
+  v = OP(dpp_mov_d<0x143, 0xc>(v), v);                                                                             \
+  return wave_lane63(v);                                                                                           \
+}
+BNMF_WAVE_EXTREMUM(wave_min_all, vmin_f64)
+BNMF_WAVE_EXTREMUM(wave_max_all, vmax_f64)
 #undef BNMF_WAVE_EXTREMUM
-template <int SIDE>
-__global__ __launch_bounds__(MQ_T) void k_map_quant(const double* ring, size_t len, int K, int N, const int* slots, int n_used, int S,
-                                                    const double* cs, int jlo, double glo, int jhi, double ghi, double* lower, double* upper) {
+// ascending sort of R values held in registers (R a power of two; every index below is a compile-time constant after unrolling)
+template <int R>
+BNMF_DEV void reg_sort(double (&a)[R]) {
+#pragma unroll
+  for (int k = 2; k <= R; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          const double x = a[i], y = a[l];
+          const bool sw = ((i & k) == 0) ? (x > y) : (x < y);
+          a[i] = sw ? y : x; a[l] = sw ? x : y;
+        }
+      }
+    }
+  }
+}
+template <int SIDE, int R>
+__global__ __launch_bounds__(MQ_T) void k_map_quant(const double* ring, size_t len, int K, int N, const int* slots, int n_used,
+                                                    const double* cs, int jlo, double glo, int jhi, double ghi, double* mean, double* lower, double* upper) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int S = 64 * R;
+  constexpr bool NIOK = (S / (MQ_T / MQ_E)) % 8 == 0;
   double* tile = (double*)smem;                           // [MQ_E][S]
+  int* sl = (int*)(tile + (size_t)MQ_E * S);              // [S] ring slots of the samples
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t e0 = (size_t)blockIdx.x * MQ_E;
+  for (int s = tid; s < n_used; s += MQ_T) sl[s] = slots[s];
+  __syncthreads();
   {
-    const int j = tid & (MQ_E - 1);
+    constexpr int SPR = MQ_T / MQ_E, NI = S / SPR;        // samples per round of the workgroup; rounds
+    const int j = tid & (MQ_E - 1), sb = tid >> 3;        // samples sb, sb + SPR, ...: NI of them
     const size_t e = e0 + j;
     const bool live = e < len;
-    const int n = live ? (SIDE ? (int)(e % (size_t)N) : (int)(e / (size_t)K)) : 0;
-    for (int s = tid >> 3; s < n_used; s += MQ_T / MQ_E) {
-      double x = 0.0;
-      if (live) {
-        const double v = ring[(size_t)slots[s] * len + e], c = cs[(size_t)s * N + n];
-        x = SIDE ? v * c : v / c;
+    const size_t ec = live ? e : len - 1;
+    const int n = SIDE ? (int)(ec % (size_t)N) : (int)(ec / (size_t)K);
+    constexpr int B = 8;
+#pragma unroll 1
+    for (int i0 = 0; i0 < NI; i0 += B) {
+      double v[B], c[B];
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const int s = sb + SPR * (i0 + b);
+        const int sc = min(s, n_used - 1);                  // every load is made (no branch around it): 8 lines in flight
+        v[b] = ring[(size_t)sl[sc] * len + ec];
+        c[b] = cs[(size_t)sc * N + n];
       }
-      tile[(size_t)j * S + s] = x;
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const int s = sb + SPR * (i0 + b);
+        tile[(size_t)j * S + s] = (live && s < n_used) ? (SIDE ? v[b] * c[b] : v[b] / c[b]) : __builtin_inf();
+      }
     }
   }
   __syncthreads();
   const int cnt = lane < n_used ? (n_used - lane + 63) >> 6 : 0;      // samples of this lane's column
   const int jl1 = min(jlo + 1, n_used - 1), jh1 = min(jhi + 1, n_used - 1);
-  for (int q = 0; q < MQ_E / (MQ_T / 64); ++q) {
-    const int j = wave * (MQ_E / (MQ_T / 64)) + q;
-    if (e0 + j >= len) break;                             // wave-uniform
-    double* a = tile + (size_t)j * S + lane;              // a[64 r]: the lane's column
-    lane_sort(a, cnt);
-    wave_lds_fence();
-    double x0 = 0.0, x1 = 0.0, y0 = 0.0, y1 = 0.0;
-    {
-      int p = 0;
-      double hv = cnt > 0 ? a[0] : __builtin_inf();
-      for (int c = 0; c <= jl1; ++c) {                    // order statistics 0 .. jl1 in ascending order
-        const double m = wave_min_all(hv);
-        if (c == jlo) x0 = m;
-        if (c == jl1) x1 = m;
-        const unsigned long long eq = __builtin_amdgcn_ballot_w64(hv == m);
-        if (eq && lane == (int)__builtin_ctzll(eq)) { ++p; hv = p < cnt ? a[64 * p] : __builtin_inf(); }
-      }
+  constexpr int EW = MQ_E / (MQ_T / 64);                  // elements of a wave
+  static_assert(EW >= 1 && NIOK, "a wave takes whole elements");
+  // the means (get_MAP_: the sum in sample order, as k_map_stats forms it) while the samples still lie in sample order: lane q of the
+  // wave walks element q of the wave — 2 lanes for a few microseconds against a second pass over the window by another kernel
+  if (mean && lane < EW) {
+    const double* x = tile + (size_t)(wave * EW + lane) * S;
+    double sum = 0.0;
+    int s0 = 0;
+    for (; s0 + 8 <= n_used; s0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) v[b] = x[s0 + b];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) sum = sum + v[b];
     }
-    {
-      int p = cnt - 1;
-      double hv = cnt > 0 ? a[64 * p] : -__builtin_inf();
-      for (int c = n_used - 1; c >= jhi; --c) {           // order statistics n_used - 1 .. jhi in descending order
-        const double m = wave_max_all(hv);
-        if (c == jh1) y1 = m;
-        if (c == jhi) y0 = m;
-        const unsigned long long eq = __builtin_amdgcn_ballot_w64(hv == m);
-        if (eq && lane == (int)__builtin_ctzll(eq)) { --p; hv = p >= 0 ? a[64 * p] : -__builtin_inf(); }
-      }
+    for (; s0 < n_used; ++s0) sum = sum + x[s0];
+    const size_t e = e0 + (size_t)(wave * EW + lane);
+    if (e < len) mean[e] = sum / (double)n_used;
+  }
+  double* col[EW];
+#pragma unroll
+  for (int q = 0; q < EW; ++q) {
+    col[q] = tile + (size_t)(wave * EW + q) * S + lane;   // col[64 r]: the lane's column
+    double a[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = col[q][64 * r];
+    reg_sort<R>(a);
+#pragma unroll
+    for (int r = 0; r < R; ++r) col[q][64 * r] = a[r];
+  }
+  wave_lds_fence();
+  // the column heads (lov / hiv), the values behind them (lon / hin: loaded when the head moves, a whole reduction before they are
+  // needed) and their positions; no branch in a step, so that the chains of a wave interleave
+  double x0[EW] = {}, x1[EW] = {}, y0[EW] = {}, y1[EW] = {}, lov[EW], hiv[EW], lon[EW], hin[EW];
+  int pl[EW], ph[EW];
+  const double INF = __builtin_inf();
+#pragma unroll
+  for (int q = 0; q < EW; ++q) {
+    pl[q] = 0; ph[q] = cnt - 1;
+    lov[q] = col[q][0];                                   // +inf where the column is empty
+    lon[q] = col[q][64];
+    hiv[q] = cnt > 0 ? col[q][64 * ph[q]] : -INF;
+    hin[q] = cnt > 1 ? col[q][64 * (ph[q] - 1)] : -INF;
+  }
+  const int nlo = jl1 + 1, nhi = n_used - jhi;           // order statistics 0 .. jl1 ascending, n_used - 1 .. jhi descending
+  auto low_step = [&](int c) {
+#pragma unroll
+    for (int q = 0; q < EW; ++q) {
+      const double m = wave_min_all(lov[q]);
+      if (c == jlo) x0[q] = m;
+      if (c == jl1) x1[q] = m;
+      const unsigned long long eq = __builtin_amdgcn_ballot_w64(lov[q] == m);
+      const bool win = lane == (int)__builtin_ctzll(eq);  // the first lane that holds it gives it up
+      lov[q] = win ? lon[q] : lov[q];
+      pl[q] += win ? 1 : 0;
+      const double nx = col[q][64 * min(pl[q] + 1, R - 1)];
+      lon[q] = pl[q] + 1 < R ? nx : INF;
     }
-    if (lane == 0) {
-      lower[e0 + j] = (1.0 - glo) * x0 + glo * x1;
-      upper[e0 + j] = (1.0 - ghi) * y0 + ghi * y1;
+  };
+  auto high_step = [&](int c) {
+    const int os = n_used - 1 - c;
+#pragma unroll
+    for (int q = 0; q < EW; ++q) {
+      const double m = wave_max_all(hiv[q]);
+      if (os == jh1) y1[q] = m;
+      if (os == jhi) y0[q] = m;
+      const unsigned long long eq = __builtin_amdgcn_ballot_w64(hiv[q] == m);
+      const bool win = lane == (int)__builtin_ctzll(eq);
+      hiv[q] = win ? hin[q] : hiv[q];
+      ph[q] -= win ? 1 : 0;
+      const double nx = col[q][64 * max(ph[q] - 1, 0)];
+      hin[q] = ph[q] - 1 >= 0 ? nx : -INF;
+    }
+  };
+  const int nboth = min(nlo, nhi);
+  for (int c = 0; c < nboth; ++c) { low_step(c); high_step(c); }
+  for (int c = nboth; c < nlo; ++c) low_step(c);
+  for (int c = nboth; c < nhi; ++c) high_step(c);
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < EW; ++q) {
+      const size_t e = e0 + (size_t)(wave * EW + q);
+      if (e < len) {
+        lower[e] = (1.0 - glo) * x0[q] + glo * x1[q];
+        upper[e] = (1.0 - ghi) * y0[q] + ghi * y1[q];
+      }
     }
   }
 }
