@@ -58,6 +58,7 @@ struct bnmf_handle {
   uint32_t z_gate_next = 0;            // != 0: the allocation kernel being launched waits at its end for the hyper sweep of this iteration
   uint32_t z_gated_for = 0;            // the last allocation kernel gated for this iteration's hyper sweep (merged draw kernel, BNMF_GATE)
   bool side_ev_stale = false;          // ev_sideP / ev_side not recorded since the last side launches (fixed-rank sweep: recorded on demand)
+  bool mhe16 = false;                  // the MH / Normal column sweep by k_mh_ecol16 (K <= 128 and its LDS fits)
   bool red_on_side2 = false;           // the last k_reduce was issued on side2 (then side2 needs no event to be ordered behind it)
   double* E_alt = nullptr;             // Gibbs sweep: the other E buffer (k_edraw of t+1 does not overwrite what k_lpe of t still reads)
   bool mh_prep_valid = false;          // MH / Normal models: Et, nzE are current and nzP is zero (k_mh_tail of the previous iteration)
@@ -661,6 +662,17 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
       if (h->mhe_lds > 160 * 1024) return fail(BNMF_EINVAL, "bnmf_create: K = %zu too large for the column kernel of the MH / Normal models (LDS)", K);
       HIPCHK(hipFuncSetAttribute((const void*)k_mh_ecol<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)k_mh_ecol<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    // k_mh_ecol16 (K <= 128: several columns per wave): its LDS grows with N — above 64 KiB it needs the attribute, above the CU's 160 KiB
+    // the sweep takes k_mh_ecol
+    {
+      const size_t lds16_max = (4 * (size_t)4 * N * (1 + PRE_W) + 2 * N) * sizeof(double);   // 16 lanes per column: 4 columns per wave
+      h->mhe16 = K <= (size_t)MHE16_KMAX && lds16_max <= 160 * 1024;
+      if (h->mhe16 && lds16_max > 64 * 1024) {
+        const void* ks[] = {(const void*)k_mh_ecol16<false, false, 16>, (const void*)k_mh_ecol16<false, true, 16>, (const void*)k_mh_ecol16<false, false, 32>,
+                            (const void*)k_mh_ecol16<false, true, 32>, (const void*)k_mh_ecol16<true, false, 16>, (const void*)k_mh_ecol16<true, false, 32>};
+        for (const void* kf : ks) HIPCHK(hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      }
     }
     HIPCHK(hipMalloc(&h->dAccPn, 3 * N * sizeof(double)));
     HIPCHK(hipMalloc(&h->dAccEpart, 3 * (size_t)h->nblkE * sizeof(double)));
@@ -1421,11 +1433,11 @@ static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged, bool poll = 
   else if (mhstep) { if (regP) goP(k_mh_prow<false, true, true>); else goP(k_mh_prow<false, false, true>); }
   else { if (regP) goP(k_mh_prow<false, true, false>); else goP(k_mh_prow<false, false, false>); }
   int grid = (G + 3) / 4; if (grid > 2048) grid = 2048;
-  if (K <= MHE16_KMAX) {                                   // several columns per wave
+  if (h->mhe16) {                                          // several columns per wave
     // lanes per column: 16 for the Gibbs-only sweep, 32 with the MH step (measured at config 3: 117 / 126 us and 276 / 205 us)
     const int gw = h->mhe_gw ? h->mhe_gw : (mhstep ? 32 : 16), cpw = 64 / gw;
     int g16 = ((G + cpw - 1) / cpw + 3) / 4; if (g16 > 2048) g16 = 2048;
-    const size_t lds16 = 4 * (size_t)cpw * N * (1 + PRE_W) * sizeof(double);
+    const size_t lds16 = (4 * (size_t)cpw * N * (1 + PRE_W) + 2 * (size_t)N) * sizeof(double);
     auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)(h->dNzE + N), accE, 0); };
     if (gw == 16) { if (mhstep) go(k_mh_ecol16<false, true, 16>); else go(k_mh_ecol16<false, false, 16>); }
     else { if (mhstep) go(k_mh_ecol16<false, true, 32>); else go(k_mh_ecol16<false, false, 32>); }
@@ -1437,10 +1449,10 @@ static int launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells, bool with_r
   if (draw_sig) cells = true;                 // sigmasq is drawn after R, A (R/sample_params.R:86-88) in the metrics pass
   const int N = h->cfg.N, G = h->cfg.G;
   if (cells) {
-    if (h->cfg.K <= MHE16_KMAX) {
+    if (h->mhe16) {
       const int gw = h->mhe_gw ? h->mhe_gw : 16, cpw = 64 / gw;
       int g16 = ((G + cpw - 1) / cpw + 3) / 4; if (g16 > 2048) g16 = 2048;
-      const size_t lds16 = 4 * (size_t)cpw * N * (1 + PRE_W) * sizeof(double);
+      const size_t lds16 = (4 * (size_t)cpw * N * (1 + PRE_W) + 2 * (size_t)N) * sizeof(double);
       if (gw == 16) hipLaunchKernelGGL((k_mh_ecol16<true, false, 16>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
       else hipLaunchKernelGGL((k_mh_ecol16<true, false, 32>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
     } else {
@@ -1691,13 +1703,20 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
   HIPCHK(hipSetDevice(h->device));
   if (int rc = ensure_metrics(h, (size_t)n_iter)) return rc;
   const uint32_t t0 = (uint32_t)h->iter + 1;
+  // BNMF_RUNCLOCK=1 (diagnostics): host time of the call's phases on stderr
+  static const bool runclock = getenv("BNMF_RUNCLOCK") != nullptr;
+  const auto rc0 = std::chrono::steady_clock::now();
+  auto rc_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - rc0).count(); };
+  double rc_first = 0.0, rc_issued = 0.0, rc_tail = 0.0, rc_main = 0.0;
   for (int i = 0; i < n_iter; ++i) {
+    if (runclock && i == 1) rc_first = rc_us();
     if (int rc = ((h->cfg.MH || h->cfg.likelihood == BNMF_NORMAL) ? sweep_mh(h, i, h->cfg.MH ? converged : 0, tm) : sweep(h, i, tm))) return rc;
     HIPCHK(hipGetLastError());                               // a refused launch of this iteration (bad geometry, LDS size)
     // a bounded in-kernel wait that timed out has set its word (mapped host memory): issue nothing more, so that one stuck
     // hand-off costs one spin bound and not one per remaining launch
     if (((volatile int*)h->hErr)[0] | ((volatile int*)h->hErr)[1]) break;
   }
+  if (runclock) rc_issued = rc_us();
   const bool reduces_on_side2 = h->red_on_side2;          // fixed-rank sweep: every earlier k_reduce sits on side2, which flush_reduce's wait covers
   flush_reduce(h, tm);
   if (!reduces_on_side2) { hipEventRecord(h->ev_z, h->side); hipStreamWaitEvent(h->stream, h->ev_z, 0); }   // the k_reduce launches on `side` are done
@@ -1705,10 +1724,14 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
   HIPCHK(hipGetLastError());
   std::vector<double> own;
   if (!metrics && h->wcap > 0) { own.resize((size_t)n_iter * BNMF_NMETRIC); metrics = own.data(); }
+  if (runclock) rc_tail = rc_us();
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (runclock) rc_main = rc_us();
   if (metrics) memcpy(metrics, h->hMetrics, (size_t)n_iter * BNMF_NMETRIC * sizeof(double));
-  HIPCHK(hipStreamSynchronize(h->side));
+  HIPCHK(hipStreamSynchronize(h->side));                    // (6 us of host time each on an idle stream; hipStreamQuery costs the same)
   HIPCHK(hipStreamSynchronize(h->side2));
+  if (runclock) fprintf(stderr, "[bnmf_run %d] first iteration issued %.1f us, all issued %.1f, tail issued %.1f, main stream idle %.1f, side streams idle %.1f\n",
+                        n_iter, rc_first, rc_issued, rc_tail, rc_main, rc_us());
   if (h->wcap > 0 && metrics) {                             // loglik / logpost of the recorded iterations (MAP metrics are window means)
     if (h->hist.size() != (size_t)h->wcap * 4) h->hist.assign((size_t)h->wcap * 4, std::nan(""));
     for (int i = 0; i < n_iter; ++i) {

@@ -523,10 +523,16 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol16(Dev d, uint32_t t, const in
   const int K = d.K, G = d.G, N = d.N;
   double* ec = (double*)smem + (size_t)(wave * CPW + grp) * N * (1 + PRE_W);   // [N] current column of E, one per group
   double* prq = ec + N;                                       // [N][PRE_W] the column's DrawPre
+  // A[n] and the all(P[,n] == 0) flags of the workgroup: read from LDS inside the factor chain (a scalar load from memory in front of
+  // every step was the chain's longest link, as in the row kernel)
+  double* anz = (double*)smem + (size_t)(MHE_T / 64) * CPW * N * (1 + PRE_W);   // [2][N]
+  for (int i = tid; i < N; i += MHE_T) { anz[i] = d.A[i]; anz[N + i] = (nzP && nzP[i] == 0) ? 1.0 : 0.0; }
+  __syncthreads();
   const double LOG1 = dlog(1.0);
   const bool normal = d.likelihood == BNMF_NORMAL;
   const int ngrp = (G + CPW - 1) / CPW;                       // sets of CPW columns
   for (int gq = blockIdx.x * (MHE_T / 64) + wave; gq < ngrp; gq += gridDim.x * (MHE_T / 64)) {
+    MHSTAMP(S0);
     const int g = gq * CPW + grp;
     const bool live = g < G;                                  // a row beyond G works on column G - 1 and writes nothing
     const int gc = live ? g : G - 1;
@@ -545,25 +551,37 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol16(Dev d, uint32_t t, const in
         const int kk = j + GW * r;
         if (kk < K) {
           double c = 0.0;
-          for (int q = 0; q < N; ++q) c = c + (d.P[kk + (size_t)K * q] * d.A[q]) * ec[q];
+          for (int q = 0; q < N; ++q) c = c + (d.P[kk + (size_t)K * q] * anz[q]) * ec[q];
           mh[r] = c;
           if (MHSTEP) l0[MHSTEP ? r : 0] = mh_log_clamped(c);
         }
       }
+      double pnx[MHE16_RPL];                                  // the lane's rows of the NEXT factor's column of P: loaded a step ahead
+#pragma unroll
+      for (int r = 0; r < MHE16_RPL; ++r) { const int kk = j + GW * r; pnx[r] = kk < K ? d.P[kk] : 0.0; }
+      MHSTAMP(S1);
+#ifdef ZSPROF
+      if (blockIdx.x == 0 && tid == 0) { g_drprof[8 * (2048 + 128)] += mhsS1 - mhsS0; g_drprof[8 * (2048 + 128) + 7] += 1ull; }
+#endif
       for (int n = 0; n < N; ++n) {
+        MHSTAMP(E0);
         const int e = n + N * gc;
-        const double a_n = d.A[n];
+        const double a_n = anz[n];
+        double pn[MHE16_RPL];
+#pragma unroll
+        for (int r = 0; r < MHE16_RPL; ++r) pn[r] = pnx[r];
+        if (n + 1 < N) {
+          const double* Pq = d.P + (size_t)K * (n + 1);
+#pragma unroll
+          for (int r = 0; r < MHE16_RPL; ++r) { const int kk = j + GW * r; if (kk < K) pnx[r] = Pq[kk]; }
+        }
         if (a_n == 0.0) {                                                                  // sample_En :12
           const double x = prior_draw<1>(d, e, t);
           if (j == 0) { ec[n] = x; if (live) d.E[e] = x; }
           continue;
         }
-        const bool allzero = nzP[n] == 0;
+        const bool allzero = anz[N + n] != 0.0;
         const double eold = ec[n];
-        const double* Pn = d.P + (size_t)K * n;
-        double pn[MHE16_RPL];
-#pragma unroll
-        for (int r = 0; r < MHE16_RPL; ++r) { const int kk = j + GW * r; pn[r] = kk < K ? Pn[kk] : 0.0; }
         double s1 = 0.0, s2 = 0.0;
         if (!allzero) {
           double a1[NS] = {}, a2[NS] = {};
@@ -577,9 +595,15 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol16(Dev d, uint32_t t, const in
               a2[r % NS] = a2[r % NS] + (a_n * (pn[r] * pn[r])) * rV;
             }
           }
+          MHSTAMP(E1a);
           s1 = grp_bcast0<GW>(grp_tree<GW>(a1), lane); s2 = grp_bcast0<GW>(grp_tree<GW>(a2), lane);
+#ifdef ZSPROF
+          if (blockIdx.x == 0 && tid == 0) { g_drprof[8 * (2048 + 64 + n)] += mhsE1a - mhsE0; }
+#endif
         }
+        MHSTAMP(E2);
         const double pr = mh_prior_or_cond_pre<1>(d, e, t, allzero, s1, s2, pre_load(prq + PRE_W * n));
+        MHSTAMP(E3);
         bool take = true;
         if (MHSTEP) {
           double tA[NS] = {}, tB[NS] = {}, tC[NS] = {}, tD[NS] = {};
@@ -611,6 +635,10 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol16(Dev d, uint32_t t, const in
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+#ifdef ZSPROF
+        { MHSTAMP(E4);
+          if (blockIdx.x == 0 && tid == 0) { unsigned long long* o = &g_drprof[8 * (2048 + 64 + n)]; o[1] += mhsE2 - mhsE0; o[2] += mhsE3 - mhsE2; o[3] += mhsE4 - mhsE3; o[5] += mhsE4 - mhsE0; o[7] += 1ull; } }
+#endif
       }
     }
     // fresh Mhat of the (updated) column: residuals for sigmasq, then the metric terms (R/utils.R:412-471)
@@ -621,7 +649,7 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol16(Dev d, uint32_t t, const in
       cfresh[r] = 0.0;
       if (kk < K) {
         double c = 0.0;
-        for (int q = 0; q < N; ++q) c = c + (d.P[kk + (size_t)K * q] * d.A[q]) * ec[q];
+        for (int q = 0; q < N; ++q) c = c + (d.P[kk + (size_t)K * q] * anz[q]) * ec[q];
         cfresh[r] = c;
       }
     }

@@ -459,6 +459,31 @@ def test_mh_chain_bitexact(prior, G, gw, monkeypatch):
     assert (acc >= 0).all() and (acc <= 1).all() and acc.mean() > 0.5
 
 
+def test_mh_chain_with_sixty_factors_bitexact():
+    """N = 60: the E-side kernel's LDS (N x 9 doubles per column, 16 columns per workgroup, + A and the zero-column flags) is above
+    64 KiB and needs the attribute set at bnmf_create; the chain stays bit-exact, with excluded factors in the sweep."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    M, _, _ = synth_counts(48, 90, 4, 20250224)
+    N = 60
+    A = np.ones(N); A[[3, 17, 59]] = 0.0
+    o = O.Oracle(M, N, prior="truncnormal", MH=True, seed=5, nthreads=8)
+    e = Engine(M, N, prior="truncnormal", MH=True, seed=5)
+    for x in (o, e):
+        apply_hyperprior_params(x, "truncnormal", M, N)
+        x.set("A", A.reshape(1, N))
+    r0, r1 = o.init(), e.init()
+    assert np.array_equal(r0[:9].view(np.uint64), r1[:9].view(np.uint64))
+    for conv in (False, True):
+        mo, me = o.run(4, converged=conv), e.run(4, converged=conv)
+        for nm in ["P", "E", "E_acceptance_rate"]:
+            a, b = o.get(nm), e.get(nm)
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), f"{nm}: {np.sum(a != b)} of {a.size} differ (converged={conv})"
+        assert np.array_equal(mo.view(np.uint64), me.view(np.uint64))
+    e.close()
+
+
 def test_mh_learned_rank_bitexact():
     """The reference's default model: Poisson-TruncNormal + MH with SBFI rank learning."""
     import oracle as O

@@ -27,3 +27,10 @@ names = ["cells + trees", "barrier 1", "segment sums + draw (lane 0)", "barrier 
 print(f"k_mh_prow row 0, converged={conv}: 10 ns ticks per factor step, mean over {n} iterations and the 20 factors")
 for i, nm in enumerate(names):
     print(f"  {nm:32s} {a[:, i].sum() / a[:, 7].sum() / 100.0:7.3f} us")
+b = np.array(list(out), dtype=np.float64).reshape(W, 8)[2048 + 64:2048 + 64 + 20]
+su = np.array(list(out), dtype=np.float64).reshape(W, 8)[2048 + 128]
+if b[:, 7].sum() > 0:
+    print(f"k_mh_ecol16 workgroup 0, wave 0 (4 columns), converged={conv}: per factor step")
+    for i, nm in ((0, "prefetch + cells (before the trees)"), (1, "cells + trees"), (2, "draw"), (3, "MH step + update + fence"), (5, "whole step")):
+        print(f"  {nm:36s} {b[:, i].sum() / b[:, 7].sum() / 100.0:7.3f} us")
+    print(f"  {'set-up before the first step':36s} {su[0] / max(su[7], 1) / 100.0:7.3f} us")
