@@ -1094,13 +1094,7 @@ static void launch_side_main(bnmf_handle* h, uint32_t t, Timer& tm) {
   h->flags_valid = false;
   h->side_valid = true;
   h->side_main = true;
-  // k_reduce of the PREVIOUS iteration stays on the side stream, behind everything issued on the main stream so far
-  if (h->red_pending) {
-    hipEventRecord(h->ev_draw, h->stream);
-    hipStreamWaitEvent(h->side, h->ev_draw, 0);
-    issue_reduce(h, h->red_t, h->red_row, tm);
-    h->red_pending = false;
-  }
+  // (k_reduce of the PREVIOUS iteration: inside this iteration's k_mh_tail, see launch_mh_metrics)
 }
 // The same work in three launches, for the Gibbs sweep.  The P-side hyper sweep depends on P_{t-1} only and has
 // the longest per-lane latency (rejection sampling of Alpha): it starts right behind k_pdraw on its own stream.
@@ -1464,8 +1458,17 @@ static int launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells, bool with_r
   RecArgs ra{};
   if (with_record) { if (int rc = record_args(h, t, ra)) return rc; }
   const int nrec = (ra.n > 0 || ra.Rdst) ? 256 : 0;
-  hipLaunchKernelGGL(k_mh_tail, dim3(2 * N + h->nblkE + nrec), dim3(ES_T), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_P].d, accPn_slot(h, t),
-                     (const double*)h->arr[BNMF_ACC_E].d, accEp_slot(h, t), h->dNzE, h->dNzE + N, h->nblkE, ra);
+  // the canonical reductions of the iteration BEFORE ride in this launch when the hyper sweep runs on the main stream (launch_side_main):
+  // as a kernel of their own on the side stream nothing ordered the writers of their slot, three iterations on, behind them
+  RedSlots rs{};
+  if (h->red_pending && h->mh_side_main) {
+    Dev dr = h->dev;
+    set_slot(h, dr, h->red_t);
+    rs = RedSlots{dr.colsse, dr.colll, dr.colkl, dr.lpE_part, dr.lpPn, accPn_slot(h, h->red_t), accEp_slot(h, h->red_t), h->red_row, 1};
+    h->red_pending = false;
+  }
+  hipLaunchKernelGGL(k_mh_tail, dim3(2 * N + h->nblkE + nrec + (rs.on ? (h->cfg.MH ? 5 : 4) : 0)), dim3(ES_T), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_P].d, accPn_slot(h, t),
+                     (const double*)h->arr[BNMF_ACC_E].d, accEp_slot(h, t), h->dNzE, h->dNzE + N, h->nblkE, ra, nrec, rs);
   h->mh_prep_valid = true;
   return 0;
 }

@@ -740,27 +740,31 @@ __global__ __launch_bounds__(ZT) void k_zalloc(Dev d, uint32_t t, ZGeom zg, int 
 // ---- k_reduce: canonical (W = 1024) reductions of one iteration's partial sums ----
 // blocks 0..3 reduce colsse, colll, colkl, lpE_part; block 0 also folds the per-factor log-prior of
 // P and sum(A).  Raw values go to raw[row][8]; k_compose turns them into metrics rows once per run.
-__global__ __launch_bounds__(RT) void k_reduce(Dev d, int row, int nblkE, const double* accPn, const double* accE_part) {
-  __shared__ double buf[RT];
-  const int tid = threadIdx.x, j = blockIdx.x;
-  const double* src = j == 0 ? d.colsse : j == 1 ? d.colll : j == 2 ? d.colkl : j == 3 ? d.lpE_part : accE_part;
+// (the partial sums of ONE iteration: the slot pointers of that iteration — k_mh_tail of the iteration after it runs this body too)
+struct RedSlots { const double *colsse, *colll, *colkl, *lpE_part, *lpPn, *accPn, *accE_part; int row, on; };
+BNMF_DEV void reduce_body(const Dev& d, const RedSlots& rs, int nblkE, int j, double* buf, int tid) {
+  const double* src = j == 0 ? rs.colsse : j == 1 ? rs.colll : j == 2 ? rs.colkl : j == 3 ? rs.lpE_part : rs.accE_part;
   const long len = j < 3 ? d.G : nblkE;
   const double r = canon1024_by256(src, len, 1, buf, tid);
   if (tid == 0) {
-    double* o = d.raw + (size_t)row * 8;
+    double* o = d.raw + (size_t)rs.row * 8;
     o[j < 4 ? j : 6] = r;
     if (j == 0) {
       double lpP = 0.0;
-      for (int n = 0; n < d.N; ++n) lpP = lpP + d.lpPn[n];
+      for (int n = 0; n < d.N; ++n) lpP = lpP + rs.lpPn[n];
       o[4] = lpP;
       if (!d.learning_rank) {             // with rank learning A changes on the main stream: k_sumA writes these
         double sumA = 0.0;
         for (int n = 0; n < d.N; ++n) sumA = sumA + d.A[n];
         o[5] = sumA;
-        if (accPn) { double sp = 0.0; for (int n = 0; n < d.N; ++n) if (d.A[n] == 1.0) sp = sp + accPn[n]; o[7] = sp; }
+        if (rs.accPn) { double sp = 0.0; for (int n = 0; n < d.N; ++n) if (d.A[n] == 1.0) sp = sp + rs.accPn[n]; o[7] = sp; }
       }
     }
   }
+}
+__global__ __launch_bounds__(RT) void k_reduce(Dev d, int row, int nblkE, const double* accPn, const double* accE_part) {
+  __shared__ double buf[RT];
+  reduce_body(d, RedSlots{d.colsse, d.colll, d.colkl, d.lpE_part, d.lpPn, accPn, accE_part, row, 1}, nblkE, blockIdx.x, buf, threadIdx.x);
 }
 // sum(A) (and the A-masked acceptance sum) of the iteration, on the main stream right after the rank update
 __global__ void k_sumA(Dev d, int row, const double* accPn, RecDst rec) {

@@ -718,10 +718,15 @@ __global__ __launch_bounds__(ES_T) void k_lp_e(Dev d, uint32_t t, const double* 
 //   blocks [N + nblkE, 2N + nblkE): for the NEXT iteration's P sweep: Et = transpose of E, nzE[n] = number of non-zero
 //                                   entries of row n of E (k_mh_nz), and nzP[n] = 0 (k_mh_prow accumulates it)
 //   blocks [2N + nblkE, ...)      : record_sample of the iteration (k_record's copy into the rings), when ra.n > 0
-__global__ __launch_bounds__(ES_T) void k_mh_tail(Dev d, uint32_t t, const double* accP, double* accPn, const double* accE, double* accE_part, int* nzE, int* nzP, int nblkE, RecArgs ra) {
+//   the last blocks (rs.on)       : k_reduce's work for the iteration BEFORE (its partial sums lie in another slot): on a side stream it
+//                                   was ordered behind its inputs only, and nothing kept the kernels of three iterations on — which write
+//                                   its slot again — behind it once the hyper sweep had moved to the main stream (round 4)
+__global__ __launch_bounds__(ES_T) void k_mh_tail(Dev d, uint32_t t, const double* accP, double* accPn, const double* accE, double* accE_part, int* nzE, int* nzP, int nblkE, RecArgs ra,
+                                                   int nrec, RedSlots rs) {
   __shared__ double buf[ES_T];
   __shared__ int cnt;
   const int tid = threadIdx.x, blk = blockIdx.x;
+  if (blk >= 2 * d.N + nblkE + nrec) { reduce_body(d, rs, nblkE, blk - (2 * d.N + nblkE + nrec), buf, tid); return; }
   if (blk < d.N) {
     if (tid >= 64) return;
     const int n = blk;
@@ -745,7 +750,7 @@ __global__ __launch_bounds__(ES_T) void k_mh_tail(Dev d, uint32_t t, const doubl
       if (tid == 0) accE_part[be] = r2;
     }
   } else if (blk >= 2 * d.N + nblkE) {
-    const size_t rt = (size_t)(blk - 2 * d.N - nblkE) * ES_T + tid, nth = (size_t)(gridDim.x - 2 * d.N - nblkE) * ES_T;
+    const size_t rt = (size_t)(blk - 2 * d.N - nblkE) * ES_T + tid, nth = (size_t)nrec * ES_T;
     for (int j = 0; j < ra.n; ++j)
       for (size_t i = rt; i < ra.len[j]; i += nth) ra.dst[j][i] = ra.src[j][i];
     if (rt == 0 && ra.Rdst) *ra.Rdst = (double)*ra.R;
