@@ -440,3 +440,16 @@ def test_four_different_chains_at_once_match_their_solo_runs():
         assert np.array_equal(e.get("P").view(np.uint64), alone[i][1].view(np.uint64)), i
         assert np.array_equal(e.get("E").view(np.uint64), alone[i][2].view(np.uint64)), i
         e.close()
+
+
+def test_six_chains_at_once_ten_times_over():
+    """tools/concurrent_check.py: six chains of six sweep types (MH before and after convergence and the Normal likelihood among them) from six host
+    threads on one device, ten times with fresh handles: every run the bits of the chain alone, metric rows included.  (Round 4: with the MH /
+    Normal hyper sweep on the main stream the reduce of the iteration before had lost its ordering against the next writers of its slot; this
+    loop showed it in three of four repetitions.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "concurrent_check.py"), "10"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
