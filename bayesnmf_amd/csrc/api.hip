@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1693,11 +1694,19 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
 // Two handles that learn the rank must not run on one device at the same time: each persistent rank sweep sizes its grid
 // as if it owned the device (one workgroup per CU, every workgroup waits for all others), and two half-resident grids
 // would wait for each other until their bounded spins give up.  Their calls take turns (a call is at most one block of
-// iterations between MAP checks).
-static std::mutex g_rank_turn[64];
+// iterations between MAP checks).  Nor may a rank-learning call run beside ANY other chain's call on the device (round 4, found
+// by tools/concurrent_check.py with full-size chains): a workgroup that waits inside a kernel for its chain's side streams (the
+// allocation kernel's gate, the draw kernels' polls) holds a CU the rank sweep's grid needs, while the rank sweep's resident
+// workgroups hold the registers the side-stream kernel needs — a cycle only the time-outs broke.  Rank-learning calls take the
+// device's lock exclusively, all other calls shared.
+static std::shared_mutex g_rank_turn[64];
 static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, Timer& tm) {
-  std::unique_lock<std::mutex> turn;
-  if (h && h->cfg.learning_rank && h->device >= 0 && h->device < 64) turn = std::unique_lock<std::mutex>(g_rank_turn[h->device]);
+  std::unique_lock<std::shared_mutex> turn;
+  std::shared_lock<std::shared_mutex> beside;
+  if (h && h->device >= 0 && h->device < 64) {
+    if (h->cfg.learning_rank) turn = std::unique_lock<std::shared_mutex>(g_rank_turn[h->device]);
+    else beside = std::shared_lock<std::shared_mutex>(g_rank_turn[h->device]);
+  }
   if (!h) return fail(BNMF_EINVAL, "bnmf_run: null handle");
   if (!h->inited) return fail(BNMF_ESTATE, "bnmf_run: call bnmf_init first");
   if (h->poisoned) return fail(BNMF_ESTATE, "bnmf_run: an earlier call timed out inside a kernel; the handle's state is invalid, destroy it");

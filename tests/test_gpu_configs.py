@@ -453,3 +453,16 @@ def test_six_chains_at_once_ten_times_over():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "concurrent_check.py"), "10"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_six_full_size_chains_at_once():
+    """The same with full-size chains (CONC_BIG=1: two gated fixed-rank chains at G = 10,000, config 3 twice, config 4 — whose persistent
+    rank sweep wants every CU —, N = 100): before rank-learning calls took the device's lock exclusively, a gate-waiting allocation workgroup,
+    the rank sweep's resident workgroups and the side-stream kernel between them waited for each other until a time-out poisoned a handle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "concurrent_check.py"), "3"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, CONC_BIG="1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -1,6 +1,7 @@
 """Several chains on ONE GPU at the same time (one host thread each) must give the same bits as each chain alone.
 usage: python tools/concurrent_check.py [repetitions of the concurrent part, default 1] — every repetition creates its handles anew (six
-chains: gated fixed rank, rank learning, MH after and before convergence, exponential prior with K > 128, Normal likelihood)."""
+chains: gated fixed rank, rank learning, MH after and before convergence, exponential prior with K > 128, Normal likelihood; CONC_BIG=1: six
+full-size chains — two gated fixed-rank ones, config 3 twice, config 4, N = 100)."""
 import os, sys, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -15,6 +16,13 @@ cases = [dict(K=96, G=3000, N=20, kw=dict(prior="gamma"), window=50, conv=True),
          dict(K=200, G=700, N=30, kw=dict(prior="exponential"), window=10, conv=True),
          dict(K=96, G=1500, N=5, kw=dict(prior="truncnormal", MH=True), window=0, conv=False),
          dict(K=60, G=800, N=4, kw=dict(prior="truncnormal", likelihood="normal"), window=5, conv=False)]
+if os.environ.get("CONC_BIG"):                             # full-size chains: two gated fixed-rank chains, config 3, config 4, N = 100
+    cases = [dict(K=96, G=10000, N=20, kw=dict(prior="gamma"), window=50, conv=True),
+             dict(K=96, G=10000, N=20, kw=dict(prior="exponential"), window=0, conv=True),
+             dict(K=96, G=5000, N=20, kw=dict(prior="truncnormal", MH=True), window=20, conv=True),
+             dict(K=96, G=10000, N=50, kw=dict(prior="gamma", learning_rank=True, temperature=np.ones(400)), window=0, conv=True),
+             dict(K=96, G=5000, N=20, kw=dict(prior="truncnormal", MH=True), window=0, conv=False),
+             dict(K=256, G=4000, N=100, kw=dict(prior="gamma"), window=0, conv=True)]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 def make(c, cid):
     M, _, _ = synth_counts(c["K"], c["G"], 4, 77 + cid)
