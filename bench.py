@@ -11,7 +11,7 @@ in HBM.  One independent chain per GPU (chain_id = rank); no data-path collectiv
 the chains' final metrics rows.  Rank 0 prints ONE JSON line.
 
 `--gpus N` without WORLD_SIZE in the environment starts the N ranks itself (fresh child processes,
-before anything here touches the GPU).  The timed region is repeated `--reps` times (default 5), each
+before anything here touches the GPU).  The timed region is repeated `--reps` times (default 9), each
 repetition timing EXACTLY `--steps` iterations between barriers; `value` is the median repetition
 (SURVEY.md 8d protocol) and every repetition is listed under `rep_values`.
 """
@@ -260,7 +260,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step region; value = median")
+    ap.add_argument("--reps", type=int, default=9, help="repetitions of the timed K-step region; value = median")
     ap.add_argument("--window", type=int, default=MAP_OVER, help="record_sample ring depth (MAP_over); 0 = recording off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the timings of BASELINE configs 2-5")
@@ -323,11 +323,14 @@ def main():
 
     chain.run(args.warmup, metrics=False)
     n_prof = min(200, max(20, args.steps // 10))
-    n_refill = max(args.warmup, 200)
+    n_refill = max(args.warmup, 1500)   # (0.14 s at the metric configuration: the device clocks have settled by the first timed repetition)
     # roofline of the dominant kernel (k_zalloc): HIP events on the chain's own stream, one kernel at a time.
     # Done before the timed region (it advances the chain like any other iterations and keeps the clocks up).
     prof, roof = roofline_of(chain, K_, args.G, N_, args.save_z, total_counts, n_prof, device=local_rank)
     chain.run(n_refill, metrics=False)  # refill the stream pipeline after the serialised profile pass; keeps the clocks up
+    n_shape = 2                         # ... and two untimed repetitions of exactly the timed shape (on some boxes the first calls after the
+    for _ in range(n_shape):            # profile pass run 3 % slower than the ones behind them)
+        chain.run(args.steps, metrics=True)
 
     rep_dt = []
     met = None
@@ -363,8 +366,8 @@ def main():
             "unit": "Gibbs iterations/s (aggregate over chains)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             # what ran before the first timed repetition: --warmup iterations, the serialised per-kernel profile pass the roofline
-            # comes from, and a refill of the stream pipeline
-            "warmup_effective": args.warmup + n_prof + n_refill,
+            # comes from, a refill of the stream pipeline, and two untimed repetitions of the timed shape
+            "warmup_effective": args.warmup + n_prof + n_refill + n_shape * args.steps,
             "rng": "philox4x32-7 (count-allocation words, variable Z) / philox4x32-10 (every other stream)",
             "ms_per_step": 1e3 * tmed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
