@@ -95,7 +95,7 @@ def roofline_of(chain, K, G, N, save_Z, total_counts, n_iter, kernel=None, devic
     philox_peak, copy_gbs = ceilings(device)
     draws = total_counts / (z_ms * 1e-3) if z_ms > 0 else 0.0
     if kernel is None:
-        kernel = "k_zalloc_sort with save_Z (+ the zero fill of Z in front of it)" if save_Z else "k_zalloc_sort"
+        kernel = "k_zalloc_sort with save_Z (item records) + k_zexpand (records -> Z)" if save_Z else "k_zalloc_sort"
     traffic, traffic_src = pmc_traffic(save_Z)
     try:
         import torch
@@ -117,7 +117,7 @@ def roofline_of(chain, K, G, N, save_Z, total_counts, n_iter, kernel=None, devic
                           "note": "peak = Philox4x32-7 (the generator of the count-allocation words) alone at 8 waves/SIMD, measured on this box (bnmf_ubench); the kernel also "
                                   "searches 19 thresholds and updates two tables per word"},
                   "note": "stats mode moves 6.3 MB per 40 M categorical draws: the kernel is VALU/Philox-bound, not HBM-bound (DESIGN.md 5)"
-                          if not save_Z else "full mode: Z (K x N x G int32) written every iteration: a coalesced zero fill, then the non-zero entries from the lanes that hold them"}
+                          if not save_Z else "full mode: Z (K x N x G int32) written every iteration: k_zalloc_sort leaves one packed record per item, k_zexpand turns the records of a column slab into Z with 16-byte stores (both in avg_launch_ms)"}
 
 
 def make_chain(M, N, seed, chain_id, device, save_Z=False, window=MAP_OVER, prior="gamma", **kw):
