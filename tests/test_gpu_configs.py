@@ -466,3 +466,14 @@ def test_six_full_size_chains_at_once():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "concurrent_check.py"), "3"], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, CONC_BIG="1"))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_chains_mixing_every_entry_point_at_once():
+    """tools/api_mix_check.py: five chains from five host threads on one device, each mixing bnmf_map (with bounds), bnmf_window, bnmf_get_array,
+    a bnmf_set_array of P mid-chain and bnmf_assign into its run blocks: the bits of the same call sequence made alone, five times over."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "api_mix_check.py"), "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
