@@ -54,6 +54,7 @@ struct bnmf_handle {
   double* dScal = nullptr;              // [BNMF_ID_MAX] broadcast scalars of bnmf_set_array (hyper-prior values given as one number)
   unsigned* dDrawOwn = nullptr; unsigned draw_seq = 0;   // k_draw: owner word per column of P, launch sequence number (kernels.h)
   int dbg_draw_no_p = 0;               // BNMF_DEBUG_DRAW_NO_P (tests): the P workgroups of k_draw leave without claiming their columns
+  int dbg_allside_delay_us = 0;        // BNMF_DEBUG_ALLSIDE_DELAY_US (tests): a delay kernel in front of EVERY kernel launched on the two side streams
   int dbg_side_delay_us = 0;           // BNMF_DEBUG_SIDE_DELAY_US (tests): a delay kernel in front of the P-side hyper sweep of launch_side_merged
   int gate_f0 = 1;                     // flag the gate waits for beside [3]: [1] E-side sweep (k_side), [9] P-side sweep on its own stream (merged draw path)
   uint32_t z_gate_next = 0;            // != 0: the allocation kernel being launched waits at its end for the hyper sweep of this iteration
@@ -591,6 +592,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   if (const char* e = getenv("BNMF_GATE")) h->gate_forced = atoi(e) != 0 ? 1 : 0;   // diagnostics / tests
   if (const char* e = getenv("BNMF_MHSIDE")) h->mh_side_main = atoi(e) != 0;
   if (const char* e = getenv("BNMF_DEBUG_DRAW_NO_P")) h->dbg_draw_no_p = atoi(e) != 0 ? 1 : 0;   // tests only
+  if (const char* e = getenv("BNMF_DEBUG_ALLSIDE_DELAY_US")) h->dbg_allside_delay_us = std::max(0, std::min(20000, atoi(e)));   // tests only
   if (const char* e = getenv("BNMF_DEBUG_SIDE_DELAY_US")) h->dbg_side_delay_us = std::max(0, std::min(20000, atoi(e)));   // tests only
   {
     // A lane that polls inside a main-stream kernel for a side-stream kernel deadlocks (until its bound) when dispatches cannot
@@ -1040,8 +1042,14 @@ static void launch_edraw(bnmf_handle* h, uint32_t t, int from_prior, bool rec) {
 }
 // k_side for iteration t (reads P_{t-1}, E_{t-1}): issued on the side stream right after the draws
 // of iteration t-1, so that it overlaps k_zalloc of iteration t-1
+// tests (BNMF_DEBUG_ALLSIDE_DELAY_US): hold a side stream back in front of its next kernel — whatever then reads too early or writes too early shows
+// as a bit that differs from the oracle's
+static void dbg_delay(bnmf_handle* h, hipStream_t st) {
+  if (h->dbg_allside_delay_us && st != h->stream) hipLaunchKernelGGL(k_debug_delay, dim3(1), dim3(64), 0, st, h->dbg_allside_delay_us);
+}
 static void issue_reduce(bnmf_handle* h, uint32_t t, int row, Timer& tm, hipStream_t st = nullptr) {
   if (!st) st = h->side;
+  dbg_delay(h, st);
   Dev dr = h->dev;
   set_slot(h, dr, t);
   tm.begin(KN_REDUCE, st);
@@ -1069,6 +1077,7 @@ static void launch_side(bnmf_handle* h, uint32_t t, Timer& tm, bool publish = fa
   hipStreamWaitEvent(h->side, h->ev_draw, 0);
   tm.begin(KN_SIDE, h->side);
   // publish (MH / Normal sweeps): the last workgroup raises flag [1] = t, which the next P-row kernel polls (no barrier packet)
+  dbg_delay(h, h->side);
   hipLaunchKernelGGL(k_side, dim3(h->cfg.N + nbP + nbE), dim3(RT), 0, h->side, h->dev, t, nbP, 0, rec_at(h, t, fused_rec(h)),
                      publish ? SideDone{h->dFlags, h->dFlags + 1, (unsigned)(h->cfg.N + nbP + nbE), t} : SideDone{});
   h->flags_valid = publish;
@@ -1112,6 +1121,7 @@ static void launch_side_P(bnmf_handle* h, uint32_t t, hipEvent_t after = nullptr
   // k_lpp below rewrites lpPn slot (t-1) % 3, last read by k_reduce of iteration t-4 (side stream): order behind it
   if (h->red_issued && !h->red_on_side2) hipStreamWaitEvent(h->side2, h->ev_red, 0);
   // ... and the log-prior of the P just drawn (k_lpp's work, iteration t-1) in the same launch
+  dbg_delay(h, h->side2);
   hipLaunchKernelGGL(k_side_lp, dim3(nbP + h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, h->cfg.N, rec_at(h, t, fused_rec(h)), SideDone{},
                      SideExtra{nbP, h->cfg.N, 0, t - 1, nullptr, 0});
 }
@@ -1122,6 +1132,7 @@ static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm, bool e_done = f
   // Esum closes the side2 work the next k_pdraw needs (the P part ran before it on the same stream): it publishes flag [3]
   // ... and, in the same launch, the log-prior of the E just drawn (k_lpe's work; iteration t-1, whose slot pointers h->dev
   // still holds): off the critical path
+  dbg_delay(h, h->side2);
   hipLaunchKernelGGL(k_side_lp, dim3(h->cfg.N + h->nblkE), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)(h->cfg.N + h->nblkE), t},
                      SideExtra{h->cfg.N, 0, h->nblkE, t - 1, lpe_src(h, t - 1), 1});
   // k_reduce of the PREVIOUS iteration here, behind the kernels that produce its inputs on this stream (k_lpp, k_lpe) and
@@ -1130,6 +1141,7 @@ static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm, bool e_done = f
   if (h->red_pending) { issue_reduce(h, h->red_t, h->red_row, tm, h->side2); h->red_pending = false; }
   if (!e_done) {
     hipStreamWaitEvent(h->side, h->ev_draw, 0);
+    dbg_delay(h, h->side);
     hipLaunchKernelGGL(k_side, dim3(nbE), dim3(RT), 0, h->side, h->dev, t, nbP, h->cfg.N + nbP, rec_at(h, t, fused_rec(h)), SideDone{h->dFlags, h->dFlags + 1, (unsigned)nbE, t});
   }
   h->flags_valid = true;
@@ -1146,9 +1158,11 @@ static void launch_side_merged(bnmf_handle* h, uint32_t t, Timer& tm) {
   const int nbP = (int)(((size_t)h->cfg.K * N + RT - 1) / RT);
   hipStreamWaitEvent(h->side, h->ev_draw, 0);
   if (h->dbg_side_delay_us) hipLaunchKernelGGL(k_debug_delay, dim3(1), dim3(64), 0, h->side, h->dbg_side_delay_us);   // tests: a late P-side sweep
+  dbg_delay(h, h->side);
   hipLaunchKernelGGL(k_side, dim3(nbP), dim3(RT), 0, h->side, h->dev, t, nbP, N, rec_at(h, t, fused_rec(h)), SideDone{h->dFlags + 8, h->dFlags + 9, (unsigned)nbP, t});
   hipStreamWaitEvent(h->side2, h->ev_draw, 0);
   if (h->red_issued && !h->red_on_side2) hipStreamWaitEvent(h->side2, h->ev_red, 0);   // lpPn slot reuse, see launch_side_P
+  dbg_delay(h, h->side2);
   hipLaunchKernelGGL(k_side_lp, dim3(2 * N + h->nblkE), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)(2 * N + h->nblkE), t},
                      SideExtra{N, N, h->nblkE, t - 1, lpe_src(h, t - 1), 1});
   if (h->red_pending) { issue_reduce(h, h->red_t, h->red_row, tm, h->side2); h->red_pending = false; }
@@ -1166,8 +1180,10 @@ static void launch_side_early(bnmf_handle* h, uint32_t t) {
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
   const int nbE = (int)(((size_t)h->cfg.N * h->cfg.G + RT - 1) / RT);
   hipStreamWaitEvent(h->side2, h->ev_draw, 0);
+  dbg_delay(h, h->side2);
   hipLaunchKernelGGL(k_side, dim3(nbP), dim3(RT), 0, h->side2, h->dev, t, nbP, h->cfg.N, rec_at(h, t, fused_rec(h)), SideDone{});
   hipStreamWaitEvent(h->side, h->ev_draw, 0);
+  dbg_delay(h, h->side);
   hipLaunchKernelGGL(k_side, dim3(nbE), dim3(RT), 0, h->side, h->dev, t, nbP, h->cfg.N + nbP, rec_at(h, t, fused_rec(h)), SideDone{h->dFlags, h->dFlags + 1, (unsigned)nbE, t});
   h->flags_valid = true;
 }
@@ -1175,10 +1191,13 @@ static void launch_side_late(bnmf_handle* h, uint32_t t, Timer& tm) {
   hipStreamWaitEvent(h->side2, h->ev_rank, 0);
   // k_lpp rewrites lpPn slot (t-1) % 3, last read by k_reduce of iteration t-4 (side stream): order behind it
   if (h->red_issued) hipStreamWaitEvent(h->side2, h->ev_red, 0);
+  dbg_delay(h, h->side2);
   hipLaunchKernelGGL(k_lpp, dim3(h->cfg.N), dim3(64), 0, h->side2, h->dev, t - 1);   // log-prior of the P just drawn
+  dbg_delay(h, h->side2);
   hipLaunchKernelGGL(k_lpe, dim3(h->nblkE), dim3(ES_T), 0, h->side2, h->dev, t - 1, lpe_src(h, t - 1)); // ... and of the E just drawn
   // Esum last: its flag [3] releases the next iteration's draws, which overwrite the P and E the two kernels above read
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
+  dbg_delay(h, h->side2);
   hipLaunchKernelGGL(k_side, dim3(h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)h->cfg.N, t});
   hipEventRecord(h->ev_sideP, h->side2);
   hipStreamWaitEvent(h->side, h->ev_sideP, 0);

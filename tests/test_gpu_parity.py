@@ -904,3 +904,31 @@ def test_sorted_schedule_kernel_save_Z_matches_register_kernel(K, G, N, monkeypa
     Z = e1.get("Z")
     assert (Z.sum(1) == M).all() and (Z.sum(0) == e1.get("ZsumK")).all() and (Z.sum(2) == e1.get("ZsumG")).all()
     e0.close(); e1.close()
+
+
+@pytest.mark.parametrize("case", ["merged", "two_kernel", "rank", "mh", "normal"])
+def test_every_side_stream_kernel_held_back(case, monkeypatch):
+    """BNMF_DEBUG_ALLSIDE_DELAY_US: a 400 us delay kernel in front of EVERY kernel on the two side streams (hyper sweeps, Esum, log-priors,
+    reductions) — several iterations' worth at these sizes.  Whatever is ordered by timing instead of by a flag, an event or stream order then
+    reads too early or overwrites too early, and a bit differs from the oracle's (the reduce of the MH / Normal sweeps, round 4, was such a case)."""
+    monkeypatch.setenv("BNMF_DEBUG_ALLSIDE_DELAY_US", "400")
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    K, G, N, prior, kw = {"merged": (96, 2700, 20, "gamma", {}), "two_kernel": (96, 300, 8, "exponential", {}),
+                          "rank": (96, 500, 8, "gamma", dict(learning_rank=True, temperature=np.linspace(0.3, 1, 30))),
+                          "mh": (96, 700, 6, "truncnormal", dict(MH=True)), "normal": (60, 400, 4, "truncnormal", dict(likelihood="normal"))}[case]
+    M, _, _ = synth_counts(K, G, 4, 991)
+    o = O.Oracle(M, N, prior=prior, seed=6, nthreads=8, **kw)
+    e = Engine(M, N, prior=prior, seed=6, window=6, **kw)
+    for x in (o, e):
+        apply_hyperprior_params(x, prior, M, N)
+    r0, r1 = o.init(), e.init()
+    assert np.array_equal(r0[:9].view(np.uint64), r1[:9].view(np.uint64))
+    for conv in ((False, True) if case == "mh" else (False,)):
+        for block in (7, 6):                                # two calls: the hand-over between bnmf_run calls as well
+            mo, me = o.run(block, converged=conv), e.run(block, converged=conv)
+            assert np.array_equal(np.nan_to_num(mo[:, :9]).view(np.uint64), np.nan_to_num(me[:, :9]).view(np.uint64)), (case, conv, block)
+            for nm in ("P", "E"):
+                assert np.array_equal(o.get(nm).view(np.uint64), e.get(nm).view(np.uint64)), (case, nm, conv)
+    e.close()
