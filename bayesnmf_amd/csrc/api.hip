@@ -54,6 +54,7 @@ struct bnmf_handle {
   double* dScal = nullptr;              // [BNMF_ID_MAX] broadcast scalars of bnmf_set_array (hyper-prior values given as one number)
   unsigned* dDrawOwn = nullptr; unsigned draw_seq = 0;   // k_draw: owner word per column of P, launch sequence number (kernels.h)
   int dbg_draw_no_p = 0;               // BNMF_DEBUG_DRAW_NO_P (tests): the P workgroups of k_draw leave without claiming their columns
+  int dbg_main_delay_us = 0;           // BNMF_DEBUG_MAIN_DELAY_US (tests): a delay kernel in front of the main stream's kernels of every sweep
   int dbg_allside_delay_us = 0;        // BNMF_DEBUG_ALLSIDE_DELAY_US (tests): a delay kernel in front of EVERY kernel launched on the two side streams
   int dbg_side_delay_us = 0;           // BNMF_DEBUG_SIDE_DELAY_US (tests): a delay kernel in front of the P-side hyper sweep of launch_side_merged
   int gate_f0 = 1;                     // flag the gate waits for beside [3]: [1] E-side sweep (k_side), [9] P-side sweep on its own stream (merged draw path)
@@ -592,6 +593,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   if (const char* e = getenv("BNMF_GATE")) h->gate_forced = atoi(e) != 0 ? 1 : 0;   // diagnostics / tests
   if (const char* e = getenv("BNMF_MHSIDE")) h->mh_side_main = atoi(e) != 0;
   if (const char* e = getenv("BNMF_DEBUG_DRAW_NO_P")) h->dbg_draw_no_p = atoi(e) != 0 ? 1 : 0;   // tests only
+  if (const char* e = getenv("BNMF_DEBUG_MAIN_DELAY_US")) h->dbg_main_delay_us = std::max(0, std::min(20000, atoi(e)));   // tests only
   if (const char* e = getenv("BNMF_DEBUG_ALLSIDE_DELAY_US")) h->dbg_allside_delay_us = std::max(0, std::min(20000, atoi(e)));   // tests only
   if (const char* e = getenv("BNMF_DEBUG_SIDE_DELAY_US")) h->dbg_side_delay_us = std::max(0, std::min(20000, atoi(e)));   // tests only
   {
@@ -1046,6 +1048,11 @@ static void launch_edraw(bnmf_handle* h, uint32_t t, int from_prior, bool rec) {
 // as a bit that differs from the oracle's
 static void dbg_delay(bnmf_handle* h, hipStream_t st) {
   if (h->dbg_allside_delay_us && st != h->stream) hipLaunchKernelGGL(k_debug_delay, dim3(1), dim3(64), 0, st, h->dbg_allside_delay_us);
+}
+// ... and the other way round (BNMF_DEBUG_MAIN_DELAY_US): the main stream held back, so that a side-stream kernel that runs on the main stream's
+// results without waiting for them reads the values of the iteration before
+static void dbg_delay_main(bnmf_handle* h) {
+  if (h->dbg_main_delay_us) hipLaunchKernelGGL(k_debug_delay, dim3(1), dim3(64), 0, h->stream, h->dbg_main_delay_us);
 }
 static void issue_reduce(bnmf_handle* h, uint32_t t, int row, Timer& tm, hipStream_t st = nullptr) {
   if (!st) st = h->side;
@@ -1502,7 +1509,9 @@ static int sweep_mh(bnmf_handle* h, int row, int converged, Timer& tm) {
   const bool on_main = h->side_main;                       // the hyper sweep of t ran on this stream (launch_side_main): nothing to wait for
   const bool poll = !on_main && h->flags_valid && !tm.on && !h->serial;
   if (!poll && !on_main) { refresh_side_events(h); hipStreamWaitEvent(h->stream, h->ev_side, 0); hipStreamWaitEvent(h->stream, h->ev_sideP, 0); }
+  dbg_delay_main(h);
   tm.begin(KN_MH, h->stream); launch_mh_PE(h, t, converged, poll); tm.end(KN_MH, h->stream);
+  dbg_delay_main(h);
   if (h->mh_side_main) launch_side_main(h, t + 1, tm); else launch_side(h, t + 1, tm, !tm.on);
   if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
   // record_sample rides in k_mh_tail: after sample_sigmasq, like record_sample (:279) after sample_params (:276)
@@ -1540,6 +1549,7 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   // packet on the main stream); after init / set_array / in profile mode a stream wait
   const bool poll = h->flags_valid && !tm.on && !h->serial;
   if (!poll) { refresh_side_events(h); hipStreamWaitEvent(h->stream, h->ev_side, 0); }
+  dbg_delay_main(h);
   if (tm.on) {                                             // profile mode: one kernel at a time
     tm.begin(KN_PDRAW, h->stream); launch_pdraw(h, t, 0, rec); tm.end(KN_PDRAW, h->stream);
     tm.begin(KN_EDRAW, h->stream); launch_edraw(h, t, 0, rec); tm.end(KN_EDRAW, h->stream);
@@ -1590,6 +1600,7 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   if (h->cfg.learning_rank && tm.on) { tm.begin(KN_RANK, h->stream); launch_rank(h, t, nullptr, row); tm.end(KN_RANK, h->stream); }
   const bool gate = gate_enabled(h) && !h->cfg.learning_rank && poll && h->z_reg && !h->z_tile;
   h->z_gate_next = gate ? t + 1 : 0u;
+  dbg_delay_main(h);
   tm.begin(KN_ZALLOC, h->stream); if (int rc = launch_zalloc(h, t)) return rc; tm.end(KN_ZALLOC, h->stream);
   h->z_gated_for = h->z_gate_next; h->z_gate_next = 0;
   record_Z(h, t);

@@ -906,12 +906,14 @@ def test_sorted_schedule_kernel_save_Z_matches_register_kernel(K, G, N, monkeypa
     e0.close(); e1.close()
 
 
+@pytest.mark.parametrize("which", ["BNMF_DEBUG_ALLSIDE_DELAY_US", "BNMF_DEBUG_MAIN_DELAY_US"])
 @pytest.mark.parametrize("case", ["merged", "two_kernel", "rank", "mh", "normal"])
-def test_every_side_stream_kernel_held_back(case, monkeypatch):
+def test_every_side_stream_kernel_held_back(case, which, monkeypatch):
     """BNMF_DEBUG_ALLSIDE_DELAY_US: a 400 us delay kernel in front of EVERY kernel on the two side streams (hyper sweeps, Esum, log-priors,
     reductions) — several iterations' worth at these sizes.  Whatever is ordered by timing instead of by a flag, an event or stream order then
-    reads too early or overwrites too early, and a bit differs from the oracle's (the reduce of the MH / Normal sweeps, round 4, was such a case)."""
-    monkeypatch.setenv("BNMF_DEBUG_ALLSIDE_DELAY_US", "400")
+    reads too early or overwrites too early, and a bit differs from the oracle's (the reduce of the MH / Normal sweeps, round 4, was such a case).
+    BNMF_DEBUG_MAIN_DELAY_US: the other way round — the main stream's kernels of every sweep held back, the side streams free to run ahead."""
+    monkeypatch.setenv(which, "400")
     import oracle as O
     from bayesnmf_amd import Engine
     from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
