@@ -48,6 +48,7 @@ struct bnmf_handle {
   hipEvent_t ev_draw = nullptr, ev_side = nullptr, ev_sideP = nullptr, ev_p = nullptr, ev_z = nullptr, ev_red = nullptr, ev_rank = nullptr;
   bool side_valid = false;             // k_side of iteration iter+1 has been issued
   bool side_main = false;              // ... on the main stream (MH / Normal sweeps: launch_side_main)
+  bool mh_side_tail = true;            // BNMF_MHSIDETAIL=0 (diagnostics): the main-stream hyper sweep as a launch of its own in front of k_mh_tail
   bool mh_side_main = true;            // BNMF_MHSIDE=0 (diagnostics / tests): the MH / Normal sweeps' hyper sweep on the side stream, as in round 3
   int gate_forced = -1;                // BNMF_GATE at bnmf_create: 0 / 1 forces the merged draw kernel off / on, else by size
   int draw_bw = 0;                     // lanes per workgroup of the merged draw kernel (chosen at the first launch)
@@ -592,6 +593,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   if (cfg->save_Z) HIPCHK(hipMalloc(&h->dZ, K * N * G * sizeof(int32_t)));
   if (const char* e = getenv("BNMF_GATE")) h->gate_forced = atoi(e) != 0 ? 1 : 0;   // diagnostics / tests
   if (const char* e = getenv("BNMF_MHSIDE")) h->mh_side_main = atoi(e) != 0;
+  if (const char* e = getenv("BNMF_MHSIDETAIL")) h->mh_side_tail = atoi(e) != 0;
   if (const char* e = getenv("BNMF_DEBUG_DRAW_NO_P")) h->dbg_draw_no_p = atoi(e) != 0 ? 1 : 0;   // tests only
   if (const char* e = getenv("BNMF_DEBUG_MAIN_DELAY_US")) h->dbg_main_delay_us = std::max(0, std::min(20000, atoi(e)));   // tests only
   if (const char* e = getenv("BNMF_DEBUG_ALLSIDE_DELAY_US")) h->dbg_allside_delay_us = std::max(0, std::min(20000, atoi(e)));   // tests only
@@ -1465,7 +1467,7 @@ static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged, bool poll = 
   } else
   hipLaunchKernelGGL(k_mh_ecol<false>, dim3(grid), dim3(MHE_T), h->mhe_lds, h->stream, h->dev, t, mhstep, (const int*)(h->dNzE + N), accE, 0);
 }
-static int launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells, bool with_record = false) {   // with_record: record_sample inside k_mh_tail
+static int launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells, bool with_record = false, bool with_side = false) {   // with_record: record_sample inside k_mh_tail; with_side: and the hyper sweep of t + 1
   const int draw_sig = h->cfg.likelihood == BNMF_NORMAL ? 1 : 0;
   if (draw_sig) cells = true;                 // sigmasq is drawn after R, A (R/sample_params.R:86-88) in the metrics pass
   const int N = h->cfg.N, G = h->cfg.G;
@@ -1494,8 +1496,14 @@ static int launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells, bool with_r
     rs = RedSlots{dr.colsse, dr.colll, dr.colkl, dr.lpE_part, dr.lpPn, accPn_slot(h, h->red_t), accEp_slot(h, h->red_t), h->red_row, 1};
     h->red_pending = false;
   }
-  hipLaunchKernelGGL(k_mh_tail, dim3(2 * N + h->nblkE + nrec + (rs.on ? (h->cfg.MH ? 5 : 4) : 0)), dim3(ES_T), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_P].d, accPn_slot(h, t),
-                     (const double*)h->arr[BNMF_ACC_E].d, accEp_slot(h, t), h->dNzE, h->dNzE + N, h->nblkE, ra, nrec, rs);
+  SideInTail sx{};
+  if (with_side) {                                           // launch_side_main's kernel as the first blocks of this one
+    const int nbP = (int)(((size_t)h->cfg.K * N + RT - 1) / RT), nbE = (int)(((size_t)N * G + RT - 1) / RT);
+    sx = SideInTail{N + nbP + nbE, nbP, t + 1, rec_at(h, t + 1, fused_rec(h))};
+    h->flags_valid = false; h->side_valid = true; h->side_main = true;
+  }
+  hipLaunchKernelGGL(k_mh_tail, dim3(sx.n + 2 * N + h->nblkE + nrec + (rs.on ? (h->cfg.MH ? 5 : 4) : 0)), dim3(ES_T), 0, h->stream, h->dev, t, (const double*)h->arr[BNMF_ACC_P].d, accPn_slot(h, t),
+                     (const double*)h->arr[BNMF_ACC_E].d, accEp_slot(h, t), h->dNzE, h->dNzE + N, h->nblkE, ra, nrec, rs, sx);
   h->mh_prep_valid = true;
   return 0;
 }
@@ -1512,10 +1520,12 @@ static int sweep_mh(bnmf_handle* h, int row, int converged, Timer& tm) {
   dbg_delay_main(h);
   tm.begin(KN_MH, h->stream); launch_mh_PE(h, t, converged, poll); tm.end(KN_MH, h->stream);
   dbg_delay_main(h);
-  if (h->mh_side_main) launch_side_main(h, t + 1, tm); else launch_side(h, t + 1, tm, !tm.on);
+  // the hyper sweep of t + 1: on the main stream — inside k_mh_tail below (its own launch in profile mode, which times it) — or on the side stream
+  const bool side_in_tail = h->mh_side_main && !tm.on && h->mh_side_tail;
+  if (side_in_tail) {} else if (h->mh_side_main) launch_side_main(h, t + 1, tm); else launch_side(h, t + 1, tm, !tm.on);
   if (h->cfg.learning_rank) { tm.begin(KN_RANK, h->stream); launch_rank(h, t); tm.end(KN_RANK, h->stream); }
   // record_sample rides in k_mh_tail: after sample_sigmasq, like record_sample (:279) after sample_params (:276)
-  tm.begin(KN_OTHER, h->stream); if (int rc = launch_mh_metrics(h, t, h->cfg.learning_rank != 0, true)) return rc; tm.end(KN_OTHER, h->stream);
+  tm.begin(KN_OTHER, h->stream); if (int rc = launch_mh_metrics(h, t, h->cfg.learning_rank != 0, true, side_in_tail)) return rc; tm.end(KN_OTHER, h->stream);
   launch_reduce(h, t, row, tm);
   return 0;
 }

@@ -721,11 +721,17 @@ __global__ __launch_bounds__(ES_T) void k_lp_e(Dev d, uint32_t t, const double* 
 //   the last blocks (rs.on)       : k_reduce's work for the iteration BEFORE (its partial sums lie in another slot): on a side stream it
 //                                   was ordered behind its inputs only, and nothing kept the kernels of three iterations on — which write
 //                                   its slot again — behind it once the hyper sweep had moved to the main stream (round 4)
+//   the FIRST blocks (sx.n > 0)   : k_side's work for the NEXT iteration (Esum, both hyper sweeps: they read P_t, E_t and the prior parameters of t, and
+//                                   write the other slot) — the two kernels ran one behind the other on the main stream, each too small for the device
+struct SideInTail { int n, nbP; uint32_t t; RecDst rec; };
+static_assert(ES_T == RT, "k_mh_tail: one block size for its own blocks, k_side's and k_reduce's");
 __global__ __launch_bounds__(ES_T) void k_mh_tail(Dev d, uint32_t t, const double* accP, double* accPn, const double* accE, double* accE_part, int* nzE, int* nzP, int nblkE, RecArgs ra,
-                                                   int nrec, RedSlots rs) {
+                                                   int nrec, RedSlots rs, SideInTail sx) {
   __shared__ double buf[ES_T];
   __shared__ int cnt;
-  const int tid = threadIdx.x, blk = blockIdx.x;
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < sx.n) { side_body(d, sx.t, sx.nbP, blockIdx.x, sx.n, sx.rec, SideDone{}, buf, tid); return; }
+  const int blk = (int)blockIdx.x - sx.n;
   if (blk >= 2 * d.N + nblkE + nrec) { reduce_body(d, rs, nblkE, blk - (2 * d.N + nblkE + nrec), buf, tid); return; }
   if (blk < d.N) {
     if (tid >= 64) return;

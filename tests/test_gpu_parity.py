@@ -436,6 +436,8 @@ def test_mh_chain_bitexact(prior, G, gw, monkeypatch):
         monkeypatch.setenv("BNMF_MHE_GW", gw)
     if gw == "16":
         monkeypatch.setenv("BNMF_MHSIDE", "0")
+    if gw == "32":
+        monkeypatch.setenv("BNMF_MHSIDETAIL", "0")          # the main-stream hyper sweep as a launch of its own (not inside k_mh_tail)
     import oracle as O
     from bayesnmf_amd import Engine
     from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
