@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cerrno>
 #include <algorithm>
 #include <map>
 #include <mutex>
@@ -16,6 +17,9 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 #include "kernels.h"
 #include "zalloc_reg.h"
 #include "zalloc_sort.h"
@@ -99,6 +103,7 @@ struct bnmf_handle {
   hipEvent_t ev[2 * BNMF_NKERNEL]{};
   bool have_ev = false;
   double* dMap = nullptr; size_t map_words = 0;   // scratch of bnmf_map (grown on demand)
+  int devlock_fd = -1;                 // the device's lock file (/tmp/bnmf_dev_<PCI bus id>.lock): g_rank_turn's rule across the PROCESSES that share the device
   unsigned char* dAsg = nullptr; size_t asg_bytes = 0;   // scratch of bnmf_assign (grown on demand): catalogue, norms, cosines, slot / signature lists
   unsigned* dFlags = nullptr;                     // [0] counter, [1] flag of the E-side hyper sweep; [2], [3] of P part + Esum; [5], [6] P inside k_draw;
                                                   // [8], [9] P-side sweep on its own stream
@@ -572,6 +577,16 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   if (int rc = take_stream(h->device, &h->side)) return rc;
   if (int rc = take_stream(h->device, &h->side2)) return rc;
   clk.mark("streams");
+  // one open file description per handle: flock() then also separates the handles of ONE process (BNMF_DEVLOCK=0: no file lock)
+  if (!(getenv("BNMF_DEVLOCK") && atoi(getenv("BNMF_DEVLOCK")) == 0)) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus - 1, h->device) == hipSuccess) {
+      for (char* c = bus; *c; ++c) if (!((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z'))) *c = '_';
+      char path[128];
+      snprintf(path, sizeof path, "/tmp/bnmf_dev_%s.lock", bus);
+      h->devlock_fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC, 0666);      // -1 (not ours to open, no /tmp): this process runs without it
+    } else (void)hipGetLastError();
+  }
   HIPCHK(hipEventCreateWithFlags(&h->ev_draw, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_sideP, hipEventDisableTiming));
@@ -858,6 +873,7 @@ int bnmf_destroy(bnmf_handle* h) {
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
   if (h->dMap) hipFree(h->dMap);
   if (h->dAsg) hipFree(h->dAsg);
+  if (h->devlock_fd >= 0) close(h->devlock_fd);
   if (h->dFlags) hipFree(h->dFlags); if (h->dDrawOwn) hipFree(h->dDrawOwn); if (h->dScal) hipFree(h->dScal); if (h->hErr) hipHostFree(h->hErr);
   give_stream(h->device, h->stream);                    // synchronised at the top of this function
   delete h;
@@ -1747,6 +1763,10 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
     if (h->cfg.learning_rank) turn = std::unique_lock<std::shared_mutex>(g_rank_turn[h->device]);
     else beside = std::shared_lock<std::shared_mutex>(g_rank_turn[h->device]);
   }
+  // ... and the same rule between the processes that share the device (each learns nothing of the others' launches): the device's
+  // lock file, exclusive / shared, for the length of the call (released when the call returns — or the process ends)
+  struct FileTurn { int fd; ~FileTurn() { if (fd >= 0) flock(fd, LOCK_UN); } } fturn{-1};
+  if (h && h->devlock_fd >= 0) { while (flock(h->devlock_fd, h->cfg.learning_rank ? LOCK_EX : LOCK_SH) != 0 && errno == EINTR) {} fturn.fd = h->devlock_fd; }
   if (!h) return fail(BNMF_EINVAL, "bnmf_run: null handle");
   if (!h->inited) return fail(BNMF_ESTATE, "bnmf_run: call bnmf_init first");
   if (h->poisoned) return fail(BNMF_ESTATE, "bnmf_run: an earlier call timed out inside a kernel; the handle's state is invalid, destroy it");

@@ -477,3 +477,14 @@ def test_chains_mixing_every_entry_point_at_once():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "api_mix_check.py"), "5"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_two_processes_share_the_device():
+    """tools/two_process_check.sh: two PROCESSES at once on the device, six full-size chains each, a rank-learning chain in both: the device's lock
+    file (/tmp/bnmf_dev_<PCI bus id>.lock: exclusive for a rank-learning call, shared for every other) keeps the two persistent rank sweeps — and a
+    rank sweep and the other process's gated chains — apart; without it (BNMF_DEVLOCK=0) both processes end in the rank sweep's time-out."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["bash", os.path.join(root, "tools", "two_process_check.sh"), "2"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
