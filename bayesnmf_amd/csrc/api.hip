@@ -99,6 +99,7 @@ struct bnmf_handle {
   uint32_t* dZsItems = nullptr; ZSBlock* dZsBlocks = nullptr; int* dZsCols = nullptr; unsigned long long* dZsProf = nullptr;
   // k_zalloc_step (zalloc_step.h): stats mode, 25 <= N <= 100, any K — the static schedule built from M at bnmf_create
   bool z_step = false; ZPGeom zpg{}; int zp_ns = 0 /* waves per workgroup */, zp_gbp = 0; size_t zp_lds = 0;
+  bool zp_it16 = false;                // k_zalloc_step's items as uint16
   uint32_t* dZpItems = nullptr; ZPWg* dZpWgs = nullptr; ZPBatch* dZpBatches = nullptr; ZPStep* dZpSteps = nullptr; int* dZpCols = nullptr;
   hipEvent_t ev[2 * BNMF_NKERNEL]{};
   bool have_ev = false;
@@ -465,6 +466,7 @@ static int build_zstep(bnmf_handle* h, const int32_t* M, int n_cu) {
   std::vector<uint32_t> items;
   items.reserve((size_t)((double)K * (double)G * 1.05) + 64 * steps.size());
   std::vector<uint32_t> bucket[ZP_QMAX + 1], wlist[ZP_WMAX], sorted;
+  int maxfrag = 0;
   for (size_t bi = 0; bi < batches.size(); ++bi) {
     const ZPBatch& bt = batches[bi];
     for (int ch = 0; ch < nch; ++ch) {
@@ -480,6 +482,7 @@ static int build_zstep(bnmf_handle* h, const int32_t* M, int n_cu) {
           for (int f = 0; f * ZP_QMAX < qt; ++f) {
             if (f >= (1 << 21)) return fail(BNMF_EINVAL, "bnmf_create: a cell of M holds %d counts: unsupported", m);
             bucket[std::min(ZP_QMAX, qt - f * ZP_QMAX)].push_back(base | ((uint32_t)f << 11));
+            maxfrag = std::max(maxfrag, f);
           }
         }
       }
@@ -497,8 +500,18 @@ static int build_zstep(bnmf_handle* h, const int32_t* M, int n_cu) {
     }
   }
   if (items.empty()) items.push_back(0xFFFFFFFFu);
-  HIPCHK(hipMalloc(&h->dZpItems, items.size() * sizeof(uint32_t)));
-  HIPCHK(hipMemcpy(h->dZpItems, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  // 2-byte items where the fragment index fits 5 bits beside row (5) and column (6), 0xFFFF staying the empty lane (column 63 does not
+  // occur): BNMF_ZPIT16=0 keeps the 4-byte form (diagnostics / tests)
+  h->zp_it16 = maxfrag <= 30 && !(getenv("BNMF_ZPIT16") && atoi(getenv("BNMF_ZPIT16")) == 0);
+  if (h->zp_it16) {
+    std::vector<uint16_t> i16(items.size());
+    for (size_t i = 0; i < items.size(); ++i) i16[i] = items[i] == 0xFFFFFFFFu ? (uint16_t)0xFFFFu : (uint16_t)items[i];
+    HIPCHK(hipMalloc(&h->dZpItems, (i16.size() * sizeof(uint16_t) + 3) & ~(size_t)3));
+    HIPCHK(hipMemcpy(h->dZpItems, i16.data(), i16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  } else {
+    HIPCHK(hipMalloc(&h->dZpItems, items.size() * sizeof(uint32_t)));
+    HIPCHK(hipMemcpy(h->dZpItems, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   HIPCHK(hipMalloc(&h->dZpWgs, wgs.size() * sizeof(ZPWg)));
   HIPCHK(hipMemcpy(h->dZpWgs, wgs.data(), wgs.size() * sizeof(ZPWg), hipMemcpyHostToDevice));
   HIPCHK(hipMalloc(&h->dZpBatches, batches.size() * sizeof(ZPBatch)));
@@ -1318,7 +1331,7 @@ static int launch_zsort(bnmf_handle* h, uint32_t t) {
   }
 }
 static int launch_zstep(bnmf_handle* h, uint32_t t) {
-  const ZPArgs pa{zargs(h), h->dZpItems, h->dZpWgs, h->dZpBatches, h->dZpSteps, h->dZpCols};
+  const ZPArgs pa{zargs(h), h->dZpItems, h->zp_it16 ? 1 : 0, h->dZpWgs, h->dZpBatches, h->dZpSteps, h->dZpCols};
   auto go = [&](auto kern) -> int {
     if (h->z_attr_kernel != (const void*)kern) {
       HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

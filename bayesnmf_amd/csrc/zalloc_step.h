@@ -56,6 +56,7 @@ struct ZPGeom { int nch, nwg; unsigned long long* prof; };   // prof: -DZPPROF b
 struct ZPArgs {
   ZArgs a;
   const uint32_t* items;             // row in chunk | column in batch << 5 | fragment << 11; 0xFFFFFFFF = empty lane
+  int it16;                          // the same fields as uint16 (no cell above 31 fragments = 7,440 counts): half the schedule's bytes per launch
   const ZPWg* wgs;
   const ZPBatch* batches;
   const ZPStep* steps;               // [batch][chunk]
@@ -204,7 +205,12 @@ __global__ __launch_bounds__(ZP_W * 64, ZP_W / 4) void k_zalloc_step(ZPArgs s, u
       for (int tk = 0; tk < st.ntw; ++tk) {
         // ---------------- pass A: lane = item
         ZPTIC(1);
-        const uint32_t it = s.items[(size_t)st.item0 + ((size_t)wave * st.ntw + tk) * 64 + lane];
+        uint32_t it;
+        {
+          const size_t ix = (size_t)st.item0 + ((size_t)wave * st.ntw + tk) * 64 + lane;
+          if (s.it16) { const uint32_t r = ((const uint16_t*)s.items)[ix]; it = r == 0xFFFFu ? 0xFFFFFFFFu : r; }   // wave-uniform
+          else it = s.items[ix];
+        }
         const bool valid = it != 0xFFFFFFFFu;
         if (__builtin_amdgcn_ballot_w64(valid) == 0) break;               // the wave's list is sorted: nothing behind an empty task
         const int kl = valid ? (int)(it & 31u) : 0, gl = valid ? (int)((it >> 5) & 63u) : 0;

@@ -320,6 +320,7 @@ def test_general_allocation_kernels(shape, force, kernel, monkeypatch):
     K, G, N = shape
     if kernel == "step32":
         monkeypatch.setenv("BNMF_ZPGB", "32")
+        monkeypatch.setenv("BNMF_ZPIT16", "0")               # ... and the 4-byte items ("step": 2-byte items, round 4)
     if kernel in ("tile", "wave"):
         monkeypatch.setenv("BNMF_ZSTEP", "0")
     if kernel == "wave":
@@ -348,6 +349,27 @@ def test_general_allocation_kernels(shape, force, kernel, monkeypatch):
         assert np.array_equal(o.get("E").view(np.uint64), e.get("E").view(np.uint64)), shape
         assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), shape
         e.close()
+
+
+def test_step_kernel_cell_beyond_the_two_byte_items():
+    """A cell of 9,000 counts is 38 items of k_zalloc_step: the fragment index no longer fits the 5 bits of the 2-byte item form, and
+    bnmf_create keeps the 4-byte items by itself."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import apply_hyperprior_params
+    rng = np.random.default_rng(5)
+    K, G, N = 40, 30, 30
+    M = rng.poisson(rng.gamma(0.5, 12.0, size=(K, G))).astype(np.int32)
+    M[3, 4] = 9000
+    o = O.Oracle(M, N, prior="gamma", seed=3, nthreads=4)
+    e = Engine(M, N, prior="gamma", seed=3)
+    for x in (o, e):
+        apply_hyperprior_params(x, "gamma", M, N)
+    o.init(); e.init()
+    mo, me = o.run(4), e.run(4)
+    assert np.array_equal(o.get("ZsumK").astype(np.int32), e.get("ZsumK")) and np.array_equal(o.get("ZsumG").astype(np.int32), e.get("ZsumG"))
+    assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64))
+    e.close()
 
 
 @pytest.mark.parametrize("N,excluded", [(30, [0, 29]), (50, list(range(3, 50))), (50, list(range(0, 50, 3)) + list(range(1, 50, 3))), (100, [n for n in range(100) if n % 7]),
