@@ -137,6 +137,9 @@ constexpr int MH_CPL = MH_SEG / 64;                       // cells per lane and 
 template <bool NORMAL, bool REG, bool MHSTEP /* the Metropolis-Hastings step runs (after convergence) */>
 __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, const int* nzE, int* nzP, double* accP, double* mhrow, double* mhlog, SideWait sw) {
   constexpr int mhstep = MHSTEP ? 1 : 0;
+#ifdef ZSPROF
+  const unsigned long long mhsK0 = __builtin_amdgcn_s_memrealtime();
+#endif
   side_wait(sw, threadIdx.x);                           // prior parameters of iteration t (k_side on the side stream)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -157,9 +160,11 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
     const double pj = d.P[k + (size_t)K * j]; pa[j] = pj * d.A[j]; pcur[j] = pj;
     anz[j] = d.A[j]; anz[N + j] = nzE[j] == 0 ? 1.0 : 0.0;
   }
-  // one factor per WAVE (lane 0): sixteen factors at a time beside each other, not one lane's worth of divergent code per wave
-  for (int j = wave; j < N; j += MHP_W) if (lane == 0) pre_store(prq + PRE_W * j, draw_pre<0>(d, k + K * j, t, MHSTEP));
-  wg_lds_barrier();
+  wg_lds_barrier();                                     // pa, anz are complete
+  // the factors' DrawPre by the LAST wave, one factor per lane (one pass for N <= 64; one factor per wave took two rounds at N = 20, with
+  // every other lane of the workgroup waiting), while the other waves form the row's Mhat below: the first reader (thread 0, behind the first
+  // barrier of the first factor step) finds them complete — every wave passes that barrier only after this code
+  if (wave == MHP_W - 1) for (int j = lane; j < N; j += 64) pre_store(prq + PRE_W * j, draw_pre<0>(d, k + K * j, t, MHSTEP));
   double mh[REG ? MH_CPL : 1], enr[REG ? MH_CPL : 1], enx[REG ? MH_CPL : 1], sgr[(REG && NORMAL) ? MH_CPL : 1];
   double lg[(REG && MHSTEP) ? MH_CPL : 1];              // log(max(Mhat, 1e-6)) of the lane's cells
   int mr[REG ? MH_CPL : 1];
@@ -193,6 +198,9 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
 #define MHSTAMP(i) const unsigned long long mhs##i = __builtin_amdgcn_s_memrealtime()
 #else
 #define MHSTAMP(i)
+#endif
+#ifdef ZSPROF
+  const unsigned long long mhsK1 = __builtin_amdgcn_s_memrealtime();
 #endif
   for (int n = 0; n < N; ++n) {
     MHSTAMP(0);
@@ -331,6 +339,13 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
     // no barrier here: the next factor's writers of `part` / `bc` are behind barriers that every wave reaches only after it has read
     // this factor's values (tid 0 reads `part` before the barrier that publishes bc; bc is rewritten only behind the next one)
   }
+#ifdef ZSPROF
+  if ((blockIdx.x == 0 || blockIdx.x == 50 || blockIdx.x == 95) && tid == 0) {
+    const unsigned long long mhsK2 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* o = &g_drprof[8 * (2048 + 129 + (blockIdx.x == 0 ? 0 : blockIdx.x == 50 ? 1 : 2))];
+    o[0] += mhsK1 - mhsK0; o[1] += mhsK2 - mhsK1; o[7] += 1ull;
+  }
+#endif
   wg_lds_barrier();                                        // pcur is complete
   // nzP[n] = number of non-zero entries of column n of P after the sweep (all(P[,n] == 0) test of sample_En_normal :56);
   // zeroed by k_mh_tail of the previous iteration (or the host before the first one)

@@ -34,3 +34,7 @@ if b[:, 7].sum() > 0:
     for i, nm in ((0, "prefetch + cells (before the trees)"), (1, "cells + trees"), (2, "draw"), (3, "MH step + update + fence"), (5, "whole step")):
         print(f"  {nm:36s} {b[:, i].sum() / b[:, 7].sum() / 100.0:7.3f} us")
     print(f"  {'set-up before the first step':36s} {su[0] / max(su[7], 1) / 100.0:7.3f} us")
+allr = np.array(list(out), dtype=np.float64).reshape(W, 8)
+for i, row in enumerate((0, 50, 95)):
+    r = allr[2048 + 129 + i]
+    if r[7] > 0: print(f"k_mh_prow row {row}: set-up before the first factor {r[0] / r[7] / 100.0:7.2f} us, the {20} factor steps {r[1] / r[7] / 100.0:7.2f} us")
