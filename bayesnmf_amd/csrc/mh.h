@@ -161,6 +161,9 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
     anz[j] = d.A[j]; anz[N + j] = nzE[j] == 0 ? 1.0 : 0.0;
   }
   wg_lds_barrier();                                     // pa, anz are complete
+#ifdef ZSPROF
+  const unsigned long long mhsKa = __builtin_amdgcn_s_memrealtime();
+#endif
   // the factors' DrawPre by the LAST wave, one factor per lane (one pass for N <= 64; one factor per wave took two rounds at N = 20, with
   // every other lane of the workgroup waiting), while the other waves form the row's Mhat below: the first reader (thread 0, behind the first
   // barrier of the first factor step) finds them complete — every wave passes that barrier only after this code
@@ -171,17 +174,32 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
   const int g0r = wave * MH_SEG + lane;                 // REG: this lane's cells are g0r + 64 i
   // fresh Mhat of the row (factor order), by the lane that owns the cell
   if (REG) {
+    // factor by factor with the lane's cells side by side (each cell's sum still runs in factor order) and EVERY load made — a cell beyond the
+    // row's end reads column G - 1 and is zeroed afterwards —: MH_CPL loads in flight per factor, four factors unrolled.  Cell by cell, every load
+    // waited for the one before it: 12.5 us of the kernel's 87 (stamps)
+    bool okc[MH_CPL]; int gi[MH_CPL];
 #pragma unroll
     for (int i = 0; i < MH_CPL; ++i) {
       const int g = g0r + 64 * i;
-      mh[i] = 0.0; mr[i] = 0; enx[i] = 0.0; enr[i] = 0.0; if (MHSTEP) lg[i] = 0.0; if (NORMAL) sgr[i] = 1.0;
-      if (wave < S && g < min(G, (wave + 1) * MH_SEG)) {
-        double c = 0.0;
-        for (int j = 0; j < N; ++j) c = c + pa[j] * d.Et[g + (size_t)G * j];
-        mh[i] = c; mr[i] = Mk[g]; enx[i] = d.Et[g];      // exposures of factor 0
-        if (MHSTEP) lg[i] = mh_log_clamped(c);
-        if (NORMAL) sgr[i] = d.sigmasq[g];
-      }
+      okc[i] = wave < S && g < min(G, (wave + 1) * MH_SEG);
+      gi[i] = okc[i] ? g : G - 1;
+      mh[i] = 0.0;
+    }
+#pragma unroll 4
+    for (int j = 0; j < N; ++j) {
+      const double paj = pa[j];
+      const double* Ej = d.Et + (size_t)G * j;
+#pragma unroll
+      for (int i = 0; i < MH_CPL; ++i) mh[i] = mh[i] + paj * Ej[gi[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < MH_CPL; ++i) {
+      mr[i] = 0; enx[i] = 0.0; enr[i] = 0.0; if (MHSTEP) lg[i] = 0.0; if (NORMAL) sgr[i] = 1.0;
+      if (okc[i]) {
+        mr[i] = Mk[gi[i]]; enx[i] = d.Et[gi[i]];         // exposures of factor 0
+        if (MHSTEP) lg[i] = mh_log_clamped(mh[i]);
+        if (NORMAL) sgr[i] = d.sigmasq[gi[i]];
+      } else mh[i] = 0.0;
     }
   } else {
     for (int s = wave; s < S; s += MHP_W) {
@@ -343,7 +361,7 @@ __global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, con
   if ((blockIdx.x == 0 || blockIdx.x == 50 || blockIdx.x == 95) && tid == 0) {
     const unsigned long long mhsK2 = __builtin_amdgcn_s_memrealtime();
     unsigned long long* o = &g_drprof[8 * (2048 + 129 + (blockIdx.x == 0 ? 0 : blockIdx.x == 50 ? 1 : 2))];
-    o[0] += mhsK1 - mhsK0; o[1] += mhsK2 - mhsK1; o[7] += 1ull;
+    o[0] += mhsK1 - mhsK0; o[1] += mhsK2 - mhsK1; o[2] += mhsKa - mhsK0; o[7] += 1ull;
   }
 #endif
   wg_lds_barrier();                                        // pcur is complete

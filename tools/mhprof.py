@@ -37,4 +37,4 @@ if b[:, 7].sum() > 0:
 allr = np.array(list(out), dtype=np.float64).reshape(W, 8)
 for i, row in enumerate((0, 50, 95)):
     r = allr[2048 + 129 + i]
-    if r[7] > 0: print(f"k_mh_prow row {row}: set-up before the first factor {r[0] / r[7] / 100.0:7.2f} us, the {20} factor steps {r[1] / r[7] / 100.0:7.2f} us")
+    if r[7] > 0: print(f"k_mh_prow row {row}: set-up before the first factor {r[0] / r[7] / 100.0:7.2f} us (of it the row's P, A, flags into LDS + barrier {r[2] / r[7] / 100.0:5.2f}), the {20} factor steps {r[1] / r[7] / 100.0:7.2f} us")
