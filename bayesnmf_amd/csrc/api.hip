@@ -66,6 +66,7 @@ struct bnmf_handle {
   uint32_t z_gate_next = 0;            // != 0: the allocation kernel being launched waits at its end for the hyper sweep of this iteration
   uint32_t z_gated_for = 0;            // the last allocation kernel gated for this iteration's hyper sweep (merged draw kernel, BNMF_GATE)
   bool side_ev_stale = false;          // ev_sideP / ev_side not recorded since the last side launches (fixed-rank sweep: recorded on demand)
+  bool mhe_k128 = false;               // BNMF_MHE_K128=1 (diagnostics / tests): k_mh_ecol16's 128-row form also where K <= 96
   bool mhe16 = false;                  // the MH / Normal column sweep by k_mh_ecol16 (K <= 128 and its LDS fits)
   bool red_on_side2 = false;           // the last k_reduce was issued on side2 (then side2 needs no event to be ordered behind it)
   double* E_alt = nullptr;             // Gibbs sweep: the other E buffer (k_edraw of t+1 does not overwrite what k_lpe of t still reads)
@@ -691,6 +692,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   if (cfg->MH || cfg->likelihood == BNMF_NORMAL) {
     h->mh_S = (int)((G + MH_SEG - 1) / MH_SEG);
     HIPCHK(hipMalloc(&h->dMhat, 3 * K * G * sizeof(double)));      // rows of Mhat maintained by the P sweep; log(Mhat) and its candidates (MH step)
+    if (const char* e = getenv("BNMF_MHE_K128")) h->mhe_k128 = atoi(e) != 0;
     if (const char* e = getenv("BNMF_MHE_GW")) h->mhe_gw = atoi(e) == 32 ? 32 : atoi(e) == 16 ? 16 : 0;   // diagnostics / tests: lanes per column of k_mh_ecol16 (0 = by mode)
     h->mhe_lds = 4 * (2 * N + 3 * K) * sizeof(double);             // k_mh_ecol: per wave E column, A, Mhat column, log(Mhat) and candidates
     if (h->mhe_lds > 64 * 1024) {
@@ -705,7 +707,9 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
       h->mhe16 = K <= (size_t)MHE16_KMAX && lds16_max <= 160 * 1024;
       if (h->mhe16 && lds16_max > 64 * 1024) {
         const void* ks[] = {(const void*)k_mh_ecol16<false, false, 16>, (const void*)k_mh_ecol16<false, true, 16>, (const void*)k_mh_ecol16<false, false, 32>,
-                            (const void*)k_mh_ecol16<false, true, 32>, (const void*)k_mh_ecol16<true, false, 16>, (const void*)k_mh_ecol16<true, false, 32>};
+                            (const void*)k_mh_ecol16<false, true, 32>, (const void*)k_mh_ecol16<true, false, 16>, (const void*)k_mh_ecol16<true, false, 32>,
+                            (const void*)k_mh_ecol16<false, false, 16, 96>, (const void*)k_mh_ecol16<false, true, 16, 96>, (const void*)k_mh_ecol16<false, false, 32, 96>,
+                            (const void*)k_mh_ecol16<false, true, 32, 96>, (const void*)k_mh_ecol16<true, false, 16, 96>, (const void*)k_mh_ecol16<true, false, 32, 96>};
         for (const void* kf : ks) HIPCHK(hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       }
     }
@@ -1491,7 +1495,10 @@ static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged, bool poll = 
     int g16 = ((G + cpw - 1) / cpw + 3) / 4; if (g16 > 2048) g16 = 2048;
     const size_t lds16 = (4 * (size_t)cpw * N * (1 + PRE_W) + 2 * (size_t)N) * sizeof(double);
     auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)(h->dNzE + N), accE, 0); };
-    if (gw == 16) { if (mhstep) go(k_mh_ecol16<false, true, 16>); else go(k_mh_ecol16<false, false, 16>); }
+    if (K <= 96 && !h->mhe_k128) {                         // register arrays for 96 rows (BNMF_MHE_K128=1: the 128-row form)
+      if (gw == 16) { if (mhstep) go(k_mh_ecol16<false, true, 16, 96>); else go(k_mh_ecol16<false, false, 16, 96>); }
+      else { if (mhstep) go(k_mh_ecol16<false, true, 32, 96>); else go(k_mh_ecol16<false, false, 32, 96>); }
+    } else if (gw == 16) { if (mhstep) go(k_mh_ecol16<false, true, 16>); else go(k_mh_ecol16<false, false, 16>); }
     else { if (mhstep) go(k_mh_ecol16<false, true, 32>); else go(k_mh_ecol16<false, false, 32>); }
   } else
   hipLaunchKernelGGL(k_mh_ecol<false>, dim3(grid), dim3(MHE_T), h->mhe_lds, h->stream, h->dev, t, mhstep, (const int*)(h->dNzE + N), accE, 0);
@@ -1505,7 +1512,10 @@ static int launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells, bool with_r
       const int gw = h->mhe_gw ? h->mhe_gw : 16, cpw = 64 / gw;
       int g16 = ((G + cpw - 1) / cpw + 3) / 4; if (g16 > 2048) g16 = 2048;
       const size_t lds16 = (4 * (size_t)cpw * N * (1 + PRE_W) + 2 * (size_t)N) * sizeof(double);
-      if (gw == 16) hipLaunchKernelGGL((k_mh_ecol16<true, false, 16>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
+      const bool k96 = h->cfg.K <= 96 && !h->mhe_k128;
+      if (gw == 16 && k96) hipLaunchKernelGGL((k_mh_ecol16<true, false, 16, 96>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
+      else if (gw == 16) hipLaunchKernelGGL((k_mh_ecol16<true, false, 16>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
+      else if (k96) hipLaunchKernelGGL((k_mh_ecol16<true, false, 32, 96>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
       else hipLaunchKernelGGL((k_mh_ecol16<true, false, 32>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
     } else {
       int grid = (G + 3) / 4; if (grid > 2048) grid = 2048;

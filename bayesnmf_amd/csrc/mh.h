@@ -545,9 +545,11 @@ BNMF_DEV double grp_bcast0(double v, int lane) {          // lane 0 of the group
   }
   return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
-template <bool METRICS_ONLY, bool MHSTEP, int GW>
+// KM: the rows the lanes' register arrays are sized for — 128, or 96 (the 96 trinucleotide contexts: a quarter fewer registers and no empty
+// rounds over rows 96..127; the kernel sits at the edge of two waves per SIMD)
+template <bool METRICS_ONLY, bool MHSTEP, int GW, int KM = MHE16_KMAX>
 __global__ __launch_bounds__(MHE_T) void k_mh_ecol16(Dev d, uint32_t t, const int* nzP, double* accE, int draw_sig) {
-  constexpr int MHE16_RPL = MHE16_KMAX / GW;              // rows per lane
+  constexpr int MHE16_RPL = KM / GW;                      // rows per lane
   constexpr int NS = 64 / GW;                             // accumulator slots per lane
   constexpr int CPW = 64 / GW;                            // columns per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

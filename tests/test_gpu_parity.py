@@ -458,6 +458,7 @@ def test_mh_chain_bitexact(prior, G, gw, monkeypatch):
         monkeypatch.setenv("BNMF_MHE_GW", gw)
     if gw == "16":
         monkeypatch.setenv("BNMF_MHSIDE", "0")
+        monkeypatch.setenv("BNMF_MHE_K128", "1")            # ... and the column kernel's 128-row form (K = 96 takes the 96-row form by default)
     if gw == "32":
         monkeypatch.setenv("BNMF_MHSIDETAIL", "0")          # the main-stream hyper sweep as a launch of its own (not inside k_mh_tail)
     import oracle as O
