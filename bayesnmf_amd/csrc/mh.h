@@ -581,14 +581,36 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol16(Dev d, uint32_t t, const in
 #pragma unroll
     for (int r = 0; r < MHE16_RPL; ++r) { const int kk = j + GW * r; mr[r] = kk < K ? d.M[kk + (size_t)K * gc] : 0; mh[r] = 0.0; }
     if (!METRICS_ONLY) {
+      // fresh Mhat of the column: factor by factor with the lane's rows side by side, every load made (a row beyond K reads row K - 1 and is
+      // zeroed afterwards; each row's sum in factor order), see k_mh_prow — in the forms that keep two waves per SIMD with it (the others go
+      // to 256 registers and one wave); else row by row
+      constexpr bool SIDE_BY_SIDE = GW == 32 || (KM == 96 && !MHSTEP);
+      if (!SIDE_BY_SIDE) {
 #pragma unroll
-      for (int r = 0; r < MHE16_RPL; ++r) {                   // fresh Mhat of the column
-        const int kk = j + GW * r;
-        if (kk < K) {
-          double c = 0.0;
-          for (int q = 0; q < N; ++q) c = c + (d.P[kk + (size_t)K * q] * anz[q]) * ec[q];
-          mh[r] = c;
-          if (MHSTEP) l0[MHSTEP ? r : 0] = mh_log_clamped(c);
+        for (int r = 0; r < MHE16_RPL; ++r) {
+          const int kk = j + GW * r;
+          if (kk < K) {
+            double c = 0.0;
+            for (int q = 0; q < N; ++q) c = c + (d.P[kk + (size_t)K * q] * anz[q]) * ec[q];
+            mh[r] = c;
+            if (MHSTEP) l0[MHSTEP ? r : 0] = mh_log_clamped(c);
+          }
+        }
+      } else {
+        int kr[MHE16_RPL];
+#pragma unroll
+        for (int r = 0; r < MHE16_RPL; ++r) kr[r] = min(j + GW * r, K - 1);
+#pragma unroll 1
+        for (int q = 0; q < N; ++q) {
+          const double aq = anz[q], eq = ec[q];
+          const double* Pq = d.P + (size_t)K * q;
+#pragma unroll
+          for (int r = 0; r < MHE16_RPL; ++r) mh[r] = mh[r] + (Pq[kr[r]] * aq) * eq;
+        }
+#pragma unroll
+        for (int r = 0; r < MHE16_RPL; ++r) {
+          if (j + GW * r < K) { if (MHSTEP) l0[MHSTEP ? r : 0] = mh_log_clamped(mh[r]); }
+          else mh[r] = 0.0;
         }
       }
       double pnx[MHE16_RPL];                                  // the lane's rows of the NEXT factor's column of P: loaded a step ahead
