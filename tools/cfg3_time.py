@@ -1,6 +1,9 @@
 """Config 3 alone (Poisson-TruncNormal + MH, N = 20, K = 96, G = 5,000): iterations per second before / after convergence, three runs."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("BNMF_TOOL_LIB"):                      # another build of the library (A/B)
+    import bayesnmf_amd.engine as _E
+    _E.LIB_PATH = os.path.abspath(os.environ["BNMF_TOOL_LIB"])
 from bayesnmf_amd import Engine
 from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
 M, _, _ = synth_counts(96, 5000, 8, 20250218)
