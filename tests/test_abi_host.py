@@ -207,52 +207,19 @@ def _shim_functions():
 
 
 def test_r_shim_binds_every_entry_point_of_the_header():
-    """The `.Call` shim (r/bnmf_shim.c) cannot be compiled here (no R), so its consistency with include/bnmf.h is checked as
-    text: every chain-level entry point of the header has a C_bnmf_* binding that calls it, every binding is registered in
-    call_methods with its own parameter count, PROTECT / UNPROTECT balance, and every `.Call` in r/bayesNMF_hip.R names a
-    registered routine and passes that many arguments."""
+    """Every chain-level entry point of include/bnmf.h has a C_bnmf_* binding in r/bnmf_shim.c that calls it.  (What the
+    compiler and an executed call can check — argument counts and types, PROTECT balance, registration, the `.Call`s of
+    r/bayesNMF_hip.R — is checked by compiling and RUNNING the shim: tests/test_rshim.py.)"""
     import re
     hdr = open(os.path.join(ROOT, "include", "bnmf.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(bnmf_\w+)\(", hdr, re.M))
+    declared = set(re.findall(r"^(?:int|const char\*|void)\s+(bnmf_\w+)\(", hdr, re.M))
     # not bound: unit probes of the parity tests, the profiler hook, library-level queries R has no use for
     not_bound = {"bnmf_ubench", "bnmf_test_math", "bnmf_test_sampler", "bnmf_test_philox", "bnmf_test_philox7", "bnmf_profile", "bnmf_kernel_name", "bnmf_version",
-                 "bnmf_device_count", "bnmf_last_error", "bnmf_get_array_i32", "bnmf_debug_rank", "bnmf_debug_zsort", "bnmf_debug_set_timeout"}
+                 "bnmf_device_count", "bnmf_last_error", "bnmf_get_array_i32", "bnmf_debug_rank", "bnmf_debug_zsort", "bnmf_debug_set_timeout", "bnmf_trim",
+                 "bnmf_probe_overlap"}
     src, fns = _shim_functions()
     for name in sorted(declared - not_bound):
         b = "C_" + name
         assert b in fns, f"{name} has no .Call binding in r/bnmf_shim.c"
         assert re.search(r"\b%s\(" % name, fns[b][1]) or name == "bnmf_destroy", f"{b} does not call {name}"
     assert "bnmf_last_error()" in src                                       # errors surface as Rf_error(bnmf_last_error())
-    reg = dict((n, int(k)) for n, k in re.findall(r'\{"(C_bnmf_\w+)",\s*\(DL_FUNC\)&\1,\s*(\d+)\}', src))
-    assert set(reg) == set(fns), set(reg) ^ set(fns)
-    for n, (npar, body) in fns.items():
-        assert reg[n] == npar, f"{n}: registered with {reg[n]} arguments, defined with {npar}"
-        prot = len(re.findall(r"\bPROTECT\(", body))
-        unprot = sum(int(k) for k in re.findall(r"\bUNPROTECT\((\d+)\)", body))
-        assert prot == unprot, f"{n}: {prot} PROTECT vs UNPROTECT({unprot})"
-    # argument counts of the C ABI calls themselves, against the header's prototypes
-    for name in sorted(declared - not_bound - {"bnmf_destroy"}):
-        proto = re.search(r"\b%s\(([^;]*?)\);" % name, hdr, re.S).group(1)
-        n_hdr = len([p for p in proto.split(",") if p.strip() and p.strip() != "void"])
-        call = re.search(r"\b%s\(" % name, fns["C_" + name][1])
-        i, depth, n_args, start = call.end(), 1, 1, call.end()
-        body = fns["C_" + name][1]
-        while depth:
-            c = body[i]
-            depth += {"(": 1, ")": -1}.get(c, 0)
-            n_args += 1 if (c == "," and depth == 1) else 0
-            i += 1
-        assert n_args == n_hdr, f"{name}: the shim passes {n_args} arguments, the header declares {n_hdr}"
-    # the R side
-    rsrc = open(os.path.join(ROOT, "r", "bayesNMF_hip.R")).read()
-    calls = list(re.finditer(r'\.Call\("(C_bnmf_\w+)"', rsrc))
-    assert {"C_bnmf_map", "C_bnmf_run_until", "C_bnmf_run_post_warmup", "C_bnmf_assign"} <= {m.group(1) for m in calls}
-    for m in calls:
-        assert m.group(1) in reg, m.group(1)
-        i, depth, n_args = m.end(), 1, 0
-        while depth:
-            c = rsrc[i]
-            depth += {"(": 1, ")": -1}.get(c, 0)
-            n_args += 1 if (c == "," and depth == 1) else 0
-            i += 1
-        assert n_args == reg[m.group(1)], f'.Call("{m.group(1)}"): {n_args} arguments in r/bayesNMF_hip.R, {reg[m.group(1)]} registered'
