@@ -98,6 +98,9 @@ struct bnmf_handle {
   int zs_it16 = 0, zs_qmax = ZS_QMAX;   // 2-byte items; quads per item
   uint32_t* dZsRec = nullptr; int zx_cols = 0; size_t zx_lds = 0;   // save_Z on the sorted schedule: the items' records, k_zexpand's columns per pass and LDS bytes
   uint32_t* dZsItems = nullptr; ZSBlock* dZsBlocks = nullptr; int* dZsCols = nullptr; unsigned long long* dZsProf = nullptr;
+  double* dZsMh = nullptr;              // [G][K] Mhat left by k_zalloc_sort for the per-column metric terms (colterms.h)
+  uint32_t ct_pending = 0;              // iteration whose column terms have not been summed yet (0: none)
+  int n_cu = 256;
   // k_zalloc_step (zalloc_step.h): stats mode, 25 <= N <= 100, any K — the static schedule built from M at bnmf_create
   bool z_step = false; ZPGeom zpg{}; int zp_ns = 0 /* waves per workgroup */, zp_gbp = 0; size_t zp_lds = 0;
   bool zp_it16 = false;                // k_zalloc_step's items as uint16
@@ -334,7 +337,7 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
         const size_t g = (size_t)bcols[b][gl];
         for (size_t k = 0; k < K; ++k) {
           const int m = M[k + K * g];
-          if (m <= 0) continue;
+          if (m <= 0) { tmp.push_back({0, (uint32_t)k | ((uint32_t)gl << 10)}); continue; }   // an item without counts: its lane leaves Mhat of the cell (s.mh)
           const int qt = (m + 3) >> 2;
           for (int f = 0; f * qmax < qt; ++f)
             tmp.push_back({std::min(qmax, qt - f * qmax), (uint32_t)k | ((uint32_t)gl << 10) | ((uint32_t)f << 16)});
@@ -388,6 +391,11 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   HIPCHK(hipMemcpy(h->dZsCols, cols.data(), cols.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMalloc(&h->dZsM, Mblk.size() * sizeof(int32_t)));
   HIPCHK(hipMemcpy(h->dZsM, Mblk.data(), Mblk.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  // three copies, iteration t in copy t % 3 (as the per-column partial sums): the terms of t are summed beside the allocation kernel of t + 1
+  // (k_side_lp of t + 2, stream side2), which is known to be over before the draw kernel of t + 3 starts — the allocation kernel of t + 2
+  // has waited for the flag of the k_side_lp behind it on that stream
+  HIPCHK(hipMalloc(&h->dZsMh, 3 * K * G * sizeof(double)));
+  HIPCHK(hipMemset(h->dZsMh, 0, 3 * K * G * sizeof(double)));
   if (c.save_Z) {
     const size_t hw = (N + 1) / 2;
     HIPCHK(hipMalloc(&h->dZsRec, items.size() * hw * sizeof(uint32_t)));
@@ -601,13 +609,13 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
       h->devlock_fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC, 0666);      // -1 (not ours to open, no /tmp): this process runs without it
     } else (void)hipGetLastError();
   }
-  HIPCHK(hipEventCreateWithFlags(&h->ev_draw, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&h->ev_sideP, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&h->ev_p, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&h->ev_rank, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&h->ev_z, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&h->ev_red, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_draw, hipEventDisableTiming | hipEventDisableSystemFence));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming | hipEventDisableSystemFence));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_sideP, hipEventDisableTiming | hipEventDisableSystemFence));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_p, hipEventDisableTiming | hipEventDisableSystemFence));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_rank, hipEventDisableTiming | hipEventDisableSystemFence));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_z, hipEventDisableTiming | hipEventDisableSystemFence));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_red, hipEventDisableTiming | hipEventDisableSystemFence));
   clk.mark("events");
   HIPCHK(hipMalloc(&h->dM, K * G * sizeof(int32_t)));
   HIPCHK(hipMemcpy(h->dM, M, K * G * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -856,6 +864,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
       }
     }
     if (const char* e = getenv("BNMF_ABLATE")) h->z_ablate = atoi(e);       // diagnostics only
+    h->n_cu = prop.multiProcessorCount;
     if (!h->z_tile && !h->z_step && !h->z_ablate) if (int rc = build_zsort(h, M, prop.multiProcessorCount)) return rc;
   }
   clk.mark("allocation-kernel schedule");
@@ -883,7 +892,7 @@ int bnmf_destroy(bnmf_handle* h) {
   if (h->dMhatZ) hipFree(h->dMhatZ);
   if (h->zpg.prof) hipFree(h->zpg.prof);
   if (h->dZpItems) hipFree(h->dZpItems); if (h->dZpWgs) hipFree(h->dZpWgs); if (h->dZpBatches) hipFree(h->dZpBatches); if (h->dZpSteps) hipFree(h->dZpSteps); if (h->dZpCols) hipFree(h->dZpCols);
-  if (h->dZsItems) hipFree(h->dZsItems); if (h->dZsBlocks) hipFree(h->dZsBlocks); if (h->dZsCols) hipFree(h->dZsCols); if (h->dZsProf) hipFree(h->dZsProf); if (h->dZsM) hipFree(h->dZsM); if (h->dZsRec) hipFree(h->dZsRec);
+  if (h->dZsItems) hipFree(h->dZsItems); if (h->dZsBlocks) hipFree(h->dZsBlocks); if (h->dZsCols) hipFree(h->dZsCols); if (h->dZsProf) hipFree(h->dZsProf); if (h->dZsM) hipFree(h->dZsM); if (h->dZsRec) hipFree(h->dZsRec); if (h->dZsMh) hipFree(h->dZsMh);
   if (h->dMhat) hipFree(h->dMhat); if (h->dAccPn) hipFree(h->dAccPn); if (h->dAccEpart) hipFree(h->dAccEpart); if (h->dNzE) hipFree(h->dNzE);
   if (h->dEt) hipFree(h->dEt); if (h->dMt) hipFree(h->dMt); if (h->zring) hipFree(h->zring);
   if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_rank) hipEventDestroy(h->ev_rank); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); give_stream(h->device, h->side); give_stream(h->device, h->side2);
@@ -1102,6 +1111,20 @@ static void issue_reduce(bnmf_handle* h, uint32_t t, int row, Timer& tm, hipStre
   h->red_on_side2 = st == h->side2;
   if (!h->red_on_side2) { hipEventRecord(h->ev_red, st); h->red_issued = true; }
 }
+// The per-column metric terms of iteration t from the Mhat k_zalloc_sort left (colterms.h), into the iteration's slot of the partial sums
+static CtArgs ct_args(const bnmf_handle* h, uint32_t t) {
+  const size_t G = h->cfg.G;
+  double* sse = h->dcol + (size_t)(t % 3u) * 3 * G;
+  return CtArgs{h->dZsMh + (size_t)(t % 3u) * h->cfg.K * G, h->dev.M, h->dev.lgfact, h->dev.logm, sse, sse + G, sse + 2 * G, h->cfg.K, h->cfg.G, h->dev.maxM};
+}
+// ... as a launch of its own on the main stream (behind the allocation kernel in stream order): whenever the next kernel on that stream
+// is not a merged draw kernel that could take the work along (first sweeps of a chain, two-kernel sweep, profile mode, end of a call)
+static void flush_colterms(bnmf_handle* h) {
+  if (!h->ct_pending) return;
+  const CtArgs a = ct_args(h, h->ct_pending);
+  hipLaunchKernelGGL(k_colterms, dim3((unsigned)((h->cfg.G + 2 * (CT_T / 64) - 1) / (2 * (CT_T / 64)))), dim3(CT_T), 0, h->stream, a);
+  h->ct_pending = 0;
+}
 // ev_sideP (side2 done) and ev_side (side done, behind ev_sideP) are what a main-stream wait or flush_reduce needs; in the
 // steady state of the fixed-rank sweep nobody waits for them (k_pdraw polls flags), so they are recorded on demand: a later
 // record covers everything enqueued before it
@@ -1165,7 +1188,7 @@ static void launch_side_P(bnmf_handle* h, uint32_t t, hipEvent_t after = nullptr
   // ... and the log-prior of the P just drawn (k_lpp's work, iteration t-1) in the same launch
   dbg_delay(h, h->side2);
   hipLaunchKernelGGL(k_side_lp, dim3(nbP + h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, h->cfg.N, rec_at(h, t, fused_rec(h)), SideDone{},
-                     SideExtra{nbP, h->cfg.N, 0, t - 1, nullptr, 0});
+                     SideExtra{nbP, h->cfg.N, 0, t - 1, nullptr, 0}, CtArgs{});
 }
 static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm, bool e_done = false) {   // ev_draw = completion of k_edraw(t-1); e_done: k_draw ran the E-side sweep
   const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
@@ -1176,7 +1199,7 @@ static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm, bool e_done = f
   // still holds): off the critical path
   dbg_delay(h, h->side2);
   hipLaunchKernelGGL(k_side_lp, dim3(h->cfg.N + h->nblkE), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)(h->cfg.N + h->nblkE), t},
-                     SideExtra{h->cfg.N, 0, h->nblkE, t - 1, lpe_src(h, t - 1), 1});
+                     SideExtra{h->cfg.N, 0, h->nblkE, t - 1, lpe_src(h, t - 1), 1}, CtArgs{});
   // k_reduce of the PREVIOUS iteration here, behind the kernels that produce its inputs on this stream (k_lpp, k_lpe) and
   // behind ev_draw (k_zalloc of that iteration): on the E part's stream it sat in front of the next E-side sweep, and the
   // P part waited for its event
@@ -1205,8 +1228,13 @@ static void launch_side_merged(bnmf_handle* h, uint32_t t, Timer& tm) {
   hipStreamWaitEvent(h->side2, h->ev_draw, 0);
   if (h->red_issued && !h->red_on_side2) hipStreamWaitEvent(h->side2, h->ev_red, 0);   // lpPn slot reuse, see launch_side_P
   dbg_delay(h, h->side2);
-  hipLaunchKernelGGL(k_side_lp, dim3(2 * N + h->nblkE), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)(2 * N + h->nblkE), t},
-                     SideExtra{N, N, h->nblkE, t - 1, lpe_src(h, t - 1), 1});
+  // the per-column metric terms of iteration t - 2 ride along (its allocation kernel ran before the draw kernel whose stop event this stream
+  // has just waited for): extra workgroups behind the log-prior ones, beside the allocation kernel of t - 1; k_reduce(t - 2) follows below
+  CtArgs ct{};
+  int n_ct = 0;
+  if (h->ct_pending) { ct = ct_args(h, h->ct_pending); n_ct = (h->cfg.G + 2 * (RT / 64) - 1) / (2 * (RT / 64)); h->ct_pending = 0; }
+  hipLaunchKernelGGL(k_side_lp, dim3(2 * N + h->nblkE + n_ct), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)(2 * N + h->nblkE), t},
+                     SideExtra{N, N, h->nblkE, t - 1, lpe_src(h, t - 1), 1}, ct);
   if (h->red_pending) { issue_reduce(h, h->red_t, h->red_row, tm, h->side2); h->red_pending = false; }
   h->flags_valid = true;
   h->side_ev_stale = true;
@@ -1301,7 +1329,7 @@ static int launch_zalloc_t(bnmf_handle* h, uint32_t t) {
 }
 template <int ZT_>
 static int launch_zsort_t(bnmf_handle* h, uint32_t t) {
-  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->zs_it16, h->zs_qmax, h->dZsRec, h->dZsProf};
+  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->zs_it16, h->zs_qmax, h->dZsRec, h->dZsMh + (size_t)(t % 3u) * h->cfg.K * h->cfg.G, h->dZsProf};
   auto go = [&](auto kern) -> int {
     if (h->z_attr_kernel != (const void*)kern) {
       HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1310,6 +1338,10 @@ static int launch_zsort_t(bnmf_handle* h, uint32_t t) {
     hipLaunchKernelGGL(kern, dim3(h->zsg.nblocks), dim3(ZT_), h->zs_lds, h->stream, sa, t, h->zsg);
     return 0;
   };
+#ifdef BNMF_FASTBUILD   /* builder's experiment builds only (one allocation kernel: the metric configuration's): never the product */
+  if (h->zs_nblk != 4) return fail(BNMF_EMODEL, "BNMF_FASTBUILD: only N = 16..20");
+  return h->zs_pk ? go(k_zalloc_sort<ZT_, 4, true>) : go(k_zalloc_sort<ZT_, 4, false>);
+#else
   if (h->zs_pk) switch (h->zs_nblk) {
     case 1: return go(k_zalloc_sort<ZT_, 1, true>);
     case 2: return go(k_zalloc_sort<ZT_, 2, true>);
@@ -1324,8 +1356,13 @@ static int launch_zsort_t(bnmf_handle* h, uint32_t t) {
     case 4: return go(k_zalloc_sort<ZT_, 4, false>);
     default: return go(k_zalloc_sort<ZT_, 5, false>);
   }
+#endif
 }
 static int launch_zsort(bnmf_handle* h, uint32_t t) {
+#ifdef BNMF_FASTBUILD
+  if (h->zs_w != 12) return fail(BNMF_EMODEL, "BNMF_FASTBUILD: only 12 waves");
+  return launch_zsort_t<768>(h, t);
+#else
   switch (h->zs_w) {
     case 16: return launch_zsort_t<1024>(h, t);
     case 12: return launch_zsort_t<768>(h, t);
@@ -1333,6 +1370,7 @@ static int launch_zsort(bnmf_handle* h, uint32_t t) {
     case 6: return launch_zsort_t<384>(h, t);
     default: return launch_zsort_t<256>(h, t);
   }
+#endif
 }
 static int launch_zstep(bnmf_handle* h, uint32_t t) {
   const ZPArgs pa{zargs(h), h->dZpItems, h->zp_it16 ? 1 : 0, h->dZpWgs, h->dZpBatches, h->dZpSteps, h->dZpCols};
@@ -1350,13 +1388,17 @@ static int launch_zalloc(bnmf_handle* h, uint32_t t) {
   if (h->z_sort) {
     if (int rc = launch_zsort(h, t)) return rc;
     if (h->cfg.save_Z) {                                   // the items' records -> the columns of Z (zalloc_sort.h k_zexpand)
-      const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->zs_it16, h->zs_qmax, h->dZsRec, h->dZsProf};
+      const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->zs_it16, h->zs_qmax, h->dZsRec, h->dZsMh + (size_t)(t % 3u) * h->cfg.K * h->cfg.G, h->dZsProf};
       hipLaunchKernelGGL(k_zexpand, dim3(h->zsg.nblocks), dim3(ZX_T), h->zx_lds, h->stream, sa, h->zx_cols);
     }
     return 0;
   }
   if (h->z_step) return launch_zstep(h, t);
   const bool sz = h->cfg.save_Z != 0;
+#ifdef BNMF_FASTBUILD
+  if (h->z_zw != 16) return fail(BNMF_EMODEL, "BNMF_FASTBUILD: only 16 waves");
+  return sz ? launch_zalloc_t<true, 1024>(h, t) : launch_zalloc_t<false, 1024>(h, t);
+#else
   switch (h->z_zw) {
     case 16: return sz ? launch_zalloc_t<true, 1024>(h, t) : launch_zalloc_t<false, 1024>(h, t);
     case 8: return sz ? launch_zalloc_t<true, 512>(h, t) : launch_zalloc_t<false, 512>(h, t);
@@ -1365,6 +1407,7 @@ static int launch_zalloc(bnmf_handle* h, uint32_t t) {
     case 2: return sz ? launch_zalloc_t<true, 128>(h, t) : launch_zalloc_t<false, 128>(h, t);
     default: return sz ? launch_zalloc_t<true, 64>(h, t) : launch_zalloc_t<false, 64>(h, t);
   }
+#endif
 }
 // sample_R then sample_An for n = 1..N (R/sample_params.R:67-74): one persistent launch for the N sequential updates
 // row >= 0 (Gibbs sweep): the kernel also records A, R and sum(A) of the iteration (k_sumA's work)
@@ -1600,6 +1643,7 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   if (!poll) { refresh_side_events(h); hipStreamWaitEvent(h->stream, h->ev_side, 0); }
   dbg_delay_main(h);
   if (tm.on) {                                             // profile mode: one kernel at a time
+    flush_colterms(h);
     tm.begin(KN_PDRAW, h->stream); launch_pdraw(h, t, 0, rec); tm.end(KN_PDRAW, h->stream);
     tm.begin(KN_EDRAW, h->stream); launch_edraw(h, t, 0, rec); tm.end(KN_EDRAW, h->stream);
     launch_side(h, t + 1, tm);
@@ -1621,6 +1665,7 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
     hipExtLaunchKernelGGL(k_draw, dim3(h->cfg.N + nE), dim3(bw), 0, h->stream, nullptr, h->ev_draw, 0, h->dev, t, rec_at(h, t, rec),
                           SideDone{h->dFlags + 5, h->dFlags + 6, (unsigned)h->cfg.N, t}, SideWait{h->dFlags + 6, h->dFlags + 6, t, h->dErr},
                           rec_at(h, t + 1, rec), SideDone{h->dFlags, h->dFlags + 1, nE, t + 1}, h->dDrawOwn, ++h->draw_seq, h->dbg_draw_no_p);
+
     launch_side_merged(h, t + 1, tm);
   } else {
     // The side work of this iteration may have been issued by launch_side_merged (the sweep before took the merged path without
@@ -1628,6 +1673,7 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
     // [9], which k_pdraw does not poll ([1] was raised by k_draw, [3] covers side2 only): the main stream waits for it here, and
     // with it launch_side_P below (released by k_pdraw's stop event) cannot overwrite the slot that sweep still reads.
     if (poll && h->gate_f0 == 9) { hipEventRecord(h->ev_side, h->side); hipStreamWaitEvent(h->stream, h->ev_side, 0); }
+    flush_colterms(h);                                     // (the column terms of t - 1: no draw kernel to take them along)
     // completion events ride on the dispatches themselves (stop events): no marker packets on the main stream
     hipExtLaunchKernelGGL(k_pdraw, dim3(h->cfg.N), dim3(PD_T), (uint32_t)(2 * (size_t)h->cfg.K * sizeof(double)), h->stream,
                           nullptr, h->ev_p, 0, h->dev, t, 0, 0, rec_pdraw(h, t, rec),
@@ -1650,7 +1696,10 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   const bool gate = gate_enabled(h) && !h->cfg.learning_rank && poll && h->z_reg && !h->z_tile;
   h->z_gate_next = gate ? t + 1 : 0u;
   dbg_delay_main(h);
-  tm.begin(KN_ZALLOC, h->stream); if (int rc = launch_zalloc(h, t)) return rc; tm.end(KN_ZALLOC, h->stream);
+  tm.begin(KN_ZALLOC, h->stream);
+  if (int rc = launch_zalloc(h, t)) return rc;
+  if (h->z_sort) { h->ct_pending = t; if (tm.on) flush_colterms(h); }   // (profile mode: the terms' own launch is timed with the allocation kernel)
+  tm.end(KN_ZALLOC, h->stream);
   h->z_gated_for = h->z_gate_next; h->z_gate_next = 0;
   record_Z(h, t);
   launch_reduce(h, t, row, tm, h->cfg.learning_rank != 0);
@@ -1677,7 +1726,7 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
     HIPCHK(hipMemset(h->dZsumK, 0, (size_t)h->cfg.N * h->cfg.G * sizeof(int32_t)));
     HIPCHK(hipMemset(h->dZsumG, 0, (size_t)h->cfg.K * h->cfg.N * sizeof(int32_t)));
     h->side_valid = false; h->side_main = false; h->flags_valid = false; h->z_gate_next = 0; h->z_gated_for = 0; h->gate_f0 = 1;
-    h->side_ev_stale = false; h->red_on_side2 = false; h->red_pending = false; h->red_issued = false; h->mh_prep_valid = false;
+    h->side_ev_stale = false; h->red_on_side2 = false; h->red_pending = false; h->red_issued = false; h->mh_prep_valid = false; h->ct_pending = 0;
     h->inited = false;
   }
   const bnmf_config& c = h->cfg;
@@ -1752,7 +1801,7 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
     hipLaunchKernelGGL(k_rank_Aprior, dim3((N + 63) / 64), dim3(64), 0, h->stream, h->dev, 1u);
   }
   if (c.MH || c.likelihood == BNMF_NORMAL) launch_mh_metrics(h, 1u, true);
-  else { if (int rc = launch_zalloc(h, 1u)) return rc; record_Z(h, 1u); }
+  else { if (int rc = launch_zalloc(h, 1u)) return rc; if (h->z_sort) { h->ct_pending = 1u; flush_colterms(h); } record_Z(h, 1u); }
   if (int rc = launch_record(h, 1u)) return rc;
   launch_reduce(h, 1u, 0, tm);
   flush_reduce(h, tm);
@@ -1813,6 +1862,7 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
   }
   if (runclock) rc_issued = rc_us();
   const bool reduces_on_side2 = h->red_on_side2;          // fixed-rank sweep: every earlier k_reduce sits on side2, which flush_reduce's wait covers
+  flush_colterms(h);                                       // the last iteration's column terms: no draw kernel behind it in this call
   flush_reduce(h, tm);
   if (!reduces_on_side2) { hipEventRecord(h->ev_z, h->side); hipStreamWaitEvent(h->stream, h->ev_z, 0); }   // the k_reduce launches on `side` are done
   hipLaunchKernelGGL(k_compose, dim3((n_iter + 63) / 64), dim3(64), 0, h->stream, h->dev, n_iter, t0);

@@ -21,15 +21,23 @@ BNMF_DEV double rexp(Stream& s, double rate) { const u32x4 w = s.next(); return 
 #ifdef ZSPROF
 constexpr int DRPROF_W = 4096;
 __device__ unsigned long long g_drprof[8 * DRPROF_W];   // diagnostics: section ticks of k_draw's E waves, [wave][8]; the last row's [4]: lanes that left ralpha_fast for the general sampler
+#ifdef ZSLIGHT   /* stamps only: no counters inside the samplers (they cost the profile build a factor of eight) */
+#define FB_COUNT
+#define PCOUNT(w, l)
+#else
 #define FB_COUNT atomicAdd(&g_drprof[8 * (DRPROF_W - 1) + 4], 1ull)
 // wave-level pass counters (first active lane counts) and lane-level attempt counters, last row: [0] Newton wave-iterations,
 // [1] Alpha wave-passes, [2] Alpha lane-attempts, [3] Newton lane-iterations, [5] rgamma wave-passes, [6] rgamma lane-attempts
 #define PCOUNT(w, l) do { if ((int)(threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_drprof[8 * (DRPROF_W - 1) + (w)], 1ull); \
                           atomicAdd(&g_drprof[8 * (DRPROF_W - 1) + (l)], 1ull); } while (0)
+#endif
 #else
 #define FB_COUNT
 #define PCOUNT(w, l)
 #endif
+// RETRY_PRIO (k_draw): a wavefront that goes round the rejection loop again raises its issue priority for the rest of the draw — it is
+// the wave its workgroup (and the kernel) will end with, and the SIMD's other waves are a pass ahead of it.  Timing only.
+template <bool RETRY_PRIO = false>
 BNMF_DEV double rgamma(Stream& s, double a, double rate) {
   if (!(a > 0.0)) return (a == 0.0) ? 0.0 : BNMF_NAN;
   const bool boost = a < 1.0;
@@ -39,6 +47,7 @@ BNMF_DEV double rgamma(Stream& s, double a, double rate) {
   double v = 1.0;
   for (int it = 0; it < MAX_ATTEMPTS; ++it) {
     PCOUNT(5, 6);
+    if (RETRY_PRIO && it == 1) __builtin_amdgcn_s_setprio(3);
     const u32x4 w = s.next();
     const double z = dqnorm(u52(w.x, w.y));
     const double ua = u52(w.z, w.w);
@@ -57,6 +66,7 @@ BNMF_DEV double rgamma(Stream& s, double a, double rate) {
     if (um1 / ua >= R) continue;
     if (dlog(ua) < R) break;
   }
+  if (RETRY_PRIO) __builtin_amdgcn_s_setprio(0);
   double g = d * v;
   if (boost) {
     const u32x4 w = s.next();
@@ -281,10 +291,14 @@ __global__ void k_alut_fill(int pass) {
   else g_alut[3 * i + 2] = i + 1 < ALUT_N ? (g_alut[3 * (i + 1)] - g_alut[3 * i]) / (alut_x(i + 1) - alut_x(i)) : g_alut[3 * i + 1];
 }
 constexpr int FAST_ATTEMPTS = 64;
-// lut: the table (g_alut, or a workgroup's copy of it in LDS: k_draw)
-BNMF_DEV double ralpha_fast(Stream& s, double c, double tau, double xprev, int* n_attempts = nullptr, const double* lut = g_alut) {
+// What an attempt of the fast path needs beside its Philox block: the Marsaglia-Tsang constants of Gamma(c, r) and the tangent of
+// lgamma at the grid point x0.
+struct AlphaFast { double d, cc, r, b0, psi0; };
+// The part of ralpha_fast in front of its attempts: Newton steps from the previous value towards the mode (psi from the table), the
+// grid point x0, the envelope.  false: the element takes the general sampler (c <= 1, r <= 0, a broad or skewed target).
+BNMF_DEV bool ralpha_setup(double c, double tau, double xprev, const double* lut, AlphaFast& p) {
   const double L = 1e-3, U = 1e4;
-  if (!(c > 1.0)) { FB_COUNT; return ralpha(s, c, tau, xprev, n_attempts); }
+  if (!(c > 1.0)) return false;
   double x = xprev;
   if (!(x >= L)) x = L;
   if (x > U) x = U;
@@ -311,41 +325,60 @@ BNMF_DEV double ralpha_fast(Stream& s, double c, double tau, double xprev, int* 
   // expected acceptance ~ 1 / sqrt(1 + rho), rho = psi'(x0) var(x): a broad or skewed target (small c) goes to the general sampler
   const double i0v = 1.0 / x0, tri = i0v + i0v * i0v;
   const double rho = tri / (cm1 * (i0v * i0v) + tri);
-  if (!(r > 0.0) || !(rho < 0.35)) { FB_COUNT; return ralpha(s, c, tau, xprev, n_attempts); }
-  const double d = c - 0.333333333333333333333;
-  const double cc = 1.0 / dsqrt(9.0 * d);
-  const double b0 = lg0 - psi0 * x0;
+  if (!(r > 0.0) || !(rho < 0.35)) return false;
+  p.d = c - 0.333333333333333333333;
+  p.cc = 1.0 / dsqrt(9.0 * p.d);
+  p.r = r;
+  p.b0 = lg0 - psi0 * x0;
+  p.psi0 = psi0;
+  return true;
+}
+// Attempt number `att` of an element = Philox block `att` of its (variable, element, iteration) stream: a pure function of the
+// element and the attempt number, so any lane may evaluate it.  true: accepted, xs is the draw.
+BNMF_DEV bool ralpha_attempt(uint32_t k0, uint32_t k1, uint32_t var, uint32_t elem, uint32_t iter, uint32_t att, const AlphaFast& p,
+                             const double* lut, double& xs_out) {
+  const double L = 1e-3, U = 1e4;
+  PCOUNT(1, 2);
+  const u32x4 w = philox4x32_10(att, elem, iter, var, k0, k1);
+  const double z = dqnorm(u52(w.x, w.y));
+  const double u = u52(w.z, w.w);
+  const double cz = p.cc * z;
+  double v = 1.0 + cz;
+  if (v <= 0.0) return false;
+  v = v * v * v;
+  const double xs = (p.d * v) / p.r;
+  if (!(xs >= L && xs <= U)) return false;
+  // lgamma(xs) between its tangent at the grid point below xs and its chord to the next one (lgamma is convex): most
+  // attempts are decided without evaluating it
+  const double lv = dabs(cz) <= 0.25 ? 3.0 * dlog1p_small(cz) : dlog(v);   // log v
+  const double a = (0.5 * (z * z) + p.d * ((1.0 - v) + lv)) + (p.b0 + p.psi0 * xs);
+  const int ix = alut_idx(xs);
+  const double dx = xs - alut_x(ix);
+  const bool grid = dx >= 0.0 && ix + 1 < ALUT_N;
+  const double tc = a - (lut[3 * ix] + lut[3 * ix + 2] * dx);   // a - chord   <= a - lgamma(xs)
+  const double tt = a - (lut[3 * ix] + lut[3 * ix + 1] * dx);   // a - tangent >= a - lgamma(xs)
+  // (u - 1) / u <= log(u) <= u - 1: the two grid tests without the logarithm when the bounds already decide them
+  const double um1 = u - 1.0;
+  bool accept;
+  if (grid && um1 < tc) accept = true;
+  else if (grid && um1 / u >= tt) accept = false;
+  else {
+    const double lu = dlog(u);
+    if (grid && lu < tc) accept = true;                  // below a - chord
+    else if (grid && lu >= tt) accept = false;           // at / above a - tangent
+    else accept = lu < a - dlgamma(xs);
+  }
+  xs_out = xs;
+  return accept;
+}
+// lut: the table (g_alut, or a workgroup's copy of it in LDS: k_draw)
+BNMF_DEV double ralpha_fast(Stream& s, double c, double tau, double xprev, int* n_attempts = nullptr, const double* lut = g_alut) {
+  AlphaFast p;
+  if (!ralpha_setup(c, tau, xprev, lut, p)) { FB_COUNT; return ralpha(s, c, tau, xprev, n_attempts); }
   for (int it = 0; it < FAST_ATTEMPTS; ++it) {
-    PCOUNT(1, 2);
-    const u32x4 w = s.next();
-    const double z = dqnorm(u52(w.x, w.y));
-    const double u = u52(w.z, w.w);
-    const double cz = cc * z;
-    double v = 1.0 + cz;
-    if (v <= 0.0) continue;
-    v = v * v * v;
-    const double xs = (d * v) / r;
-    if (!(xs >= L && xs <= U)) continue;
-    // lgamma(xs) between its tangent at the grid point below xs and its chord to the next one (lgamma is convex): most
-    // attempts are decided without evaluating it
-    const double lv = dabs(cz) <= 0.25 ? 3.0 * dlog1p_small(cz) : dlog(v);   // log v
-    const double a = (0.5 * (z * z) + d * ((1.0 - v) + lv)) + (b0 + psi0 * xs);
-    const int ix = alut_idx(xs);
-    const double dx = xs - alut_x(ix);
-    const bool grid = dx >= 0.0 && ix + 1 < ALUT_N;
-    const double tc = a - (lut[3 * ix] + lut[3 * ix + 2] * dx);   // a - chord   <= a - lgamma(xs)
-    const double tt = a - (lut[3 * ix] + lut[3 * ix + 1] * dx);   // a - tangent >= a - lgamma(xs)
-    // (u - 1) / u <= log(u) <= u - 1: the two grid tests without the logarithm when the bounds already decide them
-    const double um1 = u - 1.0;
-    bool accept;
-    if (grid && um1 < tc) accept = true;
-    else if (grid && um1 / u >= tt) accept = false;
-    else {
-      const double lu = dlog(u);
-      if (grid && lu < tc) accept = true;                  // below a - chord
-      else if (grid && lu >= tt) accept = false;           // at / above a - tangent
-      else accept = lu < a - dlgamma(xs);
-    }
+    double xs;
+    const bool accept = ralpha_attempt(s.k0, s.k1, s.var, s.elem, s.iter, s.blk, p, lut, xs);
+    ++s.blk;
     if (accept) { if (n_attempts) *n_attempts = it + 1; return xs; }
   }
   FB_COUNT;
@@ -353,6 +386,61 @@ BNMF_DEV double ralpha_fast(Stream& s, double c, double tau, double xprev, int* 
   const double xs = ralpha(s, c, tau, xprev, &na);
   if (n_attempts) *n_attempts = FAST_ATTEMPTS + na;
   return xs;
+}
+
+// ---- ralpha_fast for a whole wavefront (k_draw): the same draws, a bounded number of passes ----
+// An element's draw is its FIRST accepted attempt, and attempt k is a pure function of (element, k).  With one lane per element
+// and ~0.94 acceptance nearly every wavefront ran a second pass for its three or four rejected lanes, one in five a third (2.15
+// wave-passes for 1.06 attempts per element, and the kernel ended with its unluckiest wave).  Here the lanes whose element is
+// decided evaluate the LATER attempts of the undecided ones: with np elements pending each gets the next 64 / np attempts (rounded
+// down to a power of two) evaluated side by side, and takes the lowest-numbered accepted one — the attempt the sequential loop would
+// have stopped at.  Same bits, two passes (a third with probability ~1e-17 per element).
+// Every lane of the wave must call this (act = the lane has an element); lanes go to the general sampler exactly when ralpha_fast does.
+BNMF_DEV double ralpha_fast_wave(bool act, uint32_t k0, uint32_t k1, uint32_t var, uint32_t elem, uint32_t iter, double c, double tau, double xprev,
+                                 const double* lut) {
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  AlphaFast p{1.0, 1.0, 1.0, 0.0, 0.0};
+  int mode = 0;                                          // 0: no element, 1: fast path, 2: general sampler from block 0, 3: ... from block FAST_ATTEMPTS
+  if (act) mode = ralpha_setup(c, tau, xprev, lut, p) ? 1 : 2;
+  double res = 0.0;
+  bool pend = false;
+  if (mode == 1) pend = !ralpha_attempt(k0, k1, var, elem, iter, 0u, p, lut, res);
+  unsigned long long pm = __builtin_amdgcn_ballot_w64(pend);
+  uint32_t nk = 1;
+  while (pm != 0ull) {                                   // wave-uniform: every lane takes part in the exchanges below
+    __builtin_amdgcn_s_setprio(3);                       // the wave is a pass behind the others of its SIMD (timing only)
+    const int np = __builtin_popcountll(pm);
+    const int lg = 31 - __builtin_clz((unsigned)(64 / np));          // attempts per pending element this round: 2^lg <= 64 / np
+    const int per = 1 << lg;
+    const int slot = lane >> lg, off = lane & (per - 1);
+    int src = 0;                                         // the slot-th pending lane
+    { unsigned long long m = pm; int rk = 0; while (m) { const int b = __builtin_ctzll(m); m &= m - 1ull; src = (slot == rk) ? b : src; ++rk; } }
+    AlphaFast q;
+    q.d = __shfl(p.d, src); q.cc = __shfl(p.cc, src); q.r = __shfl(p.r, src); q.b0 = __shfl(p.b0, src); q.psi0 = __shfl(p.psi0, src);
+    const uint32_t el = (uint32_t)__shfl((int)elem, src);
+    const uint32_t att = nk + (uint32_t)off;
+    double xh = 0.0;
+    bool ok = false;
+    if (slot < np && att < (uint32_t)FAST_ATTEMPTS) ok = ralpha_attempt(k0, k1, var, el, iter, att, q, lut, xh);
+    const unsigned long long am = __builtin_amdgcn_ballot_w64(ok);
+    // the pending lane of rank rho owns the verdicts of lanes [rho 2^lg, (rho + 1) 2^lg)
+    const int rho = __builtin_popcountll(pm & ((1ull << lane) - 1ull));
+    const unsigned long long mine = pend ? (am >> (rho << lg)) & (per == 64 ? ~0ull : ((1ull << per) - 1ull)) : 0ull;
+    const int win = mine ? (rho << lg) + __builtin_ctzll(mine) : lane;
+    const double xw = __shfl(xh, win);
+    if (mine) { res = xw; pend = false; }
+    nk += (uint32_t)per;
+    if (pend && nk >= (uint32_t)FAST_ATTEMPTS) { mode = 3; pend = false; }
+    pm = __builtin_amdgcn_ballot_w64(pend);
+  }
+  __builtin_amdgcn_s_setprio(0);
+  if (mode >= 2) {
+    FB_COUNT;
+    Stream s(k0, k1, var, elem, iter);
+    s.blk = mode == 3 ? (uint32_t)FAST_ATTEMPTS : 0u;
+    res = ralpha(s, c, tau, xprev, nullptr);
+  }
+  return res;
 }
 
 }  // namespace bnmf

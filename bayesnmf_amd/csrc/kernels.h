@@ -12,6 +12,7 @@
 // independent of scheduling.  No MFMA: the path is sampling + reductions.
 #pragma once
 #include "dsamplers.h"
+#include "colterms.h"
 #include "../../include/bnmf.h"
 
 namespace bnmf {
@@ -100,7 +101,7 @@ BNMF_DEV double ld_ag(const double* p) { return __hip_atomic_load(p, __ATOMIC_RE
 // wait for P); rgamma(s, shape, rate) is that value divided by the rate, so the result is the same bits.  lut: ralpha_fast's table.
 // It also carries the element's hyper-prior values and previous Alpha: loaded before the wait, not behind it.
 struct HyperPre { double g, hB, hC, hD, al_old; };
-template <int SIDE>
+template <int SIDE, bool RETRY_PRIO = false>
 BNMF_DEV HyperPre hyper_pre(const Dev& d, int e, uint32_t t) {
   const HRef &hA = SIDE ? d.hA_e : d.hA_p, &hB = SIDE ? d.hB_e : d.hB_p;
   HyperPre p{0.0, hy(hB, e), 0.0, 0.0, 0.0};
@@ -109,11 +110,11 @@ BNMF_DEV HyperPre hyper_pre(const Dev& d, int e, uint32_t t) {
     p.hC = hy(hC, e); p.hD = hy(hD, e);
     p.al_old = slot<SIDE>(d, SIDE ? d.Alpha_e : d.Alpha_p, t - 1)[e];
     Stream s(d.k0, d.k1, SIDE ? BNMF_V_BETA_E : BNMF_V_BETA_P, (uint32_t)e, t);
-    p.g = rgamma(s, hy(hA, e) + p.al_old, 1.0);
+    p.g = rgamma<RETRY_PRIO>(s, hy(hA, e) + p.al_old, 1.0);
     return p;
   }
   Stream s(d.k0, d.k1, SIDE ? BNMF_V_LAMBDA_E : BNMF_V_LAMBDA_P, (uint32_t)e, t);
-  p.g = rgamma(s, hy(hA, e) + 1.0, 1.0);
+  p.g = rgamma<RETRY_PRIO>(s, hy(hA, e) + 1.0, 1.0);
   return p;
 }
 template <int SIDE, bool PRE = false>
@@ -371,11 +372,50 @@ __global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, Side
     if (jobS >= 0) p_column(jobS);
     return;
   }
-  // lane 0 waits for the flag pd; after a while it looks for a column of P that nobody has taken (see the head of the kernel).
-  // Returns the column this workgroup has to draw, or -1: P is complete.
+  // ---------------- E workgroups.  Round 5: no workgroup barrier after the head of the kernel.  Stamps of the waves (tools/drstamps.py) showed
+  // the barrier behind the wait for P costing every wave 2.4 us (the workgroup's slowest wave: a second pass of a rejection loop), and
+  // the kernel ending 6 us behind its median wave (Alpha: 2, 3 or 4 passes).  Now a wave waits for P by itself, the Alpha draws of a wave
+  // take two passes (ralpha_fast_wave), and a column of P that nobody has taken is drawn by ONE WAVE (p_column_wave).
+  const int lane = tid & 63;
+  // column n of P by one wavefront: p_column's operations in p_column's order (lane l takes rows l, l + 64, ...; Psum: the canonical W = 64 sum)
+  auto p_column_wave = [&](int n) __attribute__((always_inline)) {
+    const double a_n = d.A[n];
+    const double Esum = d.Esum[n];
+    double acc = 0.0;
+    for (int k = lane; k < K; k += 64) {
+      const int e = k + K * n;
+      double x;
+      if (a_n == 0.0) x = prior_draw<0>(d, e, t);
+      else {
+        double shape, rate;
+        if (d.prior == BNMF_GAMMA) { shape = slot<0>(d, d.Alpha_p, t)[e] + (double)d.ZsumG[e]; rate = slot<0>(d, d.Beta_p, t)[e] + a_n * Esum; }
+        else { shape = 1.0 + (double)d.ZsumG[e]; rate = slot<0>(d, d.Lam_p, t)[e] + a_n * Esum; }
+        Stream s(d.k0, d.k1, BNMF_V_P, (uint32_t)e, t);
+        x = rgamma(s, shape, rate);
+      }
+      d.P[e] = x;
+      if (rec.P) rec.P[e] = x;
+      d.ZsumG[e] = 0;
+      acc = acc + x;
+    }
+    if (rec.A && lane == 0) rec.A[n] = a_n;
+    if (rec.R && lane == 0 && n == 0) *rec.R = (double)*d.R;
+    acc = wave_tree64(acc);
+    if (lane == 0) st_wt(&d.Psum[n], acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have left (side_done's hand-off, for one wave)
+    if (lane == 0 && pd.flag) {
+      const unsigned old = __hip_atomic_fetch_add(pd.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == pd.nblk - 1) {
+        __hip_atomic_store(pd.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pd.flag, pd.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  // lane 0 of the wave waits for the flag pd; after a while it looks for a column of P that nobody has taken (see the head of the
+  // kernel).  Returns the column this wave has to draw, or -1: P is complete.
   auto wait_p = [&]() __attribute__((always_inline)) -> int {
-    if (tid == 0) {
-      int job = -1;
+    int job = -1;
+    if (lane == 0) {
       unsigned spins = 0;
       while (__hip_atomic_load(pw.f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pw.epoch) {
         __builtin_amdgcn_s_sleep(1);
@@ -386,73 +426,93 @@ __global__ __launch_bounds__(DW) void k_draw(Dev d, uint32_t t, RecDst rec, Side
           if (job >= 0) break;
         }
       }
-      jobS = job;
     }
-    __syncthreads();
-    return jobS;
+    return __builtin_amdgcn_readfirstlane(job);
   };
-  // the E role of the workgroup; returns a column of P to draw first (then the role is run again from its start: the same streams,
-  // the same bits — so that no draw has to be kept in registers across the column's code), or -1 when done
-  auto e_role = [&]() __attribute__((always_inline)) -> int {
   const long e = (long)((int)blockIdx.x - N) * BW + tid;
   const bool live = e < (long)d.lenE;
-  DRSTAMP(0);
-  double x = 0.0, a_n = 0.0;
-  bool scaled = false;                                   // x is Gamma(shape, 1) and still has to be divided by the rate
-  double base = 0.0;                                     // the rate without its Psum term
-  HyperPre hpre{};                                       // Gamma(shape, 1) part of the hyper sweep's first draw and the element's hyper-prior values (need nothing from this iteration)
-  int n = 0;
-  if (live) {
-    n = (int)(e % N);
-    a_n = d.A[n];
-    if (a_n == 0.0) x = prior_draw<1>(d, (int)e, t);
-    else {
-      double shape;
-      if (d.prior == BNMF_GAMMA) { shape = slot<1>(d, d.Alpha_e, t)[e] + (double)d.ZsumK[e]; base = slot<1>(d, d.Beta_e, t)[e]; }
-      else { shape = 1.0 + (double)d.ZsumK[e]; base = slot<1>(d, d.Lam_e, t)[e]; }
-      Stream s(d.k0, d.k1, BNMF_V_E, (uint32_t)e, t);
-      x = rgamma(s, shape, 1.0);
-      scaled = true;
-    }
-    hpre = hyper_pre<1>(d, (int)e, t + 1);
-  }
-  // the Alpha table: behind the draws (the waves arrive here one by one, so its loads overlap the others' arithmetic; at the head of
-  // the kernel every wave sat through them at once), visible after wait_p's barrier
-  if (d.prior == BNMF_GAMMA) for (int i = tid; i < 3 * ALUT_N; i += BW) lutS[i] = g_alut[i];
-  DRSTAMP(1);
-  const int job = wait_p();
-  if (job >= 0) return job;
-  DRSTAMP(2);
-  if (live) {
-    if (scaled) {
-      const double rate = base + a_n * ld_ag(&d.Psum[n]);
-      // rgamma(shape, rate) ends in `g / rate`; rgamma(shape, 1.0) returned g / 1.0 = g
-      x = x / rate;
-    }
-    d.E[e] = x;
-    if (rec.E) rec.E[e] = x;
-    if (d.zsumk_accum) d.ZsumK[e] = 0;
-#ifdef ZSPROF
-    DRSTAMP(3);
-    hyper_elem<1, true>(d, (int)e, t + 1, x, rec_next.pp[2], rec_next.pp[3], hpre, lutS);
-    DRSTAMP(4);
-    if ((tid & 63) == 0 && (e >> 6) < DRPROF_W - 1) {
-      unsigned long long* o = &g_drprof[8 * (e >> 6)];
-      o[0] += st1 - st0; o[1] += st2 - st1; o[2] += st3 - st2; o[3] += st4 - st3; o[5] += st4 - st0; o[6] = st0; o[7] += 1ull;
-    }
-#else
-    hyper_elem<1, true>(d, (int)e, t + 1, x, rec_next.pp[2], rec_next.pp[3], hpre, lutS);
+  const bool gam = d.prior == BNMF_GAMMA;
+  // the Alpha table: requested at the head of the kernel together with the element's own values; the one barrier of the E role
+  if (gam) for (int i = tid; i < 3 * ALUT_N; i += BW) lutS[i] = g_alut[i];
+  __syncthreads();
+  // the E role of the wave; returns a column of P to draw first (then the role is run again from its start: the same streams, the same
+  // bits — so that no draw has to be kept in registers across the column's code), or -1 when done
+  auto e_role = [&]() __attribute__((always_inline)) -> int {
+    DRSTAMP(0);
+#ifdef ZSLIGHT
+    unsigned long long stA = 0;
 #endif
-  }
-  side_done(ed, tid);
-  return -1;
+    double x = 0.0, a_n = 0.0;
+    bool scaled = false;                                 // x is Gamma(shape, 1) and still has to be divided by the rate
+    double base = 0.0;                                   // the rate without its Psum term
+    HyperPre hpre{};                                     // Gamma(shape, 1) part of the hyper sweep's first draw and the element's hyper-prior values (need nothing from this iteration)
+    int n = 0;
+    if (live) {
+      n = (int)(e % N);
+      a_n = d.A[n];
+      if (a_n == 0.0) x = prior_draw<1>(d, (int)e, t);
+      else {
+        double shape;
+        if (gam) { shape = slot<1>(d, d.Alpha_e, t)[e] + (double)d.ZsumK[e]; base = slot<1>(d, d.Beta_e, t)[e]; }
+        else { shape = 1.0 + (double)d.ZsumK[e]; base = slot<1>(d, d.Lam_e, t)[e]; }
+        Stream s(d.k0, d.k1, BNMF_V_E, (uint32_t)e, t);
+        x = rgamma<true>(s, shape, 1.0);
+        scaled = true;
+      }
+#ifdef ZSLIGHT
+      stA = __builtin_amdgcn_s_memtime();
+#endif
+      hpre = hyper_pre<1, true>(d, (int)e, t + 1);
+    }
+    DRSTAMP(1);
+    const int job = wait_p();
+    if (job >= 0) return job;
+    DRSTAMP(2);
+    double tau = 0.0;
+    if (live) {
+      if (scaled) {
+        const double rate = base + a_n * ld_ag(&d.Psum[n]);
+        // rgamma(shape, rate) ends in `g / rate`; rgamma(shape, 1.0) returned g / 1.0 = g
+        x = x / rate;
+      }
+      d.E[e] = x;
+      if (rec.E) rec.E[e] = x;
+      if (d.zsumk_accum) d.ZsumK[e] = 0;
+    }
+    DRSTAMP(3);
+    // the E-side hyper sweep of t + 1 (hyper_elem<1, true>'s operations; the Alpha draws of the wave side by side)
+    if (gam) {
+      if (live) {
+        const double b = hpre.g / (hpre.hB + x);                                                    // sample_Beta_En  :339-345
+        st_wt(&slot<1>(d, d.Beta_e, t + 1)[e], b);
+        if (rec_next.pp[3]) rec_next.pp[3][e] = b;
+        tau = (hpre.hD - dlog(clamp_tiny(b))) - dlog(clamp_tiny(x));
+      }
+      const double al = ralpha_fast_wave(live, d.k0, d.k1, BNMF_V_ALPHA_E, (uint32_t)e, t + 1, hpre.hC, tau, hpre.al_old, lutS);   // sample_Alpha_Eng :382-397
+      if (live) {
+        st_wt(&slot<1>(d, d.Alpha_e, t + 1)[e], al);
+        if (rec_next.pp[2]) rec_next.pp[2][e] = al;
+      }
+    } else if (live) hyper_elem<1, true>(d, (int)e, t + 1, x, rec_next.pp[2], rec_next.pp[3], hpre, lutS);
+#ifdef ZSPROF
+    DRSTAMP(4);
+    if (live && lane == 0 && (e >> 6) < DRPROF_W - 1) {
+      unsigned long long* o = &g_drprof[8 * (e >> 6)];
+#ifdef ZSLIGHT
+      o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st4; o[5] = stA; o[6] = __builtin_amdgcn_s_memrealtime(); o[7] = 1ull;   // absolute stamps of the last launch
+#else
+      o[0] += st1 - st0; o[1] += st2 - st1; o[2] += st3 - st2; o[3] += st4 - st3; o[5] += st4 - st0; o[6] = st0; o[7] += 1ull;
+#endif
+    }
+#endif
+    return -1;
   };
   int job = e_role();
   if (__builtin_expect(job >= 0, 0)) {                    // never taken under in-order dispatch
-    do { __syncthreads(); p_column(job); __syncthreads(); job = wait_p(); } while (job >= 0);
-    __syncthreads();
+    do { p_column_wave(job); job = wait_p(); } while (job >= 0);
     e_role();                                             // P is complete: runs through
   }
+  side_done(ed, tid);
 }
 
 // log-prior of column n of P_t under iteration t's prior parameters: canonical W = 64 over k, as in k_pdraw
@@ -485,10 +545,17 @@ __global__ __launch_bounds__(ES_T) void k_lpe(Dev d, uint32_t t, const double* E
 // other; side_done counts the k_side workgroups only.
 struct SideExtra { int first, n_lpp, n_lpe; uint32_t t_lp; const double* Esrc; int count_all; };   // count_all: the log-prior workgroups count towards sd too
 static_assert(ES_T == RT, "k_side_lp: one block size for both kinds of workgroup");
-__global__ __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(152))) void k_side_lp(Dev d, uint32_t t, int nbP, int blk0, RecDst rec, SideDone sd, SideExtra ex) {
+// Round 5: workgroups behind the log-prior ones sum the per-column metric terms of the iteration whose allocation kernel has left its Mhat
+// behind (colterms.h; ct.mh != null): four pairs of columns each.  They belong to no flag: k_reduce follows this kernel in stream order.
+__global__ __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(152))) void k_side_lp(Dev d, uint32_t t, int nbP, int blk0, RecDst rec, SideDone sd, SideExtra ex, CtArgs ct) {
   __shared__ double buf[RT];
   const int j = (int)blockIdx.x - ex.first;
   if (j < 0) { side_body(d, t, nbP, blockIdx.x + blk0, ex.first, rec, sd, buf, threadIdx.x); return; }
+  if (j >= ex.n_lpp + ex.n_lpe) {
+    const int p = (j - ex.n_lpp - ex.n_lpe) * (RT / 64) + ((int)threadIdx.x >> 6);
+    if (2 * p < ct.G) colterms_pair(ct, 2 * p, (int)threadIdx.x & 63);
+    return;
+  }
   if (j < ex.n_lpp) { if (threadIdx.x < 64) lpp_body(d, ex.t_lp, j, threadIdx.x); }
   else lpe_body(d, ex.t_lp, j - ex.n_lpp, ex.Esrc, buf, threadIdx.x);
   // the prior parameters these workgroups read (slot t_lp & 1) are overwritten two iterations on: where the writer is released

@@ -42,6 +42,7 @@ struct ZSArgs {
   const int32_t* Mblk;               // M with its columns in block order: column col0 + gl of Mblk = column cols[col0 + gl] of M
   int it16, qmax;                    // item format; quads per item (ZS_QMAX, or ZS_QMAX16 with 2-byte items)
   uint32_t* rec;                     // save_Z: [item slot / 64][(N + 1) / 2][64] the items' histograms, two 16-bit counts per word; else null
+  double* mh;                        // [G][K] Mhat of every cell, left by the lane of the cell's first item for the per-column metric terms (colterms_pair)
   unsigned long long* prof;          // -DZSPROF builds only: per-section s_memtime ticks summed over the waves (diagnostics)
 };
 // -DZSPROF: section timers.  [0] block set-up, [1] thresholds, [2] quad loops, [3] histogram flush, [4] metric tasks,
@@ -53,7 +54,6 @@ struct ZSArgs {
 #define ZSTIC(i)
 #define ZSTOC(i)
 #endif
-constexpr int ZS_MCOL = 2;           // columns per metric task (independent chains in flight: the task is latency-bound)
 // host and device agree on the LDS layout through these.  PK: zG / zK hold two factors per word (16-bit halves, as the
 // lanes' histograms do), chosen at bnmf_create when no half can overflow
 #define BNMF_HD __host__ __device__ inline
@@ -129,8 +129,7 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
   __syncthreads();
   ZSTOC(0);
   const int nthr = N - 1;
-  const int nmt = (bk.ncols + ZS_MCOL - 1) / ZS_MCOL;      // metric tasks
-  const int ntot = bk.ntask + nmt;
+  const int ntot = bk.ntask;
   const uint32_t hlb = lds_off(hist + lane);
   // the next task of the block: lane 0 draws a ticket, every lane reads lane 0's (readlane: whatever EXEC is)
   auto next_task = [&]() -> int {
@@ -138,88 +137,14 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
     if (lane == 0) tk = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return __builtin_amdgcn_readlane(tk, 0);
   };
-  // tickets [0, nmt): metric tasks (uniform size), then the item tasks in descending size: the block's tail is made of its
-  // smallest tasks
-  for (int tk = next_task(); tk < ntot; tk = next_task()) {
-    const int task = tk - nmt;
-    if (task < 0) {
-      ZSTIC(4);
-      // ---------------- metric task: ZS_MCOL columns, lane = row, canonical W = 64 sums per column (as phase 1 of
-      // k_zalloc_reg); the columns' chains are independent and interleave
-      const int gl0 = tk * ZS_MCOL;
-      double a_sse[ZS_MCOL], a_ll[ZS_MCOL], a_kl[ZS_MCOL];
-#pragma unroll
-      for (int j = 0; j < ZS_MCOL; ++j) { a_sse[j] = 0.0; a_ll[j] = 0.0; a_kl[j] = 0.0; }
-      // a last pass of at most 32 rows (K = 96: rows 64..95): the two columns share it, lanes 0..31 column 0, lanes 32..63
-      // column 1, and column 1's terms come down with v_permlane32_swap to the lanes whose accumulators they belong to —
-      // the same additions in the same order, without half the wave idling through a pass
-      const int KL = K - ((KR - 1) << 6);
-      const bool split = ZS_MCOL == 2 && KL <= 32;
-      for (int r = 0; r < KR - (split ? 1 : 0); ++r) {
-        const int kk = (r << 6) + lane;
-        if (kk < K) {
-          int m[ZS_MCOL];
-          double lgf[ZS_MCOL], lgm[ZS_MCOL], c[ZS_MCOL];
-#pragma unroll
-          for (int j = 0; j < ZS_MCOL; ++j) {
-            const int gl = min(gl0 + j, bk.ncols - 1);
-            m[j] = Ms[kk + (size_t)K * gl];
-            const int mi = m[j] < 0 ? 0 : (m[j] > d.maxM ? d.maxM : m[j]);
-            lgf[j] = d.lgfact[mi]; lgm[j] = d.logm[mi];
-            c[j] = 0.0;
-          }
-#pragma unroll
-          for (int n = 0; n < NC; ++n) if (n < NMIN || n < N) {
-            const double pkn = Pl[kk + (size_t)K * n];
-#pragma unroll
-            for (int j = 0; j < ZS_MCOL; ++j) c[j] = c[j] + pkn * ae[(size_t)n * GBc + min(gl0 + j, bk.ncols - 1)];
-          }
-#pragma unroll
-          for (int j = 0; j < ZS_MCOL; ++j) {
-            const double dd = c[j] - (double)m[j];
-            const double mh = c[j] < 1e-6 ? 1e-6 : c[j];
-            const double lmh = dlog(mh);
-            const double mt = m[j] < 1 ? 1e-6 : (double)m[j];
-            a_sse[j] = a_sse[j] + dd * dd;
-            a_ll[j] = a_ll[j] + (((double)m[j] * lmh - mh) - lgf[j]);
-            a_kl[j] = a_kl[j] + mt * (lgm[j] - lmh);
-          }
-        }
-      }
-      if (split) {
-        const int jc = lane >> 5, rl = lane & 31;
-        const int kk = ((KR - 1) << 6) + rl;
-        double tsse = 0.0, tll = 0.0, tkl = 0.0;
-        if (rl < KL) {
-          const int gl = min(gl0 + jc, bk.ncols - 1);
-          const int m = Ms[kk + (size_t)K * gl];
-          const int mi = m < 0 ? 0 : (m > d.maxM ? d.maxM : m);
-          const double lgf = d.lgfact[mi], lgm = d.logm[mi];
-          double c = 0.0;
-#pragma unroll
-          for (int n = 0; n < NC; ++n) if (n < NMIN || n < N) c = c + Pl[kk + (size_t)K * n] * ae[(size_t)n * GBc + gl];
-          const double dd = c - (double)m;
-          const double mh = c < 1e-6 ? 1e-6 : c;
-          const double lmh = dlog(mh);
-          const double mt = m < 1 ? 1e-6 : (double)m;
-          tsse = dd * dd;
-          tll = ((double)m * lmh - mh) - lgf;
-          tkl = mt * (lgm - lmh);
-        }
-        const double u0 = down32(tsse), u1 = down32(tll), u2 = down32(tkl);
-        if (lane < 32 && rl < KL) {
-          a_sse[0] = a_sse[0] + tsse; a_ll[0] = a_ll[0] + tll; a_kl[0] = a_kl[0] + tkl;
-          constexpr int J1 = ZS_MCOL > 1 ? 1 : 0;
-          if (ZS_MCOL > 1) { a_sse[J1] = a_sse[J1] + u0; a_ll[J1] = a_ll[J1] + u1; a_kl[J1] = a_kl[J1] + u2; }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < ZS_MCOL; ++j) {
-        const double r0 = wave_tree64(a_sse[j]), r1 = wave_tree64(a_ll[j]), r2 = wave_tree64(a_kl[j]);
-        if (lane == 0 && gl0 + j < bk.ncols) { const int g = colid[gl0 + j]; d.colsse[g] = r0; d.colll[g] = r1; d.colkl[g] = r2; }
-      }
-      ZSTOC(4);
-    } else {
+  // the item tasks in descending size: the block's tail is made of its smallest tasks (the last ones: the cells without counts, which
+  // are items too since round 5 — their lanes form Mhat and nothing else).  Round 5: no metric tasks.  The per-column metric terms
+  // (R/utils.R:412-455) need Mhat of every cell in the canonical W = 64 order over the rows; rounds 3-4 formed it a second time, lane = row
+  // (14 % of the kernel's wave time; without those dot products the iteration was 4.5 us shorter).  Now the lane of a cell's first item
+  // leaves the Mhat it has just formed in s.mh, and the terms are summed from there by colterms_pair (kernels.h): in idle slots of the
+  // next draw kernel, or by k_colterms.
+  for (int task = next_task(); task < ntot; task = next_task()) {
+    {
     // ---------------- item task: lane = item
     ZSTIC(1);
     uint32_t it;
@@ -233,6 +158,7 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
     const int m = Ms[k + (size_t)K * gl];
     const int g = colid[gl];
     int nq = 0, npad = 0;
+    bool any = false;
     uint32_t pv[NPV > 0 ? NPV : 1];
     {
       // Mhat = sum_n P[k,n] (A[n] E[n,g]) in factor order; thr_n = floor(cum_n 2^32 / Mhat) saturating at 2^32 - 1 = "never"
@@ -250,6 +176,9 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
         nq = min(s.qmax, qt - q0);
         npad = (q0 + nq == qt) ? ((4 - (m & 3)) & 3) : 0;
       }
+      if (valid && q0 == 0) s.mh[(size_t)k + (size_t)K * (size_t)g] = c;
+      any = __builtin_amdgcn_ballot_w64(nq > 0) != 0;      // a task of cells without counts: no thresholds, no draws
+      if (any) {
       const double scale = 4294967296.0 / c;
 #pragma unroll
       for (int j = 0; j < NBLK; ++j) {
@@ -262,6 +191,7 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
         }
         tblk[j * 64 + lane] = u4{tv[0], tv[1], tv[2], tv[3]};
         if (j < NPV) pv[j] = tv[4];
+      }
       }
     }
     const uint32_t celem = (uint32_t)k + (uint32_t)K * (uint32_t)g;
@@ -286,7 +216,7 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
     ZSTOC(1);
     ZSTIC(2);
     // full quads, then each lane's last quad (the only one that can hold pads)
-    for (int i = 0; __builtin_amdgcn_ballot_w64(i < nq - 1) != 0; ++i)
+    if (any) for (int i = 0; __builtin_amdgcn_ballot_w64(i < nq - 1) != 0; ++i)
       if (i < nq - 1) quad(q0 + i, 1u, 1u, 1u, 1u);
     if (nq > 0) quad(q0 + nq - 1, 1u, npad > 2 ? 0u : 1u, npad > 1 ? 0u : 1u, npad > 0 ? 0u : 1u);
     wave_lds_fence();

@@ -2,6 +2,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import bayesnmf_amd.engine as _E
+if os.environ.get('BNMF_TEST_LIB'): _E.LIB_PATH = os.path.abspath(os.environ['BNMF_TEST_LIB'])
 from bayesnmf_amd import Engine
 from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
 cfg = os.environ.get("CFG", "3")
