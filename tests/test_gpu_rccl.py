@@ -6,6 +6,7 @@ import subprocess
 import sys
 import textwrap
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -52,3 +53,26 @@ def test_run_rank_over_a_world_of_one_nccl_rank(tmp_path):
     """)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_two_ranks_rehearsal():
+    """SURVEY.md 8(e), VERDICT r4 item 8: `bench.py --gpus 2` must not run for the first time in a SCALE measurement.  A one-GPU box
+    cannot measure two GPUs, so BNMF_BENCH_REHEARSE=1 puts both ranks on GPU 0 and gathers over gloo: the launcher path (spawn_ranks),
+    the process group set-up with stdout kept clean, the barriers and the all-reduce(MAX) of the timed region, the gathers of the
+    chains' last rows and MAP statistics all execute.  Exactly ONE JSON line on stdout, marked as a rehearsal, two different chains."""
+    import json
+    env = dict(os.environ, BNMF_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-secondary",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and "REHEARSAL" in d
+    assert d["scaling"] == "weak" and d["config"]["chains"] == 2 and len(d["rep_values"]) == d["reps"]
+    lp = d["chains_final_logposterior"]
+    assert len(lp) == 2 and lp[0] != lp[1] and all(np.isfinite(lp))          # chain_id = rank: two different chains
+    assert d["collectives"]["world"] == 2 and len(d["collectives"]["gathered"]) == 2
+    assert d["value"] > 0 and abs(d["value"] - 2 * 20 / (d["ms_per_step"] * 1e-3 * 20)) / d["value"] < 1e-9
