@@ -12,13 +12,15 @@
 #include <cerrno>
 #include <algorithm>
 #include <map>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
-#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
 #include <fcntl.h>
 #include <sys/file.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include "kernels.h"
 #include "zalloc_reg.h"
@@ -108,7 +110,9 @@ struct bnmf_handle {
   hipEvent_t ev[2 * BNMF_NKERNEL]{};
   bool have_ev = false;
   double* dMap = nullptr; size_t map_words = 0;   // scratch of bnmf_map (grown on demand)
-  int devlock_fd = -1;                 // the device's lock file (/tmp/bnmf_dev_<PCI bus id>.lock): g_rank_turn's rule across the PROCESSES that share the device
+  int devlock_fd = -1;                 // the device's lock file (<BNMF_LOCKDIR or /tmp>/bnmf_dev_<PCI bus id>.lock): the device gate's rule across the PROCESSES that share the device
+  int devgate_fd = -1;                 // ... and its turnstile (.gate): a process that wants the device exclusively holds it while it waits, new sharers queue behind it
+  bool devlock_off = false;            // BNMF_DEVLOCK=0: the caller vouches that no other process uses the device
   unsigned char* dAsg = nullptr; size_t asg_bytes = 0;   // scratch of bnmf_assign (grown on demand): catalogue, norms, cosines, slot / signature lists
   unsigned* dFlags = nullptr;                     // [0] counter, [1] flag of the E-side hyper sweep; [2], [3] of P part + Esum; [5], [6] P inside k_draw;
                                                   // [8], [9] P-side sweep on its own stream
@@ -545,6 +549,7 @@ static int build_zstep(bnmf_handle* h, const int32_t* M, int n_cu) {
 static std::mutex g_stream_mtx;
 static std::vector<hipStream_t> g_stream_pool[64];
 static int take_stream(int device, hipStream_t* out) {
+  if (device < 0 || device >= 64) return fail(BNMF_EINVAL, "device ordinal %d out of range", device);
   {
     std::lock_guard<std::mutex> lock(g_stream_mtx);
     auto& v = g_stream_pool[device];
@@ -555,6 +560,7 @@ static int take_stream(int device, hipStream_t* out) {
 }
 static void give_stream(int device, hipStream_t st) {
   if (!st) return;
+  if (device < 0 || device >= 64) { hipStreamDestroy(st); return; }
   std::lock_guard<std::mutex> lock(g_stream_mtx);
   g_stream_pool[device].push_back(st);
 }
@@ -565,14 +571,30 @@ static void give_stream(int device, hipStream_t st) {
 struct CachedBuf { void* p; size_t bytes; };
 static std::mutex g_ring_mtx;
 static std::vector<CachedBuf> g_ring_cache[64];
-static size_t ring_cache_cap() { const char* e = getenv("BNMF_RING_CACHE_GB"); return (size_t)((e ? atof(e) : 32.0) * 1e9); }
+// What a destroyed handle leaves cached per device: its record_sample rings, for the next handle of the same shape (bayesNMF() after
+// bayesNMF(), a BIC sweep).  Round 5: 8 GB by default (it was 32: room for one ring set of the metric configuration, 6.5 GB,
+// not for several), dropped whenever a device allocation of the library fails (the allocation is then tried again), and bnmf_trim()
+// releases it — and the pooled streams — on request (the library usually shares its process with PyTorch / RCCL).
+static size_t ring_cache_cap() { const char* e = getenv("BNMF_RING_CACHE_GB"); return (size_t)((e ? atof(e) : 8.0) * 1e9); }
+static size_t ring_cache_drop(int device) {
+  std::vector<CachedBuf> drop;
+  { std::lock_guard<std::mutex> lock(g_ring_mtx); if (device >= 0 && device < 64) drop.swap(g_ring_cache[device]); }
+  size_t tot = 0;
+  for (const auto& c : drop) { hipFree(c.p); tot += c.bytes; }
+  return tot;
+}
 static int ring_alloc(int device, size_t bytes, double** out) {
+  if (device < 0 || device >= 64) return fail(BNMF_EINVAL, "device ordinal %d out of range", device);
   {
     std::lock_guard<std::mutex> lock(g_ring_mtx);
     auto& v = g_ring_cache[device];
     for (size_t i = v.size(); i-- > 0;) if (v[i].bytes == bytes) { *out = (double*)v[i].p; v.erase(v.begin() + (long)i); return 0; }
   }
-  HIPCHK(hipMalloc(out, bytes));
+  if (hipMalloc(out, bytes) != hipSuccess) {               // out of memory with rings of other shapes cached: give them back, try once more
+    (void)hipGetLastError();
+    ring_cache_drop(device);
+    HIPCHK(hipMalloc(out, bytes));
+  }
   return 0;
 }
 static void ring_release(int device, void* p, size_t bytes) {
@@ -592,6 +614,176 @@ static void ring_release(int device, void* p, size_t bytes) {
   }
   for (void* q : drop) hipFree(q);
 }
+// ---- who may use a device at the same time ----
+// A rank-learning call takes its device exclusively, every other bnmf_run shares it (why: run_impl).  Round 5: the
+// in-process gate is WRITER-PREFERRING — a std::shared_mutex of glibc admits new readers while a writer waits, so a rank-learning
+// chain beside chains that keep issuing overlapping calls could wait for ever.  Here a waiting exclusive caller closes the gate for
+// new sharers; those already inside finish their call (at most one block of iterations).
+struct DeviceGate {
+  std::mutex m; std::condition_variable cv;
+  int sharers = 0, waiting_excl = 0; bool excl = false;
+  unsigned long admitted_while_excl_waited = 0;           // must stay 0 (bnmf_test_gate)
+  void lock_shared() {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return !excl && waiting_excl == 0; });
+    if (waiting_excl) ++admitted_while_excl_waited;
+    ++sharers;
+  }
+  void unlock_shared() { std::lock_guard<std::mutex> lk(m); if (--sharers == 0) cv.notify_all(); }
+  void lock() {
+    std::unique_lock<std::mutex> lk(m);
+    ++waiting_excl;
+    cv.wait(lk, [&] { return !excl && sharers == 0; });
+    --waiting_excl; excl = true;
+  }
+  void unlock() { std::lock_guard<std::mutex> lk(m); excl = false; cv.notify_all(); }
+};
+static DeviceGate g_dev_gate[64];
+// The same rule between PROCESSES: two lock files per device.  <dir>/bnmf_dev_<bus>.lock is held shared / exclusive for the length of
+// a call; <dir>/bnmf_dev_<bus>.gate is the turnstile that makes it fair: an exclusive caller holds the gate exclusively from before
+// it asks for the lock until it has it, a sharer passes through the gate (shared, released at once) before it asks — so sharers
+// that arrive while an exclusive caller waits queue behind it (flock alone lets them overtake).
+// The files: an existing one is opened read-only (flock needs no write access; O_CREAT on a file of another user in a sticky /tmp is
+// refused under fs.protected_regular); a missing one is created and made world-accessible.  BNMF_LOCKDIR replaces /tmp (containers
+// that share a GPU but not /tmp).  Failure is said once on stderr and remembered in the handle (run_impl refuses rank learning then).
+static int open_lock_file(const char* path) {
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd >= 0) return fd;
+    if (errno != ENOENT) return -1;
+    fd = open(path, O_RDWR | O_CREAT | O_EXCL | O_CLOEXEC, 0666);
+    if (fd >= 0) { (void)fchmod(fd, 0666); return fd; }
+    if (errno != EEXIST) return -1;                        // (EEXIST: another process has just created it — open it)
+  }
+  return -1;
+}
+static void devlock_open(const char* bus, int* lock_fd, int* gate_fd) {
+  const char* dir = getenv("BNMF_LOCKDIR");
+  if (!dir || !*dir) dir = "/tmp";
+  char path[512];
+  snprintf(path, sizeof path, "%s/bnmf_dev_%s.lock", dir, bus);
+  *lock_fd = open_lock_file(path);
+  const int e1 = errno;
+  snprintf(path, sizeof path, "%s/bnmf_dev_%s.gate", dir, bus);
+  *gate_fd = *lock_fd >= 0 ? open_lock_file(path) : -1;
+  if (*lock_fd < 0 || *gate_fd < 0) {
+    static std::atomic<bool> said{false};
+    if (!said.exchange(true))
+      fprintf(stderr, "[bnmf] warning: cannot open the device lock files %s/bnmf_dev_%s.{lock,gate} (%s): chains of OTHER processes on this device are not "
+                      "kept apart from rank-learning chains; set BNMF_LOCKDIR to a directory all of them can write, or BNMF_DEVLOCK=0 if there are none\n",
+              dir, bus, strerror(*lock_fd < 0 ? e1 : errno));
+    if (*lock_fd >= 0) { close(*lock_fd); *lock_fd = -1; }
+  }
+}
+// host-only checks of the two mechanisms above (tests/test_abi_host.py; no GPU involved)
+extern "C" int bnmf_test_gate(int n_sharers, int calls_per_sharer, int hold_us, long* excl_wait_us, long* admitted_while_waiting) {
+  // sharers keep the gate busy with overlapping calls (a reader-preferring lock would never let the exclusive caller in before they
+  // stop); the exclusive caller asks once they are all running.  Reports how long it waited and how many sharers were admitted
+  // while it did (must be 0).
+  DeviceGate g;
+  std::atomic<int> running{0};
+  std::atomic<bool> stop{false};
+  std::vector<std::thread> th;
+  for (int i = 0; i < n_sharers; ++i)
+    th.emplace_back([&, i] {
+      for (int c = 0; c < calls_per_sharer && !stop.load(); ++c) {
+        g.lock_shared();
+        running.fetch_add(1);
+        std::this_thread::sleep_for(std::chrono::microseconds(hold_us + 37 * i));
+        g.unlock_shared();
+      }
+    });
+  while (running.load() < n_sharers) std::this_thread::yield();
+  const auto t0 = std::chrono::steady_clock::now();
+  g.lock();
+  const long waited = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+  stop.store(true);
+  g.unlock();
+  for (auto& t : th) t.join();
+  if (excl_wait_us) *excl_wait_us = waited;
+  if (admitted_while_waiting) *admitted_while_waiting = (long)g.admitted_while_excl_waited;
+  return 0;
+}
+extern "C" int bnmf_test_devlock(const char* bus_tag, int* lock_ok, int* gate_ok) {
+  int a = -1, b = -1;
+  devlock_open(bus_tag ? bus_tag : "test", &a, &b);
+  if (lock_ok) *lock_ok = a >= 0;
+  if (gate_ok) *gate_ok = b >= 0;
+  int rc = 0;
+  if (a >= 0 && b >= 0) {                                  // the turnstile order of run_impl, both kinds of caller
+    if (flock(b, LOCK_EX) || flock(a, LOCK_EX) || flock(b, LOCK_UN) || flock(a, LOCK_UN)) rc = -1;
+    if (flock(b, LOCK_SH) || flock(b, LOCK_UN) || flock(a, LOCK_SH) || flock(a, LOCK_UN)) rc = -1;
+  }
+  if (a >= 0) close(a);
+  if (b >= 0) close(b);
+  return rc;
+}
+
+// ---- can two kernels on two streams of this device run at the same time?  (once per device and process) ----
+// The steady-state sweeps hand results from the side streams to the main stream through words in memory that a lane of the
+// main-stream kernel polls (kernels.h side_wait, the allocation kernels' gate): that needs the polled-for kernel to be able to
+// START while the polling one is resident.  A runtime or tool that serialises dispatches (counter collection, AMD_SERIALIZE_KERNEL,
+// HIP_LAUNCH_BLOCKING, a debugger, ...) breaks it — whatever its name.  The probe: kernel A on one stream spins (bounded: 2 ms)
+// on a word that kernel B on another stream sets; A reports whether it saw the word.  Overlap -> flag polling; no overlap -> every
+// hand-off is a stream wait on an event (serial-safe mode).  BNMF_DEBUG_PROBE=serial|overlap (tests) replaces the measurement.
+__global__ void k_probe_wait(unsigned* word, unsigned* out, long long ticks_100mhz) {
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  unsigned seen = 0;
+  while (!(seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+    if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > ticks_100mhz) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  *out = seen ? 1u : 2u;
+}
+__global__ void k_probe_set(unsigned* word) { __hip_atomic_store(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static std::mutex g_probe_mtx;
+static int g_probe[64];   // 0 unknown, 1 overlap, 2 serial
+static int probe_overlap(int device, int* overlap) {
+  std::lock_guard<std::mutex> lk(g_probe_mtx);
+  if (const char* e = getenv("BNMF_DEBUG_PROBE")) {            // tests: the probe's outcome, not the mode (BNMF_SERIAL is the caller's switch)
+    if (!strcmp(e, "serial")) { *overlap = 0; return 0; }
+    if (!strcmp(e, "overlap")) { *overlap = 1; return 0; }
+  }
+  if (device < 0 || device >= 64) { *overlap = 0; return 0; }
+  if (!g_probe[device]) {
+    hipStream_t a = nullptr, b = nullptr;
+    if (int rc = take_stream(device, &a)) return rc;
+    if (int rc = take_stream(device, &b)) { give_stream(device, a); return rc; }
+    unsigned* w = nullptr;
+    HIPCHK(hipMalloc(&w, 2 * sizeof(unsigned)));
+    HIPCHK(hipMemset(w, 0, 2 * sizeof(unsigned)));
+    HIPCHK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, a, w, w + 1, 200000LL);   // 2 ms of the 100 MHz counter
+    hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, b, w);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(a));
+    HIPCHK(hipStreamSynchronize(b));
+    unsigned res[2] = {0, 0};
+    HIPCHK(hipMemcpy(res, w, sizeof res, hipMemcpyDeviceToHost));
+    hipFree(w);
+    give_stream(device, a); give_stream(device, b);
+    g_probe[device] = res[1] == 1u ? 1 : 2;
+    if (getenv("BNMF_TIMING")) fprintf(stderr, "[bnmf] device %d: kernels on two streams %s\n", device, g_probe[device] == 1 ? "overlap" : "do NOT overlap: serial-safe mode");
+  }
+  *overlap = g_probe[device] == 1;
+  return 0;
+}
+extern "C" int bnmf_trim(int device, size_t* bytes_released) {
+  if (device < 0 || device >= 64) return fail(BNMF_EINVAL, "bnmf_trim: device ordinal %d out of range", device);
+  HIPCHK(hipSetDevice(device));
+  const size_t b = ring_cache_drop(device);
+  std::vector<hipStream_t> st;
+  { std::lock_guard<std::mutex> lock(g_stream_mtx); st.swap(g_stream_pool[device]); }
+  for (hipStream_t q : st) hipStreamDestroy(q);
+  if (bytes_released) *bytes_released = b;
+  return 0;
+}
+extern "C" int bnmf_probe_overlap(int device, int* overlap) {
+  if (!overlap) return fail(BNMF_EINVAL, "bnmf_probe_overlap: null argument");
+  HIPCHK(hipSetDevice(device));
+  return probe_overlap(device, overlap);
+}
+
 static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h) {
   const size_t K = cfg->K, G = cfg->G, N = cfg->N;
   CreateClock clk;
@@ -600,13 +792,12 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   if (int rc = take_stream(h->device, &h->side2)) return rc;
   clk.mark("streams");
   // one open file description per handle: flock() then also separates the handles of ONE process (BNMF_DEVLOCK=0: no file lock)
-  if (!(getenv("BNMF_DEVLOCK") && atoi(getenv("BNMF_DEVLOCK")) == 0)) {
+  h->devlock_off = getenv("BNMF_DEVLOCK") && atoi(getenv("BNMF_DEVLOCK")) == 0;
+  if (!h->devlock_off) {
     char bus[64] = {0};
     if (hipDeviceGetPCIBusId(bus, (int)sizeof bus - 1, h->device) == hipSuccess) {
       for (char* c = bus; *c; ++c) if (!((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z'))) *c = '_';
-      char path[128];
-      snprintf(path, sizeof path, "/tmp/bnmf_dev_%s.lock", bus);
-      h->devlock_fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC, 0666);      // -1 (not ours to open, no /tmp): this process runs without it
+      devlock_open(bus, &h->devlock_fd, &h->devgate_fd);
     } else (void)hipGetLastError();
   }
   HIPCHK(hipEventCreateWithFlags(&h->ev_draw, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -639,9 +830,12 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
     // A lane that polls inside a main-stream kernel for a side-stream kernel deadlocks (until its bound) when dispatches cannot
     // overlap: the waited-for kernel only starts once the waiting one has ended.  Where the process is known to serialise its
     // dispatches, every hand-off is a stream wait on an event instead (the structure profile mode has always used).
-    auto on = [](const char* name) { const char* e = getenv(name); return e && *e && strcmp(e, "0") != 0; };
-    h->serial = on("AMD_SERIALIZE_KERNEL") || on("HIP_LAUNCH_BLOCKING") || on("ROCPROF_COUNTER_COLLECTION") || getenv("ROCPROF_COUNTERS") != nullptr;
-    if (const char* e = getenv("BNMF_SERIAL")) h->serial = atoi(e) != 0;
+    // Round 5: MEASURED, not guessed from the environment (rounds 3-4 looked for AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING and the
+    // profiler's variables; any other serialising tool ended in a time-out): probe_overlap runs a two-stream hand-off once per device.
+    int ov = 0;
+    if (int rc = probe_overlap(h->device, &ov)) return rc;
+    h->serial = ov == 0;
+    if (const char* e = getenv("BNMF_SERIAL")) h->serial = atoi(e) != 0;      // the caller's explicit choice
   }
   HIPCHK(hipMalloc(&h->dFlags, 64));
   HIPCHK(hipMemset(h->dFlags, 0, 64));
@@ -863,7 +1057,9 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
         if (getenv("BNMF_ZTDBG")) { HIPCHK(hipMalloc(&tg.dbg, 8 * sizeof(unsigned long long))); HIPCHK(hipMemset(tg.dbg, 0, 8 * sizeof(unsigned long long))); }   // diagnostics only
       }
     }
-    if (const char* e = getenv("BNMF_ABLATE")) h->z_ablate = atoi(e);       // diagnostics only
+#ifdef BNMF_DIAG   /* the builder's diagnostic builds only (tools/bin/, never libbnmf.so): phases of the allocation kernels switched off */
+    if (const char* e = getenv("BNMF_ABLATE")) h->z_ablate = atoi(e);
+#endif
     h->n_cu = prop.multiProcessorCount;
     if (!h->z_tile && !h->z_step && !h->z_ablate) if (int rc = build_zsort(h, M, prop.multiProcessorCount)) return rc;
   }
@@ -900,6 +1096,7 @@ int bnmf_destroy(bnmf_handle* h) {
   if (h->dMap) hipFree(h->dMap);
   if (h->dAsg) hipFree(h->dAsg);
   if (h->devlock_fd >= 0) close(h->devlock_fd);
+  if (h->devgate_fd >= 0) close(h->devgate_fd);
   if (h->dFlags) hipFree(h->dFlags); if (h->dDrawOwn) hipFree(h->dDrawOwn); if (h->dScal) hipFree(h->dScal); if (h->hErr) hipHostFree(h->hErr);
   give_stream(h->device, h->stream);                    // synchronised at the top of this function
   delete h;
@@ -1325,7 +1522,10 @@ template <bool SZ, int ZT_>
 static int launch_zalloc_t(bnmf_handle* h, uint32_t t) {
   if (h->z_tile) return (h->z_lean && ZT_ == 1024) ? launch_ztile<SZ, ZT_, (ZT_ == 1024)>(h, t) : launch_ztile<SZ, ZT_, false>(h, t);
   if (!h->z_reg) return launch_z(h, t, k_zalloc<SZ, ZT_>, h->dev, ZT_);
-  return h->z_ablate ? launch_zreg_t<SZ, ZT_, true>(h, t) : launch_zreg_t<SZ, ZT_, false>(h, t);   // DIAG build honours BNMF_ABLATE
+#ifdef BNMF_DIAG
+  if (h->z_ablate) return launch_zreg_t<SZ, ZT_, true>(h, t);   // the DIAG instantiation honours BNMF_ABLATE
+#endif
+  return launch_zreg_t<SZ, ZT_, false>(h, t);
 }
 template <int ZT_>
 static int launch_zsort_t(bnmf_handle* h, uint32_t t) {
@@ -1827,19 +2027,32 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
 // allocation kernel's gate, the draw kernels' polls) holds a CU the rank sweep's grid needs, while the rank sweep's resident
 // workgroups hold the registers the side-stream kernel needs — a cycle only the time-outs broke.  Rank-learning calls take the
 // device's lock exclusively, all other calls shared.
-static std::shared_mutex g_rank_turn[64];
+static int flock_retry(int fd, int op) { int rc; while ((rc = flock(fd, op)) != 0 && errno == EINTR) {} return rc; }
 static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, Timer& tm) {
-  std::unique_lock<std::shared_mutex> turn;
-  std::shared_lock<std::shared_mutex> beside;
-  if (h && h->device >= 0 && h->device < 64) {
-    if (h->cfg.learning_rank) turn = std::unique_lock<std::shared_mutex>(g_rank_turn[h->device]);
-    else beside = std::shared_lock<std::shared_mutex>(g_rank_turn[h->device]);
-  }
-  // ... and the same rule between the processes that share the device (each learns nothing of the others' launches): the device's
-  // lock file, exclusive / shared, for the length of the call (released when the call returns — or the process ends)
-  struct FileTurn { int fd; ~FileTurn() { if (fd >= 0) flock(fd, LOCK_UN); } } fturn{-1};
-  if (h && h->devlock_fd >= 0) { while (flock(h->devlock_fd, h->cfg.learning_rank ? LOCK_EX : LOCK_SH) != 0 && errno == EINTR) {} fturn.fd = h->devlock_fd; }
   if (!h) return fail(BNMF_EINVAL, "bnmf_run: null handle");
+  const bool excl = h->cfg.learning_rank != 0;
+  // The rule between the PROCESSES that share the device first (each learns nothing of the others' launches), then the one between the
+  // chains of this process — a call blocked on another process must not hold this process's gate.  Without the lock files a
+  // rank-learning call is refused (two such chains of two processes end in each other's time-outs) unless the caller has said
+  // BNMF_DEVLOCK=0: no other process uses the device.
+  struct FileTurn { int fd; ~FileTurn() { if (fd >= 0) flock(fd, LOCK_UN); } } fturn{-1};
+  if (!h->devlock_off) {
+    if (h->devlock_fd < 0 || h->devgate_fd < 0) {
+      if (excl) return fail(BNMF_ESTATE, "bnmf_run: a rank-learning chain needs its device to itself, and the device's lock files could not be opened "
+                                         "(see the warning at bnmf_create): set BNMF_LOCKDIR, or BNMF_DEVLOCK=0 if no other process uses this GPU");
+    } else {
+      int rc;
+      if (excl) { rc = flock_retry(h->devgate_fd, LOCK_EX); if (!rc) { rc = flock_retry(h->devlock_fd, LOCK_EX); flock(h->devgate_fd, LOCK_UN); } }
+      else { rc = flock_retry(h->devgate_fd, LOCK_SH); if (!rc) { flock(h->devgate_fd, LOCK_UN); rc = flock_retry(h->devlock_fd, LOCK_SH); } }
+      if (rc) return fail(BNMF_ESTATE, "bnmf_run: the device's lock file could not be taken (%s)", strerror(errno));
+      fturn.fd = h->devlock_fd;
+    }
+  }
+  struct GateTurn { DeviceGate* g; bool ex; ~GateTurn() { if (g) { if (ex) g->unlock(); else g->unlock_shared(); } } } gturn{nullptr, excl};
+  if (h->device >= 0 && h->device < 64) {
+    gturn.g = &g_dev_gate[h->device];
+    if (excl) gturn.g->lock(); else gturn.g->lock_shared();
+  }
   if (!h->inited) return fail(BNMF_ESTATE, "bnmf_run: call bnmf_init first");
   if (h->poisoned) return fail(BNMF_ESTATE, "bnmf_run: an earlier call timed out inside a kernel; the handle's state is invalid, destroy it");
   if (n_iter < 0) return fail(BNMF_EINVAL, "bnmf_run: n_iter < 0");

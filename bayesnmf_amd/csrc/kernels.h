@@ -613,6 +613,9 @@ constexpr int ZH = 68;             // pitch of the per-lane histogram rows (16-b
 // column in row order, so the results are bit-identical to the one-chunk mapping.
 template <bool SAVE_Z, int ZT>
 __global__ __launch_bounds__(ZT) void k_zalloc(Dev d, uint32_t t, ZGeom zg, int ablate) {
+#ifndef BNMF_DIAG
+  ablate = 0;                        // switching phases off is for the builder's diagnostic builds (-DBNMF_DIAG), never for libbnmf.so
+#endif
   constexpr int ZW = ZT / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -68,7 +68,7 @@ WHY = {0: None, 1: "no change", 2: "no best", 3: "max iters"}
 ABI_SYMBOLS = ["bnmf_create", "bnmf_destroy", "bnmf_set_array", "bnmf_get_array", "bnmf_get_array_i32",
                "bnmf_init", "bnmf_run", "bnmf_window", "bnmf_map", "bnmf_run_until", "bnmf_run_post_warmup", "bnmf_assign", "bnmf_get_iter", "bnmf_profile",
                "bnmf_kernel_name", "bnmf_ubench", "bnmf_test_math", "bnmf_test_sampler", "bnmf_test_philox", "bnmf_test_philox7",
-               "bnmf_device_info", "bnmf_device_count", "bnmf_last_error", "bnmf_version"]
+               "bnmf_device_info", "bnmf_device_count", "bnmf_last_error", "bnmf_version", "bnmf_probe_overlap", "bnmf_trim"]
 
 
 def lib():
@@ -105,6 +105,8 @@ def lib():
         L.bnmf_test_philox7.argtypes = [C.c_int, up, up, up]
         L.bnmf_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         L.bnmf_device_count.restype = C.c_int
+        L.bnmf_probe_overlap.argtypes = [C.c_int, C.POINTER(C.c_int)]
+        L.bnmf_trim.argtypes = [C.c_int, C.POINTER(C.c_size_t)]
         L.bnmf_last_error.restype = C.c_char_p
         L.bnmf_version.restype = C.c_int
         _LIB = L
@@ -129,6 +131,13 @@ def ubench(device=0):
     a, b = C.c_double(), C.c_double()
     _chk(lib().bnmf_ubench(device, C.byref(a), C.byref(b)))
     return a.value, b.value
+
+
+def trim(device=0):
+    """Release what destroyed handles left cached on the device (rings, streams); returns the bytes of device memory given back."""
+    b = C.c_size_t(0)
+    _chk(lib().bnmf_trim(device, C.byref(b)))
+    return b.value
 
 
 def device_info(device=0):

@@ -188,9 +188,24 @@ int bnmf_test_philox7(int device, const uint32_t ctr[4], const uint32_t key[2], 
  * phase time stamps of the rank sweep (BNMF_RANKDBG=1 at bnmf_create; returns the grid size), section ticks of the allocation
  * kernel (-DZSPROF / -DZPPROF builds only, else BNMF_ESTATE), and what a bounded in-kernel wait does when it gives up
  * (word 0: a draw kernel waiting for the hyper sweep, word 1: the rank sweep's exchange).  Not part of the drop-in boundary. */
+/* host-only checks (no GPU) of what keeps the chains that share a device apart (api.hip DeviceGate, devlock_open; tests/test_abi_host.py):
+ * the writer-preferring gate under overlapping sharers (how long the exclusive caller waited, sharers admitted while it did: 0), and the
+ * opening of the device's two lock files under BNMF_LOCKDIR (or /tmp) with the lock order of bnmf_run.  Not part of the drop-in boundary. */
+int bnmf_test_gate(int n_sharers, int calls_per_sharer, int hold_us, long* excl_wait_us, long* admitted_while_waiting);
+int bnmf_test_devlock(const char* bus_tag, int* lock_ok, int* gate_ok);
 int bnmf_debug_rank(bnmf_handle* h, unsigned long long* out, size_t n);
 int bnmf_debug_zsort(bnmf_handle* h, unsigned long long* out);
 int bnmf_debug_set_timeout(bnmf_handle* h, int word);
+
+/* Can two kernels on two streams of this device run at the same time?  Measured once per device and process by a two-stream
+ * hand-off (kernel A spins, bounded, on a word kernel B sets).  bnmf_create uses it to choose between flag polling inside the
+ * kernels (overlap) and stream waits on events ("serial-safe mode": counter collection, AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING
+ * and any other tool that serialises dispatches).  *overlap = 1 / 0. */
+int bnmf_probe_overlap(int device, int* overlap);
+
+/* What destroyed handles leave cached on a device for the next handle — their record_sample rings (up to BNMF_RING_CACHE_GB, default 8)
+ * and three HIP streams each — is released; bytes_released (may be NULL) = device memory given back. */
+int bnmf_trim(int device, size_t* bytes_released);
 
 int bnmf_device_info(int device, char* buf, size_t buflen);
 int bnmf_device_count(void);

@@ -216,10 +216,55 @@ def test_r_shim_binds_every_entry_point_of_the_header():
     # not bound: unit probes of the parity tests, the profiler hook, library-level queries R has no use for
     not_bound = {"bnmf_ubench", "bnmf_test_math", "bnmf_test_sampler", "bnmf_test_philox", "bnmf_test_philox7", "bnmf_profile", "bnmf_kernel_name", "bnmf_version",
                  "bnmf_device_count", "bnmf_last_error", "bnmf_get_array_i32", "bnmf_debug_rank", "bnmf_debug_zsort", "bnmf_debug_set_timeout", "bnmf_trim",
-                 "bnmf_probe_overlap"}
+                 "bnmf_probe_overlap", "bnmf_test_gate", "bnmf_test_devlock"}
     src, fns = _shim_functions()
     for name in sorted(declared - not_bound):
         b = "C_" + name
         assert b in fns, f"{name} has no .Call binding in r/bnmf_shim.c"
         assert re.search(r"\b%s\(" % name, fns[b][1]) or name == "bnmf_destroy", f"{b} does not call {name}"
     assert "bnmf_last_error()" in src                                       # errors surface as Rf_error(bnmf_last_error())
+
+
+# ---- who may use a device at the same time (api.hip DeviceGate, devlock_open): host-only, deterministic ----
+def _gate_lib():
+    import ctypes as C
+    from bayesnmf_amd.engine import lib
+    L = lib()
+    L.bnmf_test_gate.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    L.bnmf_test_devlock.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    return L
+
+
+def test_device_gate_lets_the_exclusive_caller_in_under_overlapping_sharers():
+    """Six sharers keep the gate busy with overlapping calls (each 2 ms, staggered: the gate never falls empty by itself for seconds).
+    A reader-preferring lock — glibc's std::shared_mutex, which rounds 3-4 used — would not admit the exclusive caller before they stop
+    (6 x 400 calls x 2 ms = 0.8 s each); the gate admits no sharer while it waits, so it is in after the calls that were running."""
+    import ctypes as C
+    L = _gate_lib()
+    waited, admitted = C.c_long(-1), C.c_long(-1)
+    assert L.bnmf_test_gate(6, 400, 2000, C.byref(waited), C.byref(admitted)) == 0
+    assert admitted.value == 0
+    assert 0 <= waited.value < 100_000, waited.value            # the running calls end within ~2.2 ms; 100 ms allows for a loaded host
+
+
+def test_device_lock_files(tmp_path, monkeypatch, capfd):
+    """The two lock files of a device: created world-accessible under BNMF_LOCKDIR, an existing read-only file of somebody else is
+    still good for flock (no O_CREAT on it), the lock order of bnmf_run works on them; a directory that cannot be written is said on
+    stderr, once, and reported (bnmf_run then refuses rank learning instead of running it unprotected)."""
+    import ctypes as C
+    import stat
+    L = _gate_lib()
+    ok1, ok2 = C.c_int(-1), C.c_int(-1)
+    monkeypatch.setenv("BNMF_LOCKDIR", str(tmp_path))
+    assert L.bnmf_test_devlock(b"0000_e5_00_0", C.byref(ok1), C.byref(ok2)) == 0 and ok1.value == 1 and ok2.value == 1
+    for ext in ("lock", "gate"):
+        f = tmp_path / f"bnmf_dev_0000_e5_00_0.{ext}"
+        assert f.exists() and stat.S_IMODE(f.stat().st_mode) == 0o666
+        os.chmod(f, 0o444)                                       # as another user's file under umask 022 looks to us
+    assert L.bnmf_test_devlock(b"0000_e5_00_0", C.byref(ok1), C.byref(ok2)) == 0 and ok1.value == 1 and ok2.value == 1
+    capfd.readouterr()
+    monkeypatch.setenv("BNMF_LOCKDIR", str(tmp_path / "no" / "such" / "dir"))
+    assert L.bnmf_test_devlock(b"0000_e5_00_0", C.byref(ok1), C.byref(ok2)) == 0 and ok1.value == 0 and ok2.value == 0
+    assert "cannot open the device lock files" in capfd.readouterr().err
+    L.bnmf_test_devlock(b"0000_e5_00_0", C.byref(ok1), C.byref(ok2))
+    assert "cannot open" not in capfd.readouterr().err           # said once per process

@@ -1,10 +1,13 @@
 """GPU parity tests proper: the HIP engine (through the C ABI) against the CPU oracle on the
 same seeded inputs.  Integers bit-exact; fp64 values bit-exact where the op sequences are
 identical (they are, by the stream spec) with a stated fallback tolerance."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 ULP_TOL = 0          # spec: identical op order + -ffp-contract=off on both sides => 0 ulp
 METRIC_RTOL = 1e-12  # written tolerance for the fp64-accumulated metrics rows
@@ -774,14 +777,17 @@ def test_reference_example_data_known_answer(rank, tmp_path):
 
 @pytest.mark.parametrize("model", ["gamma_gate", "gamma_small", "mh", "rank"])
 def test_serial_mode_bitexact(model, monkeypatch):
-    """BNMF_SERIAL=1 (chosen automatically under counter collection, AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING): no kernel
-    polls for a kernel of another stream, every hand-off is a stream wait on an event.  Same chain, bit for bit, as the oracle —
-    for the gated fixed-rank sweep (BNMF_GATE=1 forced: the gate must stay off), the small fixed-rank sweep, an MH model and
-    rank learning."""
+    """Serial-safe mode — what bnmf_create chooses when its probe (two kernels on two streams, api.hip probe_overlap) finds that
+    dispatches do not overlap (counter collection, AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING, any other serialising tool): no kernel
+    polls for a kernel of another stream, every hand-off is a stream wait on an event.  No environment variable of any runtime is set
+    here: BNMF_DEBUG_PROBE=serial replaces the probe's measurement by "no overlap".  Same chain, bit for bit, as the oracle — for the
+    gated fixed-rank sweep (BNMF_GATE=1 forced: the gate must stay off), the small fixed-rank sweep, an MH model and rank learning."""
     import oracle as O
     from bayesnmf_amd import Engine
     from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
-    monkeypatch.setenv("BNMF_SERIAL", "1")
+    for v in ("BNMF_SERIAL", "AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING", "ROCPROF_COUNTER_COLLECTION", "ROCPROF_COUNTERS"):
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setenv("BNMF_DEBUG_PROBE", "serial")
     kw, prior, N = {}, "gamma", 12
     if model == "gamma_gate":
         monkeypatch.setenv("BNMF_GATE", "1")
@@ -959,3 +965,75 @@ def test_every_side_stream_kernel_held_back(case, which, monkeypatch):
             for nm in ("P", "E"):
                 assert np.array_equal(o.get(nm).view(np.uint64), e.get(nm).view(np.uint64)), (case, nm, conv)
     e.close()
+
+
+def test_probe_finds_overlapping_dispatch_on_a_plain_box():
+    """The probe itself (api.hip probe_overlap): on a box without a serialising tool two kernels on two streams run at the same time;
+    with the debug hook the answer is the hook's."""
+    import ctypes as C
+    from bayesnmf_amd.engine import lib, _chk
+    L = lib()
+    L.bnmf_probe_overlap.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    ov = C.c_int(-1)
+    for v in ("BNMF_DEBUG_PROBE", "AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING"):
+        assert v not in os.environ
+    _chk(L.bnmf_probe_overlap(0, C.byref(ov)))
+    assert ov.value == 1
+    os.environ["BNMF_DEBUG_PROBE"] = "serial"
+    try:
+        _chk(L.bnmf_probe_overlap(0, C.byref(ov)))
+        assert ov.value == 0
+    finally:
+        del os.environ["BNMF_DEBUG_PROBE"]
+
+
+def test_probe_under_a_serialising_runtime_setting():
+    """... and under a setting that really serialises the dispatches (AMD_SERIALIZE_KERNEL=3, in a child process: the runtime reads it
+    when it starts) the probe says so — nothing in the library looks the variable up — and a gated chain runs in serial-safe mode,
+    bit-identical to the same chain of this process."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent(f"""
+        import sys, ctypes as C
+        sys.path.insert(0, {ROOT!r})
+        import numpy as np
+        from bayesnmf_amd.engine import lib, _chk
+        from bayesnmf_amd import Engine
+        from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+        L = lib(); L.bnmf_probe_overlap.argtypes = [C.c_int, C.POINTER(C.c_int)]
+        ov = C.c_int(-1); _chk(L.bnmf_probe_overlap(0, C.byref(ov)))
+        M, _, _ = synth_counts(96, 3000, 4, 78)
+        e = Engine(M, 20, prior="gamma", seed=5, window=3); apply_hyperprior_params(e, "gamma", M, 20); e.init()
+        m = e.run(12)
+        print("PROBE", ov.value, m[-1, 4].hex(), e.get("E").view(np.uint64).sum())
+    """)
+    outs = []
+    for extra in ({}, {"AMD_SERIALIZE_KERNEL": "3"}):
+        env = {k: v for k, v in os.environ.items() if k not in ("BNMF_SERIAL", "BNMF_DEBUG_PROBE")}
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("PROBE")][0].split())
+    assert outs[0][1] == "1" and outs[1][1] == "0", outs           # overlap on the plain run, none under AMD_SERIALIZE_KERNEL
+    assert outs[0][2:] == outs[1][2:], outs                        # the same chain either way
+
+
+def test_ablate_variable_is_not_read_by_the_product_library(monkeypatch):
+    """BNMF_ABLATE (phases of the allocation kernels switched off, for section timings) used to be read at run time by
+    libbnmf.so — a stray variable meant wrong sufficient statistics without a word.  It is compile-time only now (-DBNMF_DIAG builds of
+    the builder's tools): with the variable set the product library still allocates every count."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    monkeypatch.setenv("BNMF_ABLATE", "1")
+    for zsort in ("1", "0"):                                          # the sorted-schedule kernel and the register kernel behind it
+        monkeypatch.setenv("BNMF_ZSORT", zsort)
+        M, _, _ = synth_counts(96, 300, 4, 79)
+        o = O.Oracle(M, 8, prior="gamma", seed=9, nthreads=8)
+        e = Engine(M, 8, prior="gamma", seed=9)
+        for c in (o, e):
+            apply_hyperprior_params(c, "gamma", M, 8)
+        o.init(); e.init()
+        o.run(3); e.run(3)
+        assert np.array_equal(o.get("ZsumG").astype(np.int32), e.get("ZsumG")) and e.get("ZsumG").sum() == M.sum()
+        assert np.array_equal(o.get("ZsumK").astype(np.int32), e.get("ZsumK"))
+        e.close()
