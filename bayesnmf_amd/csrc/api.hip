@@ -99,6 +99,10 @@ struct bnmf_handle {
   bool z_sort = false, zs_pk = false; ZSGeom zsg{}; int zs_nblk = 0, zs_w = 0; size_t zs_lds = 0; int32_t* dZsM = nullptr;
   int zs_it16 = 0, zs_qmax = ZS_QMAX;   // 2-byte items; quads per item
   uint32_t* dZsRec = nullptr; int zx_cols = 0; size_t zx_lds = 0;   // save_Z on the sorted schedule: the items' records, k_zexpand's columns per pass and LDS bytes
+  // Round 5: Z of the sorted schedule is kept AS RECORDS (two 16-bit counts per word and item: 44 MB per iteration at the metric configuration
+  // against 77 MB of Z) and expanded when somebody reads it (bnmf_get_array, bnmf_window): k_zexpand left the loop.  With a window the
+  // records of iteration t live in slot (t - 1) % wcap of dZsRecRing (samples$Z); zs_eager (BNMF_ZEAGER=1, measurements): expand every iteration.
+  uint32_t* dZsRecRing = nullptr; size_t zs_recwords = 0; int z_expanded_iter = 0; bool zs_eager = false;
   uint32_t* dZsItems = nullptr; ZSBlock* dZsBlocks = nullptr; int* dZsCols = nullptr; unsigned long long* dZsProf = nullptr;
   double* dZsMh = nullptr;              // [G][K] Mhat left by k_zalloc_sort for the per-column metric terms (colterms.h)
   uint32_t ct_pending = 0;              // iteration whose column terms have not been summed yet (0: none)
@@ -148,6 +152,7 @@ static bool is_prior_param(int id) { return id >= BNMF_ALPHA_P && id <= BNMF_LAM
 static int cur_slot(const bnmf_handle* h) { return (h->iter > 0 ? h->iter : 1) & 1; }
 static bool is_pside(int id) { size_t dummy = 0; (void)dummy; return id == BNMF_P || id == BNMF_ALPHA_P || id == BNMF_BETA_P || id == BNMF_MU_P || id == BNMF_SIGMASQ_P || id == BNMF_LAMBDA_P; }
 
+static int ensure_Z(bnmf_handle* h);   // save_Z on the sorted schedule: Z of the current iteration expanded from its records, if it is not
 static int ensure(bnmf_handle* h, int id) {
   Arr& a = h->arr[id];
   if (a.d) return 0;
@@ -402,7 +407,9 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   HIPCHK(hipMemset(h->dZsMh, 0, 3 * K * G * sizeof(double)));
   if (c.save_Z) {
     const size_t hw = (N + 1) / 2;
-    HIPCHK(hipMalloc(&h->dZsRec, items.size() * hw * sizeof(uint32_t)));
+    h->zs_recwords = items.size() * hw;
+    HIPCHK(hipMalloc(&h->dZsRec, h->zs_recwords * sizeof(uint32_t)));
+    h->zs_eager = getenv("BNMF_ZEAGER") && atoi(getenv("BNMF_ZEAGER")) != 0;
     const size_t lds_max = 160 * 1024;
     h->zx_cols = std::max(1, std::min(GBc, zexpand_cols((int)K, (int)N, lds_max)));
     h->zx_lds = ((size_t)h->zx_cols * N * ((K + 1) / 2) * 4 + 15) & ~(size_t)15;
@@ -1088,7 +1095,7 @@ int bnmf_destroy(bnmf_handle* h) {
   if (h->dMhatZ) hipFree(h->dMhatZ);
   if (h->zpg.prof) hipFree(h->zpg.prof);
   if (h->dZpItems) hipFree(h->dZpItems); if (h->dZpWgs) hipFree(h->dZpWgs); if (h->dZpBatches) hipFree(h->dZpBatches); if (h->dZpSteps) hipFree(h->dZpSteps); if (h->dZpCols) hipFree(h->dZpCols);
-  if (h->dZsItems) hipFree(h->dZsItems); if (h->dZsBlocks) hipFree(h->dZsBlocks); if (h->dZsCols) hipFree(h->dZsCols); if (h->dZsProf) hipFree(h->dZsProf); if (h->dZsM) hipFree(h->dZsM); if (h->dZsRec) hipFree(h->dZsRec); if (h->dZsMh) hipFree(h->dZsMh);
+  if (h->dZsItems) hipFree(h->dZsItems); if (h->dZsBlocks) hipFree(h->dZsBlocks); if (h->dZsCols) hipFree(h->dZsCols); if (h->dZsProf) hipFree(h->dZsProf); if (h->dZsM) hipFree(h->dZsM); if (h->dZsRec) hipFree(h->dZsRec); if (h->dZsRecRing) hipFree(h->dZsRecRing); if (h->dZsMh) hipFree(h->dZsMh);
   if (h->dMhat) hipFree(h->dMhat); if (h->dAccPn) hipFree(h->dAccPn); if (h->dAccEpart) hipFree(h->dAccEpart); if (h->dNzE) hipFree(h->dNzE);
   if (h->dEt) hipFree(h->dEt); if (h->dMt) hipFree(h->dMt); if (h->zring) hipFree(h->zring);
   if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_rank) hipEventDestroy(h->ev_rank); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); give_stream(h->device, h->side); give_stream(h->device, h->side2);
@@ -1125,6 +1132,7 @@ int bnmf_set_array(bnmf_handle* h, int id, const double* x, size_t n) {
     std::vector<int32_t> tmp(n);
     for (size_t i = 0; i < n; ++i) tmp[i] = (int32_t)x[i];
     HIPCHK(hipMemcpy(dst, tmp.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (id == BNMF_Z) h->z_expanded_iter = h->iter;        // (what the caller stored is what a read returns until the next sweep)
     return 0;
   }
   Arr& a = h->arr[id];
@@ -1172,6 +1180,7 @@ int bnmf_get_array(bnmf_handle* h, int id, double* out, size_t n) {
   if (id == BNMF_ZSUMK || id == BNMF_ZSUMG || id == BNMF_Z) {
     const int32_t* src = id == BNMF_ZSUMK ? h->dZsumK : id == BNMF_ZSUMG ? h->dZsumG : h->dZ;
     if (!src) return fail(BNMF_EUNSET, "bnmf_get_array: Z is not materialised (save_Z = 0)");
+    if (id == BNMF_Z) if (int rc = ensure_Z(h)) return rc;
     std::vector<int32_t> tmp(n);
     HIPCHK(hipMemcpy(tmp.data(), src, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n; ++i) out[i] = tmp[i];
@@ -1193,6 +1202,7 @@ int bnmf_get_array_i32(bnmf_handle* h, int id, int32_t* out, size_t n) {
   if (n != len) return fail(BNMF_ESIZE, "bnmf_get_array_i32: id %d expects %zu values, got %zu", id, len, n);
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (id == BNMF_Z) if (int rc = ensure_Z(h)) return rc;
   HIPCHK(hipMemcpy(out, src, n * sizeof(int32_t), hipMemcpyDeviceToHost));
   return 0;
 }
@@ -1226,6 +1236,16 @@ int bnmf_debug_set_timeout(bnmf_handle* h, int word) {   // tests: what a bounde
   if (!h || word < 0 || word > 1) return fail(BNMF_EINVAL, "bnmf_debug_set_timeout: bad argument");
   ((volatile int*)h->hErr)[word] = 2;
   return 0;
+}
+int bnmf_get_stat(bnmf_handle* h, int what, double* out) {   // sizes of the schedule's buffers, for bench.py's byte counts
+  if (!h || !out) return fail(BNMF_EINVAL, "bnmf_get_stat: null argument");
+  switch (what) {
+    case 0: *out = (double)h->zs_recwords * 4.0; return 0;                                  // bytes of item records per iteration (save_Z, sorted schedule; else 0)
+    case 1: *out = h->dZsMh ? (double)h->cfg.K * h->cfg.G * 8.0 : 0.0; return 0;            // bytes of Mhat left per iteration for the column terms
+    case 2: *out = h->dZsRecRing ? 1.0 : 0.0; return 0;                                     // samples$Z kept as a ring of records
+    case 3: *out = h->zs_eager ? 1.0 : 0.0; return 0;
+    default: return fail(BNMF_EINVAL, "bnmf_get_stat: unknown statistic %d", what);
+  }
 }
 int bnmf_get_iter(bnmf_handle* h, int* iter) { if (!h || !iter) return fail(BNMF_EINVAL, "null"); *iter = h->iter; return 0; }
 
@@ -1527,9 +1547,28 @@ static int launch_zalloc_t(bnmf_handle* h, uint32_t t) {
 #endif
   return launch_zreg_t<SZ, ZT_, false>(h, t);
 }
+// where the item records of iteration t go (save_Z on the sorted schedule): the sample's slot of the record ring, or the one buffer
+static uint32_t* zs_rec_at(const bnmf_handle* h, uint32_t t) {
+  if (!h->dZsRec) return nullptr;
+  return h->dZsRecRing ? h->dZsRecRing + (size_t)((t - 1) % (uint32_t)h->wcap) * h->zs_recwords : h->dZsRec;
+}
+// Z[k, n, g] of iteration t from its records into h->dZ (main stream)
+static void launch_zexpand(bnmf_handle* h, uint32_t t) {
+  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->zs_it16, h->zs_qmax, zs_rec_at(h, t), nullptr, h->dZsProf};
+  hipLaunchKernelGGL(k_zexpand, dim3(h->zsg.nblocks), dim3(ZX_T), h->zx_lds, h->stream, sa, h->zx_cols);
+  h->z_expanded_iter = (int)t;
+}
+static int ensure_Z(bnmf_handle* h) {
+  if (!h->z_sort || !h->dZsRec || !h->cfg.save_Z || h->iter < 1 || h->z_expanded_iter == h->iter) return 0;
+  HIPCHK(hipSetDevice(h->device));
+  launch_zexpand(h, (uint32_t)h->iter);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
 template <int ZT_>
 static int launch_zsort_t(bnmf_handle* h, uint32_t t) {
-  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->zs_it16, h->zs_qmax, h->dZsRec, h->dZsMh + (size_t)(t % 3u) * h->cfg.K * h->cfg.G, h->dZsProf};
+  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->zs_it16, h->zs_qmax, zs_rec_at(h, t), h->dZsMh + (size_t)(t % 3u) * h->cfg.K * h->cfg.G, h->dZsProf};
   auto go = [&](auto kern) -> int {
     if (h->z_attr_kernel != (const void*)kern) {
       HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1587,10 +1626,8 @@ static int launch_zstep(bnmf_handle* h, uint32_t t) {
 static int launch_zalloc(bnmf_handle* h, uint32_t t) {
   if (h->z_sort) {
     if (int rc = launch_zsort(h, t)) return rc;
-    if (h->cfg.save_Z) {                                   // the items' records -> the columns of Z (zalloc_sort.h k_zexpand)
-      const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->zs_it16, h->zs_qmax, h->dZsRec, h->dZsMh + (size_t)(t % 3u) * h->cfg.K * h->cfg.G, h->dZsProf};
-      hipLaunchKernelGGL(k_zexpand, dim3(h->zsg.nblocks), dim3(ZX_T), h->zx_lds, h->stream, sa, h->zx_cols);
-    }
+    // save_Z: the items' records ARE the sample (zs_rec_at); Z is expanded from them when it is read (ensure_Z, bnmf_window)
+    if (h->cfg.save_Z && h->zs_eager) launch_zexpand(h, t);
     return 0;
   }
   if (h->z_step) return launch_zstep(h, t);
@@ -1641,7 +1678,13 @@ static int ensure_rings(bnmf_handle* h) {
     Arr& a = h->arr[id];
     if (!a.ring) if (int rc = ring_alloc(h->device, (size_t)h->wcap * id_len(h, id) * sizeof(double), &a.ring)) return rc;
   }
-  if (h->dZ && !h->zring) {                                // samples$Z (R/bayesNMF_sampler.R:245-252): K*N*G ints per kept sample
+  if (h->dZ && h->z_sort && h->dZsRec) {                   // samples$Z on the sorted schedule: a ring of item records (zs_rec_at)
+    if (!h->dZsRecRing) {
+      const double gb = (double)h->wcap * (double)h->zs_recwords * 4.0 / 1e9;
+      const char* e = getenv("BNMF_ZRING_GB");
+      if (gb <= (e ? atof(e) : 32.0)) HIPCHK(hipMalloc(&h->dZsRecRing, (size_t)h->wcap * h->zs_recwords * sizeof(uint32_t)));
+    }
+  } else if (h->dZ && !h->zring) {                         // samples$Z (R/bayesNMF_sampler.R:245-252): K*N*G ints per kept sample
     const double gb = (double)h->wcap * (double)id_len(h, BNMF_Z) * 4.0 / 1e9;
     const char* e = getenv("BNMF_ZRING_GB");
     if (gb <= (e ? atof(e) : 32.0)) HIPCHK(hipMalloc(&h->zring, (size_t)h->wcap * id_len(h, BNMF_Z) * sizeof(int32_t)));
@@ -1649,7 +1692,7 @@ static int ensure_rings(bnmf_handle* h) {
   return 0;
 }
 static void record_Z(bnmf_handle* h, uint32_t t) {
-  if (!h->zring) return;
+  if (!h->zring) return;                                   // (sorted schedule: the allocation kernel wrote the sample's records into its ring slot)
   const size_t len = id_len(h, BNMF_Z);
   hipMemcpyAsync(h->zring + (size_t)((t - 1) % (uint32_t)h->wcap) * len, h->dZ, len * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream);
 }
@@ -1898,8 +1941,11 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   dbg_delay_main(h);
   tm.begin(KN_ZALLOC, h->stream);
   if (int rc = launch_zalloc(h, t)) return rc;
-  if (h->z_sort) { h->ct_pending = t; if (tm.on) flush_colterms(h); }   // (profile mode: the terms' own launch is timed with the allocation kernel)
   tm.end(KN_ZALLOC, h->stream);
+  if (h->z_sort) {
+    h->ct_pending = t;
+    if (tm.on) { tm.begin(KN_OTHER, h->stream); flush_colterms(h); tm.end(KN_OTHER, h->stream); }   // profile mode: the column terms as a launch of their own ("other")
+  }
   h->z_gated_for = h->z_gate_next; h->z_gate_next = 0;
   record_Z(h, t);
   launch_reduce(h, t, row, tm, h->cfg.learning_rank != 0);
@@ -1926,7 +1972,7 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
     HIPCHK(hipMemset(h->dZsumK, 0, (size_t)h->cfg.N * h->cfg.G * sizeof(int32_t)));
     HIPCHK(hipMemset(h->dZsumG, 0, (size_t)h->cfg.K * h->cfg.N * sizeof(int32_t)));
     h->side_valid = false; h->side_main = false; h->flags_valid = false; h->z_gate_next = 0; h->z_gated_for = 0; h->gate_f0 = 1;
-    h->side_ev_stale = false; h->red_on_side2 = false; h->red_pending = false; h->red_issued = false; h->mh_prep_valid = false; h->ct_pending = 0;
+    h->side_ev_stale = false; h->red_on_side2 = false; h->red_pending = false; h->red_issued = false; h->mh_prep_valid = false; h->ct_pending = 0; h->z_expanded_iter = 0;
     h->inited = false;
   }
   const bnmf_config& c = h->cfg;
@@ -2133,13 +2179,19 @@ int bnmf_window(bnmf_handle* h, int id, int last_n, double* out) {
   if (last_n < 1 || last_n > W || last_n > h->iter) return fail(BNMF_ESIZE, "bnmf_window: last_n = %d but only min(window = %d, iter = %d) samples are kept", last_n, W, h->iter);
   if (id < 0 || id >= BNMF_ID_MAX) return fail(BNMF_EINVAL, "bnmf_window: unknown id %d", id);
   if (id == BNMF_Z) {
-    if (!h->zring) return fail(BNMF_EUNSET, "bnmf_window: Z is not kept per sample (needs save_Z, a window, and window * K*N*G * 4 B within BNMF_ZRING_GB)");
+    if (!h->zring && !h->dZsRecRing) return fail(BNMF_EUNSET, "bnmf_window: Z is not kept per sample (needs save_Z, a window, and the window's samples within BNMF_ZRING_GB)");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     const size_t lenz = id_len(h, BNMF_Z);
     std::vector<int32_t> tmp(lenz);
     for (int i = 0; i < last_n; ++i) {
       const size_t slot = (size_t)(h->iter - last_n + i) % (size_t)h->wcap;
+      if (h->dZsRecRing) {                                   // sorted schedule: the sample is its item records; expand them (k_zexpand) and copy
+        launch_zexpand(h, (uint32_t)(h->iter - last_n + i + 1));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(tmp.data(), h->dZ, lenz * sizeof(int32_t), hipMemcpyDeviceToHost));
+      } else
       HIPCHK(hipMemcpy(tmp.data(), h->zring + slot * lenz, lenz * sizeof(int32_t), hipMemcpyDeviceToHost));
       for (size_t j = 0; j < lenz; ++j) out[(size_t)i * lenz + j] = tmp[j];
     }

@@ -68,7 +68,7 @@ WHY = {0: None, 1: "no change", 2: "no best", 3: "max iters"}
 ABI_SYMBOLS = ["bnmf_create", "bnmf_destroy", "bnmf_set_array", "bnmf_get_array", "bnmf_get_array_i32",
                "bnmf_init", "bnmf_run", "bnmf_window", "bnmf_map", "bnmf_run_until", "bnmf_run_post_warmup", "bnmf_assign", "bnmf_get_iter", "bnmf_profile",
                "bnmf_kernel_name", "bnmf_ubench", "bnmf_test_math", "bnmf_test_sampler", "bnmf_test_philox", "bnmf_test_philox7",
-               "bnmf_device_info", "bnmf_device_count", "bnmf_last_error", "bnmf_version", "bnmf_probe_overlap", "bnmf_trim"]
+               "bnmf_device_info", "bnmf_device_count", "bnmf_last_error", "bnmf_version", "bnmf_probe_overlap", "bnmf_trim", "bnmf_get_stat"]
 
 
 def lib():
@@ -107,6 +107,7 @@ def lib():
         L.bnmf_device_count.restype = C.c_int
         L.bnmf_probe_overlap.argtypes = [C.c_int, C.POINTER(C.c_int)]
         L.bnmf_trim.argtypes = [C.c_int, C.POINTER(C.c_size_t)]
+        L.bnmf_get_stat.argtypes = [C.c_void_p, C.c_int, dp]
         L.bnmf_last_error.restype = C.c_char_p
         L.bnmf_version.restype = C.c_int
         _LIB = L
@@ -320,6 +321,12 @@ class Engine:
                     P_lower=f(Pl, (K, N)), P_upper=f(Pu, (K, N)), E_lower=f(El, (N, G)), E_upper=f(Eu, (N, G)),
                     top_A=top.reshape(5, N)[:npat], top_counts=[int(c) for c in info.top_counts][:npat],
                     n_used=info.n_used, n_patterns=info.n_patterns, rmse=info.rmse, kl=info.kl)
+
+    def stat(self, what):
+        """Sizes of the handle's per-iteration buffers (bnmf_get_stat)."""
+        v = C.c_double()
+        _chk(lib().bnmf_get_stat(self._h, int(what), C.byref(v)))
+        return v.value
 
     @property
     def iter(self):

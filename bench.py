@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 K_, G_, N_, R_TRUE, DATA_SEED = 96, 10000, 20, 8, 20250218
 MAP_OVER = 1000                # new_convergence_control() default: depth of the record_sample ring
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_TAG = "r04"                         # profiles/<tag>_pmc_*.json: the committed counter passes the roofline quotes (falls back to r03)
+PROFILE_TAG = "r05"                         # profiles/<tag>_pmc_*.json: the committed counter passes the roofline quotes (falls back to r03)
 
 
 def z_bytes(K, G, N, save_Z):
@@ -116,8 +116,56 @@ def roofline_of(chain, K, G, N, save_Z, total_counts, n_iter, kernel=None, devic
                           "valu_busy_source": f"{busy_src} (committed SQ counters, not collected in this run)" if busy_src else None,
                           "note": "peak = Philox4x32-7 (the generator of the count-allocation words) alone at 8 waves/SIMD, measured on this box (bnmf_ubench); the kernel also "
                                   "searches 19 thresholds and updates two tables per word"},
-                  "note": "stats mode moves 6.3 MB per 40 M categorical draws: the kernel is VALU/Philox-bound, not HBM-bound (DESIGN.md 5)"
+                  "column_terms_launch_ms": prof.get("other"),
+                  "note": "stats mode moves 6.3 MB per 40 M categorical draws: the kernel is VALU/Philox-bound, not HBM-bound (DESIGN.md 5); since round 5 it leaves "
+                          "Mhat (8KG bytes, not credited) for the per-column metric terms, which are summed beside the next allocation kernel (in this serialised "
+                          "profile pass: a launch of their own, column_terms_launch_ms)"
                           if not save_Z else "full mode: Z (K x N x G int32) written every iteration: k_zalloc_sort leaves one packed record per item, k_zexpand turns the records of a column slab into Z with 16-byte stores (both in avg_launch_ms)"}
+
+
+def full_mode(M, total_counts, args, device):
+    """Full mode (save_Z: samples$Z, R/bayesNMF_sampler.R:245-252) AS A THROUGHPUT, same protocol as the headline (median of repetitions of
+    --steps iterations, a metrics row every iteration, record_sample on — here into a 100-deep window: 1000 samples of Z do not fit any budget).
+    Two forms, both reported:
+      records       what the library does: the allocation kernel writes every sample of Z as its item records (two 16-bit counts per word
+                    and item; `record_bytes` per iteration) into the sample's slot of a ring; Z[k,n,g] itself is expanded from the records when
+                    it is read (bnmf_get_array / bnmf_window: `expand_ms` per sample).  Bytes credited: the stats-mode bytes + the records.
+      materialised  BNMF_ZEAGER=1: k_zexpand runs every iteration and Z (K x N x G int32) is written every iteration — the form SURVEY 8(d)'s
+                    B_full = B_stats + 4KNG describes; frac = B_full x rate / 8 TB/s."""
+    import torch
+    K, G = M.shape
+    steps = max(args.steps, 200)
+    res = {}
+    for name, eager in (("records", False), ("materialised", True)):
+        if eager:
+            os.environ["BNMF_ZEAGER"] = "1"
+        try:
+            c = make_chain(M, N_, seed=1, chain_id=0, device=device, save_Z=True, window=100)
+        finally:
+            os.environ.pop("BNMF_ZEAGER", None)
+        c.run(300, metrics=False)
+        vals = []
+        for _ in range(5):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); c.run(steps, metrics=True); torch.cuda.synchronize()
+            vals.append(steps / (time.perf_counter() - t0))
+        rate = float(np.median(vals))
+        rec_bytes = c.stat(0)
+        t0 = time.perf_counter(); z = c.get("Z"); t_get = time.perf_counter() - t0
+        assert (z.sum(axis=1) == M).all()                        # every count of the last iteration is in Z
+        b_stats = z_bytes(K, G, N_, False)
+        nbytes = b_stats + (4 * K * N_ * G if eager else rec_bytes)
+        res[name] = {"value": rate, "unit": "Gibbs iterations/s", "steps": steps, "rep_values": vals, "record_bytes_per_iteration": rec_bytes,
+                     "samples_Z_kept": "ring of records (window 100)" if c.stat(2) else "last iteration only",
+                     "roofline": {"bound": "hbm", "kernel": "k_zalloc_sort (records)" + (" + k_zexpand (records -> Z) every iteration" if eager else ""),
+                                  "algorithmic_bytes_per_iteration": nbytes, "achieved": nbytes * rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": nbytes * rate / 1e9 / HBM_PEAK_GBS},
+                     "get_Z_ms": 1e3 * t_get}
+        prof = c.profile(60)
+        res[name]["kernel_ms"] = prof
+        c.close()
+    res["note"] = ("samples$Z is kept as item records and expanded on read; 'materialised' writes Z every iteration (the expansion cannot share a CU with "
+                   "the allocation or the draw kernel: its slab is 150 KB of LDS, theirs 153 / 45 KB with 14 of 16 wave slots — DESIGN.md 5)")
+    return res
 
 
 def make_chain(M, N, seed, chain_id, device, save_Z=False, window=MAP_OVER, prior="gamma", **kw):
@@ -383,11 +431,9 @@ def main():
             "kernel_ms": prof,
         }
         if world == 1 and not args.save_z:
-            # the same kernel in full mode (Z materialised): the only mode in which HBM traffic is substantial
-            cz = make_chain(M, N_, seed=1, chain_id=0, device=local_rank, save_Z=True, window=0)
-            cz.run(50, metrics=False)
-            _, out["roofline_save_Z"] = roofline_of(cz, K_, args.G, N_, True, total_counts, 100, device=local_rank)
-            cz.close()
+            out["full_mode"] = full_mode(M, total_counts, args, local_rank)
+            out["value_save_Z"] = out["full_mode"]["records"]["value"]
+            out["roofline_save_Z"] = out["full_mode"]["materialised"]["roofline"]
         if gathered is not None:
             out["chains_final_logposterior"] = [float(g[0][4]) for g in gathered]
             out["collectives"] = {"backend": "gloo" if rehearse else "nccl (RCCL)", "world": world, "forced_on_one_rank": bool(args.force_dist and world == 1),

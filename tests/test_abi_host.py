@@ -216,7 +216,7 @@ def test_r_shim_binds_every_entry_point_of_the_header():
     # not bound: unit probes of the parity tests, the profiler hook, library-level queries R has no use for
     not_bound = {"bnmf_ubench", "bnmf_test_math", "bnmf_test_sampler", "bnmf_test_philox", "bnmf_test_philox7", "bnmf_profile", "bnmf_kernel_name", "bnmf_version",
                  "bnmf_device_count", "bnmf_last_error", "bnmf_get_array_i32", "bnmf_debug_rank", "bnmf_debug_zsort", "bnmf_debug_set_timeout", "bnmf_trim",
-                 "bnmf_probe_overlap", "bnmf_test_gate", "bnmf_test_devlock"}
+                 "bnmf_probe_overlap", "bnmf_test_gate", "bnmf_test_devlock", "bnmf_get_stat"}
     src, fns = _shim_functions()
     for name in sorted(declared - not_bound):
         b = "C_" + name
