@@ -1415,8 +1415,12 @@ static void launch_side_E(bnmf_handle* h, uint32_t t, Timer& tm, bool e_done = f
   // ... and, in the same launch, the log-prior of the E just drawn (k_lpe's work; iteration t-1, whose slot pointers h->dev
   // still holds): off the critical path
   dbg_delay(h, h->side2);
-  hipLaunchKernelGGL(k_side_lp, dim3(h->cfg.N + h->nblkE), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)(h->cfg.N + h->nblkE), t},
-                     SideExtra{h->cfg.N, 0, h->nblkE, t - 1, lpe_src(h, t - 1), 1}, CtArgs{});
+  // (the per-column metric terms of the iteration before ride along as in launch_side_merged: workgroups behind the log-prior ones)
+  CtArgs ct{};
+  int n_ct = 0;
+  if (h->ct_pending) { ct = ct_args(h, h->ct_pending); n_ct = (h->cfg.G + 2 * (RT / 64) - 1) / (2 * (RT / 64)); h->ct_pending = 0; }
+  hipLaunchKernelGGL(k_side_lp, dim3(h->cfg.N + h->nblkE + n_ct), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)(h->cfg.N + h->nblkE), t},
+                     SideExtra{h->cfg.N, 0, h->nblkE, t - 1, lpe_src(h, t - 1), 1}, ct);
   // k_reduce of the PREVIOUS iteration here, behind the kernels that produce its inputs on this stream (k_lpp, k_lpe) and
   // behind ev_draw (k_zalloc of that iteration): on the E part's stream it sat in front of the next E-side sweep, and the
   // P part waited for its event
@@ -1916,7 +1920,7 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
     // [9], which k_pdraw does not poll ([1] was raised by k_draw, [3] covers side2 only): the main stream waits for it here, and
     // with it launch_side_P below (released by k_pdraw's stop event) cannot overwrite the slot that sweep still reads.
     if (poll && h->gate_f0 == 9) { hipEventRecord(h->ev_side, h->side); hipStreamWaitEvent(h->stream, h->ev_side, 0); }
-    flush_colterms(h);                                     // (the column terms of t - 1: no draw kernel to take them along)
+    if (h->cfg.learning_rank) flush_colterms(h);           // (fixed rank: launch_side_E below takes the column terms of t - 1 along)
     // completion events ride on the dispatches themselves (stop events): no marker packets on the main stream
     hipExtLaunchKernelGGL(k_pdraw, dim3(h->cfg.N), dim3(PD_T), (uint32_t)(2 * (size_t)h->cfg.K * sizeof(double)), h->stream,
                           nullptr, h->ev_p, 0, h->dev, t, 0, 0, rec_pdraw(h, t, rec),
@@ -2122,8 +2126,14 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
   if (runclock) rc_issued = rc_us();
   const bool reduces_on_side2 = h->red_on_side2;          // fixed-rank sweep: every earlier k_reduce sits on side2, which flush_reduce's wait covers
   flush_colterms(h);                                       // the last iteration's column terms: no draw kernel behind it in this call
+  // Round 5: the main stream waits for EVERYTHING issued on the two side streams (a fresh event each) in front of the last reduction:
+  // when it is idle so are they, and the two host-side synchronisations of idle streams that stood below (6 us each, at the end of
+  // every call) are gone.  (flush_reduce's own wait for side2 is then a wait for an event that has fired.)
+  hipEventRecord(h->ev_z, h->side); hipStreamWaitEvent(h->stream, h->ev_z, 0);
+  hipEventRecord(h->ev_sideP, h->side2); hipStreamWaitEvent(h->stream, h->ev_sideP, 0);
+  if (h->side_ev_stale) { hipStreamWaitEvent(h->side, h->ev_sideP, 0); hipEventRecord(h->ev_side, h->side); h->side_ev_stale = false; }   // (what refresh_side_events would record)
   flush_reduce(h, tm);
-  if (!reduces_on_side2) { hipEventRecord(h->ev_z, h->side); hipStreamWaitEvent(h->stream, h->ev_z, 0); }   // the k_reduce launches on `side` are done
+  (void)reduces_on_side2;
   hipLaunchKernelGGL(k_compose, dim3((n_iter + 63) / 64), dim3(64), 0, h->stream, h->dev, n_iter, t0);
   HIPCHK(hipGetLastError());
   std::vector<double> own;
@@ -2132,8 +2142,7 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
   HIPCHK(hipStreamSynchronize(h->stream));
   if (runclock) rc_main = rc_us();
   if (metrics) memcpy(metrics, h->hMetrics, (size_t)n_iter * BNMF_NMETRIC * sizeof(double));
-  HIPCHK(hipStreamSynchronize(h->side));                    // (6 us of host time each on an idle stream; hipStreamQuery costs the same)
-  HIPCHK(hipStreamSynchronize(h->side2));
+
   if (runclock) fprintf(stderr, "[bnmf_run %d] first iteration issued %.1f us, all issued %.1f, tail issued %.1f, main stream idle %.1f, side streams idle %.1f\n",
                         n_iter, rc_first, rc_issued, rc_tail, rc_main, rc_us());
   if (h->wcap > 0 && metrics) {                             // loglik / logpost of the recorded iterations (MAP metrics are window means)

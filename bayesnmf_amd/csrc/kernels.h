@@ -191,11 +191,23 @@ BNMF_DEV double prior_logdens(const Dev& d, int e, double x, uint32_t t) {
 constexpr int RT = 256;
 BNMF_DEV double canon1024_by256(const double* x, long L, long stride, double* buf, int tid) {
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  for (long i = tid; i < L; i += 1024) {
-    a0 = a0 + x[i * stride];
-    if (i + 256 < L) a1 = a1 + x[(i + 256) * stride];
-    if (i + 512 < L) a2 = a2 + x[(i + 512) * stride];
-    if (i + 768 < L) a3 = a3 + x[(i + 768) * stride];
+  // five rounds at a time: their twenty loads are requested before the first is added (one round per round trip made the reductions
+  // of G = 10,000 terms ten dependent round trips: 15 us for k_reduce, twice in a row at the end of every bnmf_run).  The additions and
+  // their order are the same: accumulator c adds its terms in ascending order, an absent term adds nothing.
+  constexpr int RB = 5;
+  for (long i0 = tid; i0 < L; i0 += 1024 * RB) {
+    double v[RB][4]; bool ok[RB][4];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { const long i = i0 + 1024L * r + 256L * c; ok[r][c] = i < L; v[r][c] = ok[r][c] ? x[i * stride] : 0.0; }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      if (ok[r][0]) a0 = a0 + v[r][0];
+      if (ok[r][1]) a1 = a1 + v[r][1];
+      if (ok[r][2]) a2 = a2 + v[r][2];
+      if (ok[r][3]) a3 = a3 + v[r][3];
+    }
   }
   a0 = a0 + a2; a1 = a1 + a3;          // tree level h = 512
   a0 = a0 + a1;                         // tree level h = 256
@@ -816,19 +828,31 @@ BNMF_DEV void reduce_body(const Dev& d, const RedSlots& rs, int nblkE, int j, do
   const double* src = j == 0 ? rs.colsse : j == 1 ? rs.colll : j == 2 ? rs.colkl : j == 3 ? rs.lpE_part : rs.accE_part;
   const long len = j < 3 ? d.G : nblkE;
   const double r = canon1024_by256(src, len, 1, buf, tid);
-  if (tid == 0) {
-    double* o = d.raw + (size_t)rs.row * 8;
-    o[j < 4 ? j : 6] = r;
-    if (j == 0) {
-      double lpP = 0.0;
-      for (int n = 0; n < d.N; ++n) lpP = lpP + rs.lpPn[n];
-      o[4] = lpP;
-      if (!d.learning_rank) {             // with rank learning A changes on the main stream: k_sumA writes these
-        double sumA = 0.0;
-        for (int n = 0; n < d.N; ++n) sumA = sumA + d.A[n];
-        o[5] = sumA;
-        if (rs.accPn) { double sp = 0.0; for (int n = 0; n < d.N; ++n) if (d.A[n] == 1.0) sp = sp + rs.accPn[n]; o[7] = sp; }
-      }
+  double* o = d.raw + (size_t)rs.row * 8;
+  if (tid == 0) o[j < 4 ? j : 6] = r;
+  if (j != 0) return;                     // (block-uniform)
+  // the sums over the factors, n ascending from +0.0 as before — but the terms are fetched by the lanes side by side (lane 0 walking
+  // global memory was one round trip per factor, three times N of them in a row)
+  auto seq_sum = [&](auto term) -> double {
+    double acc = 0.0;
+    for (int base = 0; base < d.N; base += RT) {
+      __syncthreads();
+      if (base + tid < d.N) buf[tid] = term(base + tid);
+      __syncthreads();
+      if (tid == 0) for (int i = 0; i < min(RT, d.N - base); ++i) acc = acc + buf[i];
+    }
+    return acc;                           // valid on thread 0
+  };
+  const double lpP = seq_sum([&](int n) { return rs.lpPn[n]; });
+  if (tid == 0) o[4] = lpP;
+  if (!d.learning_rank) {                 // with rank learning A changes on the main stream: k_sumA writes these
+    const double sumA = seq_sum([&](int n) { return d.A[n]; });
+    if (tid == 0) o[5] = sumA;
+    if (rs.accPn) {
+      // (the old loop skipped the factors with A[n] != 1: an absent term adds nothing; here it adds +0.0, which leaves every sum of these
+      // non-negative rates unchanged bit for bit — the sum starts at +0.0 and never holds -0.0)
+      const double sp = seq_sum([&](int n) { return d.A[n] == 1.0 ? rs.accPn[n] : 0.0; });
+      if (tid == 0) o[7] = sp;
     }
   }
 }
