@@ -42,6 +42,64 @@ static int fail(int code, const char* fmt, ...) {
 enum { KN_PDRAW = 0, KN_EDRAW = 1, KN_ZALLOC = 2, KN_REDUCE = 3, KN_SIDE = 4, KN_RANK = 5, KN_MH = 6, KN_OTHER = 7 };
 static const char* k_names[BNMF_NKERNEL] = {"k_pdraw", "k_edraw", "k_zalloc", "k_reduce", "k_side", "k_rank", "k_mh", "other"};
 
+// ---- device memory of the handles: a small per-device pool ----
+// bnmf_destroy followed by bnmf_create (bayesNMF() after bayesNMF(), a BIC sweep, the fuzzers) freed ~60 device allocations and made them
+// again.  The re-made allocations cost the next handle a wait of 8-13 ms (rounds 3-4; 27 ms with round 5's Mhat buffers: about a
+// millisecond per MB) at its first synchronisation — the driver remaps freed memory lazily, at the first submission that touches it; a
+// first handle of a process never saw it (tools/recreate.py: the wait sat in the first bnmf_set_array's stream synchronisation, lives
+// 1, 2, 3 of a process, not life 0).  Freed blocks now go to a per-device free list keyed by their size and the next handle of the same
+// shape takes them from there: no free, no map, no wait.  Blocks above 256 MB (the record_sample rings: their own cache below) and
+// whatever exceeds BNMF_POOL_GB (default 1) are really freed; bnmf_trim() empties the list; an allocation that fails empties it and
+// is tried again.
+struct DevPool {
+  std::mutex m;
+  std::multimap<size_t, void*> free_blocks;
+  std::map<void*, size_t> live;
+  size_t cached = 0;
+};
+static DevPool g_pool[64];
+static size_t pool_cap() { static const size_t cap = [] { const char* e = getenv("BNMF_POOL_GB"); return (size_t)((e ? atof(e) : 1.0) * 1e9); }(); return cap; }
+static size_t pool_drop(int device) {
+  if (device < 0 || device >= 64) return 0;
+  std::vector<void*> drop;
+  size_t tot = 0;
+  { std::lock_guard<std::mutex> lk(g_pool[device].m); for (auto& kv : g_pool[device].free_blocks) drop.push_back(kv.second); tot = g_pool[device].cached; g_pool[device].free_blocks.clear(); g_pool[device].cached = 0; }
+  for (void* q : drop) (void)hipFree(q);
+  return tot;
+}
+static hipError_t dmalloc_raw(void** out, size_t bytes) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || bytes == 0 || bytes > ((size_t)256 << 20)) return hipMalloc(out, bytes);
+  DevPool& P = g_pool[dev];
+  {
+    std::lock_guard<std::mutex> lk(P.m);
+    auto it = P.free_blocks.find(bytes);
+    if (it != P.free_blocks.end()) { *out = it->second; P.free_blocks.erase(it); P.cached -= bytes; P.live[*out] = bytes; return hipSuccess; }
+  }
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess) { (void)hipGetLastError(); pool_drop(dev); e = hipMalloc(out, bytes); }
+  if (e == hipSuccess) { std::lock_guard<std::mutex> lk(P.m); P.live[*out] = bytes; }
+  return e;
+}
+template <class T> static hipError_t dmalloc(T** out, size_t bytes) { return dmalloc_raw((void**)out, bytes); }
+static hipError_t dfree(void* p) {
+  if (!p) return hipSuccess;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipFree(p);
+  DevPool& P = g_pool[dev];
+  {
+    std::lock_guard<std::mutex> lk(P.m);
+    auto it = P.live.find(p);
+    if (it != P.live.end()) {
+      const size_t bytes = it->second;
+      P.live.erase(it);
+      if (P.cached + bytes <= pool_cap()) { P.free_blocks.insert({bytes, p}); P.cached += bytes; return hipSuccess; }
+    }
+  }
+  return hipFree(p);
+}
+
+
 struct Arr { double* d = nullptr; size_t n = 0; int stride = 1; bool set = false; std::vector<int> redraw; double* ring = nullptr;
              bool slab = false; };   // slab: d points into the handle's block of scalars (a broadcast hyper-prior value), not an allocation of its own
 
@@ -157,7 +215,7 @@ static int ensure(bnmf_handle* h, int id) {
   Arr& a = h->arr[id];
   if (a.d) return 0;
   const size_t n = id_len(h, id), tot = n * (is_prior_param(id) ? 2 : 1);
-  HIPCHK(hipMalloc(&a.d, tot * sizeof(double)));
+  HIPCHK(dmalloc(&a.d, tot * sizeof(double)));
   std::vector<double> nan(tot, std::nan(""));
   HIPCHK(hipMemcpy(a.d, nan.data(), tot * sizeof(double), hipMemcpyHostToDevice));
   a.n = n; a.stride = 1;
@@ -387,28 +445,28 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
       const uint32_t v = items[i];
       i16[i] = v == 0xFFFFFFFFu ? (uint16_t)0xFFFFu : (uint16_t)((v & 127u) | (((v >> 10) & 63u) << 7) | ((v >> 16) << 13));
     }
-    HIPCHK(hipMalloc(&h->dZsItems, ((i16.size() * sizeof(uint16_t) + 3) & ~(size_t)3)));
+    HIPCHK(dmalloc(&h->dZsItems, ((i16.size() * sizeof(uint16_t) + 3) & ~(size_t)3)));
     HIPCHK(hipMemcpy(h->dZsItems, i16.data(), i16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   } else {
-    HIPCHK(hipMalloc(&h->dZsItems, items.size() * sizeof(uint32_t)));
+    HIPCHK(dmalloc(&h->dZsItems, items.size() * sizeof(uint32_t)));
     HIPCHK(hipMemcpy(h->dZsItems, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
   h->zs_it16 = it16 ? 1 : 0; h->zs_qmax = qmax;
-  HIPCHK(hipMalloc(&h->dZsBlocks, blocks.size() * sizeof(ZSBlock)));
+  HIPCHK(dmalloc(&h->dZsBlocks, blocks.size() * sizeof(ZSBlock)));
   HIPCHK(hipMemcpy(h->dZsBlocks, blocks.data(), blocks.size() * sizeof(ZSBlock), hipMemcpyHostToDevice));
-  HIPCHK(hipMalloc(&h->dZsCols, cols.size() * sizeof(int)));
+  HIPCHK(dmalloc(&h->dZsCols, cols.size() * sizeof(int)));
   HIPCHK(hipMemcpy(h->dZsCols, cols.data(), cols.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipMalloc(&h->dZsM, Mblk.size() * sizeof(int32_t)));
+  HIPCHK(dmalloc(&h->dZsM, Mblk.size() * sizeof(int32_t)));
   HIPCHK(hipMemcpy(h->dZsM, Mblk.data(), Mblk.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   // three copies, iteration t in copy t % 3 (as the per-column partial sums): the terms of t are summed beside the allocation kernel of t + 1
   // (k_side_lp of t + 2, stream side2), which is known to be over before the draw kernel of t + 3 starts — the allocation kernel of t + 2
   // has waited for the flag of the k_side_lp behind it on that stream
-  HIPCHK(hipMalloc(&h->dZsMh, 3 * K * G * sizeof(double)));
+  HIPCHK(dmalloc(&h->dZsMh, 3 * K * G * sizeof(double)));
   HIPCHK(hipMemset(h->dZsMh, 0, 3 * K * G * sizeof(double)));
   if (c.save_Z) {
     const size_t hw = (N + 1) / 2;
     h->zs_recwords = items.size() * hw;
-    HIPCHK(hipMalloc(&h->dZsRec, h->zs_recwords * sizeof(uint32_t)));
+    HIPCHK(dmalloc(&h->dZsRec, h->zs_recwords * sizeof(uint32_t)));
     h->zs_eager = getenv("BNMF_ZEAGER") && atoi(getenv("BNMF_ZEAGER")) != 0;
     const size_t lds_max = 160 * 1024;
     h->zx_cols = std::max(1, std::min(GBc, zexpand_cols((int)K, (int)N, lds_max)));
@@ -421,7 +479,7 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   h->zs_lds = (zsort_shared_bytes((int)K, (int)N, KP, GBc, pk) + (size_t)W * zsort_wave_bytes(nblk, (int)N) + 15) & ~(size_t)15;
   h->z_sort = true;
 #ifdef ZSPROF
-  HIPCHK(hipMalloc(&h->dZsProf, 8 * sizeof(unsigned long long)));
+  HIPCHK(dmalloc(&h->dZsProf, 8 * sizeof(unsigned long long)));
   HIPCHK(hipMemset(h->dZsProf, 0, 8 * sizeof(unsigned long long)));
 #endif
   return 0;
@@ -526,23 +584,23 @@ static int build_zstep(bnmf_handle* h, const int32_t* M, int n_cu) {
   if (h->zp_it16) {
     std::vector<uint16_t> i16(items.size());
     for (size_t i = 0; i < items.size(); ++i) i16[i] = items[i] == 0xFFFFFFFFu ? (uint16_t)0xFFFFu : (uint16_t)items[i];
-    HIPCHK(hipMalloc(&h->dZpItems, (i16.size() * sizeof(uint16_t) + 3) & ~(size_t)3));
+    HIPCHK(dmalloc(&h->dZpItems, (i16.size() * sizeof(uint16_t) + 3) & ~(size_t)3));
     HIPCHK(hipMemcpy(h->dZpItems, i16.data(), i16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   } else {
-    HIPCHK(hipMalloc(&h->dZpItems, items.size() * sizeof(uint32_t)));
+    HIPCHK(dmalloc(&h->dZpItems, items.size() * sizeof(uint32_t)));
     HIPCHK(hipMemcpy(h->dZpItems, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
-  HIPCHK(hipMalloc(&h->dZpWgs, wgs.size() * sizeof(ZPWg)));
+  HIPCHK(dmalloc(&h->dZpWgs, wgs.size() * sizeof(ZPWg)));
   HIPCHK(hipMemcpy(h->dZpWgs, wgs.data(), wgs.size() * sizeof(ZPWg), hipMemcpyHostToDevice));
-  HIPCHK(hipMalloc(&h->dZpBatches, batches.size() * sizeof(ZPBatch)));
+  HIPCHK(dmalloc(&h->dZpBatches, batches.size() * sizeof(ZPBatch)));
   HIPCHK(hipMemcpy(h->dZpBatches, batches.data(), batches.size() * sizeof(ZPBatch), hipMemcpyHostToDevice));
-  HIPCHK(hipMalloc(&h->dZpSteps, steps.size() * sizeof(ZPStep)));
+  HIPCHK(dmalloc(&h->dZpSteps, steps.size() * sizeof(ZPStep)));
   HIPCHK(hipMemcpy(h->dZpSteps, steps.data(), steps.size() * sizeof(ZPStep), hipMemcpyHostToDevice));
-  HIPCHK(hipMalloc(&h->dZpCols, cols.size() * sizeof(int)));
+  HIPCHK(dmalloc(&h->dZpCols, cols.size() * sizeof(int)));
   HIPCHK(hipMemcpy(h->dZpCols, cols.data(), cols.size() * sizeof(int), hipMemcpyHostToDevice));
   h->zpg = ZPGeom{nch, (int)nwg, nullptr};
 #ifdef ZPPROF
-  HIPCHK(hipMalloc(&h->zpg.prof, 8 * sizeof(unsigned long long)));
+  HIPCHK(dmalloc(&h->zpg.prof, 8 * sizeof(unsigned long long)));
   HIPCHK(hipMemset(h->zpg.prof, 0, 8 * sizeof(unsigned long long)));
 #endif
   h->zp_ns = W; h->zp_gbp = GBP;
@@ -757,7 +815,7 @@ static int probe_overlap(int device, int* overlap) {
     if (int rc = take_stream(device, &a)) return rc;
     if (int rc = take_stream(device, &b)) { give_stream(device, a); return rc; }
     unsigned* w = nullptr;
-    HIPCHK(hipMalloc(&w, 2 * sizeof(unsigned)));
+    HIPCHK(dmalloc(&w, 2 * sizeof(unsigned)));
     HIPCHK(hipMemset(w, 0, 2 * sizeof(unsigned)));
     HIPCHK(hipDeviceSynchronize());
     hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, a, w, w + 1, 200000LL);   // 2 ms of the 100 MHz counter
@@ -767,7 +825,7 @@ static int probe_overlap(int device, int* overlap) {
     HIPCHK(hipStreamSynchronize(b));
     unsigned res[2] = {0, 0};
     HIPCHK(hipMemcpy(res, w, sizeof res, hipMemcpyDeviceToHost));
-    hipFree(w);
+    dfree(w);
     give_stream(device, a); give_stream(device, b);
     g_probe[device] = res[1] == 1u ? 1 : 2;
     if (getenv("BNMF_TIMING")) fprintf(stderr, "[bnmf] device %d: kernels on two streams %s\n", device, g_probe[device] == 1 ? "overlap" : "do NOT overlap: serial-safe mode");
@@ -778,7 +836,7 @@ static int probe_overlap(int device, int* overlap) {
 extern "C" int bnmf_trim(int device, size_t* bytes_released) {
   if (device < 0 || device >= 64) return fail(BNMF_EINVAL, "bnmf_trim: device ordinal %d out of range", device);
   HIPCHK(hipSetDevice(device));
-  const size_t b = ring_cache_drop(device);
+  const size_t b = ring_cache_drop(device) + pool_drop(device);
   std::vector<hipStream_t> st;
   { std::lock_guard<std::mutex> lock(g_stream_mtx); st.swap(g_stream_pool[device]); }
   for (hipStream_t q : st) hipStreamDestroy(q);
@@ -815,17 +873,17 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   HIPCHK(hipEventCreateWithFlags(&h->ev_z, hipEventDisableTiming | hipEventDisableSystemFence));
   HIPCHK(hipEventCreateWithFlags(&h->ev_red, hipEventDisableTiming | hipEventDisableSystemFence));
   clk.mark("events");
-  HIPCHK(hipMalloc(&h->dM, K * G * sizeof(int32_t)));
+  HIPCHK(dmalloc(&h->dM, K * G * sizeof(int32_t)));
   HIPCHK(hipMemcpy(h->dM, M, K * G * sizeof(int32_t), hipMemcpyHostToDevice));
   clk.mark("M to the device");
   int mx = 0;
   for (size_t i = 0; i < K * G; ++i) { if (M[i] < 0) return fail(BNMF_EINVAL, "bnmf_create: negative count in M"); if (M[i] > mx) mx = M[i]; }
   h->maxM = mx;
-  HIPCHK(hipMalloc(&h->dZsumK, N * G * sizeof(int32_t)));
-  HIPCHK(hipMalloc(&h->dZsumG, K * N * sizeof(int32_t)));
+  HIPCHK(dmalloc(&h->dZsumK, N * G * sizeof(int32_t)));
+  HIPCHK(dmalloc(&h->dZsumG, K * N * sizeof(int32_t)));
   HIPCHK(hipMemset(h->dZsumK, 0, N * G * sizeof(int32_t)));
   HIPCHK(hipMemset(h->dZsumG, 0, K * N * sizeof(int32_t)));
-  if (cfg->save_Z) HIPCHK(hipMalloc(&h->dZ, K * N * G * sizeof(int32_t)));
+  if (cfg->save_Z) HIPCHK(dmalloc(&h->dZ, K * N * G * sizeof(int32_t)));
   if (const char* e = getenv("BNMF_GATE")) h->gate_forced = atoi(e) != 0 ? 1 : 0;   // diagnostics / tests
   if (const char* e = getenv("BNMF_MHSIDE")) h->mh_side_main = atoi(e) != 0;
   if (const char* e = getenv("BNMF_MHSIDETAIL")) h->mh_side_tail = atoi(e) != 0;
@@ -844,29 +902,29 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
     h->serial = ov == 0;
     if (const char* e = getenv("BNMF_SERIAL")) h->serial = atoi(e) != 0;      // the caller's explicit choice
   }
-  HIPCHK(hipMalloc(&h->dFlags, 64));
+  HIPCHK(dmalloc(&h->dFlags, 64));
   HIPCHK(hipMemset(h->dFlags, 0, 64));
-  HIPCHK(hipMalloc(&h->dScal, BNMF_ID_MAX * sizeof(double)));
-  HIPCHK(hipMalloc(&h->dDrawOwn, N * sizeof(unsigned)));
+  HIPCHK(dmalloc(&h->dScal, BNMF_ID_MAX * sizeof(double)));
+  HIPCHK(dmalloc(&h->dDrawOwn, N * sizeof(unsigned)));
   HIPCHK(hipMemset(h->dDrawOwn, 0, N * sizeof(unsigned)));
   HIPCHK(hipHostMalloc((void**)&h->hErr, 64, hipHostMallocMapped));
   memset(h->hErr, 0, 64);
   HIPCHK(hipHostGetDevicePointer((void**)&h->dErr, h->hErr, 0));
-  HIPCHK(hipMalloc(&h->dR, sizeof(int)));
+  HIPCHK(dmalloc(&h->dR, sizeof(int)));
   int Rinit = (int)N;
   HIPCHK(hipMemcpy(h->dR, &Rinit, sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipMalloc(&h->dRedraw, N * sizeof(int)));
-  HIPCHK(hipMalloc(&h->dEsum, N * sizeof(double)));
-  HIPCHK(hipMalloc(&h->dPsum, N * sizeof(double)));
-  HIPCHK(hipMalloc(&h->dlpPn, 3 * N * sizeof(double)));
+  HIPCHK(dmalloc(&h->dRedraw, N * sizeof(int)));
+  HIPCHK(dmalloc(&h->dEsum, N * sizeof(double)));
+  HIPCHK(dmalloc(&h->dPsum, N * sizeof(double)));
+  HIPCHK(dmalloc(&h->dlpPn, 3 * N * sizeof(double)));
   h->nblkE = (int)((N * G + ES_T - 1) / ES_T);
-  HIPCHK(hipMalloc(&h->dlpE, 3 * (size_t)h->nblkE * sizeof(double)));
-  HIPCHK(hipMalloc(&h->dcol, 3 * 3 * G * sizeof(double)));   // per-column partials, 3 slots (t % 3)
+  HIPCHK(dmalloc(&h->dlpE, 3 * (size_t)h->nblkE * sizeof(double)));
+  HIPCHK(dmalloc(&h->dcol, 3 * 3 * G * sizeof(double)));   // per-column partials, 3 slots (t % 3)
   if (cfg->learning_rank) {
     const size_t gran_words = (size_t)RK_REP * 4 * 2 * ((G + RK_MAXC - 1) / RK_MAXC);   // [RK_REP copies][4 buffers][2 granules per block sum]
-    HIPCHK(hipMalloc(&h->dRankCol, gran_words * sizeof(double)));
+    HIPCHK(dmalloc(&h->dRankCol, gran_words * sizeof(double)));
     HIPCHK(hipMemset(h->dRankCol, 0, gran_words * sizeof(double)));           // tag 0 is never used
-    HIPCHK(hipMalloc(&h->dRankSync, 32));
+    HIPCHK(dmalloc(&h->dRankSync, 32));
     HIPCHK(hipMemset(h->dRankSync, 0, 32));
     // grid of the persistent rank sweep: co-resident by construction (one 512-lane workgroup per CU)
     hipDeviceProp_t prop0;
@@ -895,12 +953,12 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
     // per-factor exchange, not by VALU contention)
     h->rank_grid = h->rank_half ? (int)wg_half : (int)std::min<long>(wg_needed, h->rank_reg ? cap_reg : cap_gen);
     if (const char* e = getenv("BNMF_RANKGRID")) { const long v = atol(e); if (!h->rank_half && v >= wg_needed && v <= (h->rank_reg ? cap_reg : cap_gen)) h->rank_grid = (int)v; }   // diagnostics only
-    if (!h->rank_reg) HIPCHK(hipMalloc(&h->dRankMhat, K * G * sizeof(double)));
-    if (getenv("BNMF_RANKDBG")) { HIPCHK(hipMalloc(&h->dRankDbg, (size_t)h->rank_grid * 16 * 8 * 8)); HIPCHK(hipMemset(h->dRankDbg, 0, (size_t)h->rank_grid * 16 * 8 * 8)); }   // diagnostics only
+    if (!h->rank_reg) HIPCHK(dmalloc(&h->dRankMhat, K * G * sizeof(double)));
+    if (getenv("BNMF_RANKDBG")) { HIPCHK(dmalloc(&h->dRankDbg, (size_t)h->rank_grid * 16 * 8 * 8)); HIPCHK(hipMemset(h->dRankDbg, 0, (size_t)h->rank_grid * 16 * 8 * 8)); }   // diagnostics only
   }
   if (cfg->MH || cfg->likelihood == BNMF_NORMAL) {
     h->mh_S = (int)((G + MH_SEG - 1) / MH_SEG);
-    HIPCHK(hipMalloc(&h->dMhat, 3 * K * G * sizeof(double)));      // rows of Mhat maintained by the P sweep; log(Mhat) and its candidates (MH step)
+    HIPCHK(dmalloc(&h->dMhat, 3 * K * G * sizeof(double)));      // rows of Mhat maintained by the P sweep; log(Mhat) and its candidates (MH step)
     if (const char* e = getenv("BNMF_MHE_K128")) h->mhe_k128 = atoi(e) != 0;
     if (const char* e = getenv("BNMF_MHE_GW")) h->mhe_gw = atoi(e) == 32 ? 32 : atoi(e) == 16 ? 16 : 0;   // diagnostics / tests: lanes per column of k_mh_ecol16 (0 = by mode)
     h->mhe_lds = 4 * (2 * N + 3 * K) * sizeof(double);             // k_mh_ecol: per wave E column, A, Mhat column, log(Mhat) and candidates
@@ -922,20 +980,20 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
         for (const void* kf : ks) HIPCHK(hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       }
     }
-    HIPCHK(hipMalloc(&h->dAccPn, 3 * N * sizeof(double)));
-    HIPCHK(hipMalloc(&h->dAccEpart, 3 * (size_t)h->nblkE * sizeof(double)));
-    HIPCHK(hipMalloc(&h->dNzE, 2 * N * sizeof(int)));
-    HIPCHK(hipMalloc(&h->dEt, N * G * sizeof(double)));
-    HIPCHK(hipMalloc(&h->dMt, K * G * sizeof(int32_t)));
+    HIPCHK(dmalloc(&h->dAccPn, 3 * N * sizeof(double)));
+    HIPCHK(dmalloc(&h->dAccEpart, 3 * (size_t)h->nblkE * sizeof(double)));
+    HIPCHK(dmalloc(&h->dNzE, 2 * N * sizeof(int)));
+    HIPCHK(dmalloc(&h->dEt, N * G * sizeof(double)));
+    HIPCHK(dmalloc(&h->dMt, K * G * sizeof(int32_t)));
     {
       std::vector<int32_t> mt(K * G);
       for (size_t g = 0; g < G; ++g) for (size_t k = 0; k < K; ++k) mt[g + G * k] = M[k + K * g];
       HIPCHK(hipMemcpy(h->dMt, mt.data(), K * G * sizeof(int32_t), hipMemcpyHostToDevice));
     }
   }
-  HIPCHK(hipMalloc(&h->dLut, 2 * (size_t)(mx + 1) * sizeof(double)));
+  HIPCHK(dmalloc(&h->dLut, 2 * (size_t)(mx + 1) * sizeof(double)));
   if (cfg->n_temperature > 0 && cfg->temperature) {
-    HIPCHK(hipMalloc(&h->dTemp, cfg->n_temperature * sizeof(double)));
+    HIPCHK(dmalloc(&h->dTemp, cfg->n_temperature * sizeof(double)));
     HIPCHK(hipMemcpy(h->dTemp, cfg->temperature, cfg->n_temperature * sizeof(double), hipMemcpyHostToDevice));
     h->temp_host.assign(cfg->temperature, cfg->temperature + cfg->n_temperature);
   } else h->cfg.n_temperature = 0;
@@ -943,7 +1001,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   h->metrics_rows = 1024;
   HIPCHK(hipHostMalloc((void**)&h->hMetrics, h->metrics_rows * BNMF_NMETRIC * sizeof(double), hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void**)&h->dMetrics, h->hMetrics, 0));
-  HIPCHK(hipMalloc(&h->dRaw, h->metrics_rows * 8 * sizeof(double)));
+  HIPCHK(dmalloc(&h->dRaw, h->metrics_rows * 8 * sizeof(double)));
   hipLaunchKernelGGL(k_luts, dim3((mx + 256) / 256), dim3(256), 0, h->stream, h->dLut, h->dLut + (mx + 1), mx);
   HIPCHK(hipGetLastError());
   clk.mark("small buffers, tables");
@@ -1059,9 +1117,9 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
         if (ns < 1) ns = 1;
         tg.nslice = (int)ns;
         h->z_grid = tg.nch * tg.nslice;
-        HIPCHK(hipMalloc(&h->dMhatZ, K * G * sizeof(double)));
+        HIPCHK(dmalloc(&h->dMhatZ, K * G * sizeof(double)));
         tg.dbg = nullptr;
-        if (getenv("BNMF_ZTDBG")) { HIPCHK(hipMalloc(&tg.dbg, 8 * sizeof(unsigned long long))); HIPCHK(hipMemset(tg.dbg, 0, 8 * sizeof(unsigned long long))); }   // diagnostics only
+        if (getenv("BNMF_ZTDBG")) { HIPCHK(dmalloc(&tg.dbg, 8 * sizeof(unsigned long long))); HIPCHK(hipMemset(tg.dbg, 0, 8 * sizeof(unsigned long long))); }   // diagnostics only
       }
     }
 #ifdef BNMF_DIAG   /* the builder's diagnostic builds only (tools/bin/, never libbnmf.so): phases of the allocation kernels switched off */
@@ -1085,26 +1143,26 @@ int bnmf_destroy(bnmf_handle* h) {
   if (h->side2) hipStreamSynchronize(h->side2);
   for (int id = 0; id < BNMF_ID_MAX; ++id) {
     Arr& a = h->arr[id];
-    if (a.d && !a.slab) hipFree(a.d);
+    if (a.d && !a.slab) dfree(a.d);
     if (a.ring) ring_release(h->device, a.ring, (size_t)h->wcap * id_len(h, id) * sizeof(double));
   }
-  hipFree(h->dM); hipFree(h->dZsumK); hipFree(h->dZsumG); if (h->dZ) hipFree(h->dZ);
-  hipFree(h->dR); hipFree(h->dRedraw); hipFree(h->dEsum); hipFree(h->dPsum); hipFree(h->dlpPn);
-  hipFree(h->dlpE); hipFree(h->dcol); hipFree(h->dLut); if (h->dTemp) hipFree(h->dTemp); if (h->hMetrics) hipHostFree(h->hMetrics); hipFree(h->dRaw); if (h->dRankCol) hipFree(h->dRankCol); if (h->dRankMhat) hipFree(h->dRankMhat); if (h->dRankSync) hipFree(h->dRankSync);
-  if (h->E_alt) hipFree(h->E_alt);
-  if (h->dMhatZ) hipFree(h->dMhatZ);
-  if (h->zpg.prof) hipFree(h->zpg.prof);
-  if (h->dZpItems) hipFree(h->dZpItems); if (h->dZpWgs) hipFree(h->dZpWgs); if (h->dZpBatches) hipFree(h->dZpBatches); if (h->dZpSteps) hipFree(h->dZpSteps); if (h->dZpCols) hipFree(h->dZpCols);
-  if (h->dZsItems) hipFree(h->dZsItems); if (h->dZsBlocks) hipFree(h->dZsBlocks); if (h->dZsCols) hipFree(h->dZsCols); if (h->dZsProf) hipFree(h->dZsProf); if (h->dZsM) hipFree(h->dZsM); if (h->dZsRec) hipFree(h->dZsRec); if (h->dZsRecRing) hipFree(h->dZsRecRing); if (h->dZsMh) hipFree(h->dZsMh);
-  if (h->dMhat) hipFree(h->dMhat); if (h->dAccPn) hipFree(h->dAccPn); if (h->dAccEpart) hipFree(h->dAccEpart); if (h->dNzE) hipFree(h->dNzE);
-  if (h->dEt) hipFree(h->dEt); if (h->dMt) hipFree(h->dMt); if (h->zring) hipFree(h->zring);
+  dfree(h->dM); dfree(h->dZsumK); dfree(h->dZsumG); if (h->dZ) dfree(h->dZ);
+  dfree(h->dR); dfree(h->dRedraw); dfree(h->dEsum); dfree(h->dPsum); dfree(h->dlpPn);
+  dfree(h->dlpE); dfree(h->dcol); dfree(h->dLut); if (h->dTemp) dfree(h->dTemp); if (h->hMetrics) hipHostFree(h->hMetrics); dfree(h->dRaw); if (h->dRankCol) dfree(h->dRankCol); if (h->dRankMhat) dfree(h->dRankMhat); if (h->dRankSync) dfree(h->dRankSync);
+  if (h->E_alt) dfree(h->E_alt);
+  if (h->dMhatZ) dfree(h->dMhatZ);
+  if (h->zpg.prof) dfree(h->zpg.prof);
+  if (h->dZpItems) dfree(h->dZpItems); if (h->dZpWgs) dfree(h->dZpWgs); if (h->dZpBatches) dfree(h->dZpBatches); if (h->dZpSteps) dfree(h->dZpSteps); if (h->dZpCols) dfree(h->dZpCols);
+  if (h->dZsItems) dfree(h->dZsItems); if (h->dZsBlocks) dfree(h->dZsBlocks); if (h->dZsCols) dfree(h->dZsCols); if (h->dZsProf) dfree(h->dZsProf); if (h->dZsM) dfree(h->dZsM); if (h->dZsRec) dfree(h->dZsRec); if (h->dZsRecRing) dfree(h->dZsRecRing); if (h->dZsMh) dfree(h->dZsMh);
+  if (h->dMhat) dfree(h->dMhat); if (h->dAccPn) dfree(h->dAccPn); if (h->dAccEpart) dfree(h->dAccEpart); if (h->dNzE) dfree(h->dNzE);
+  if (h->dEt) dfree(h->dEt); if (h->dMt) dfree(h->dMt); if (h->zring) dfree(h->zring);
   if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_rank) hipEventDestroy(h->ev_rank); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); give_stream(h->device, h->side); give_stream(h->device, h->side2);
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
-  if (h->dMap) hipFree(h->dMap);
-  if (h->dAsg) hipFree(h->dAsg);
+  if (h->dMap) dfree(h->dMap);
+  if (h->dAsg) dfree(h->dAsg);
   if (h->devlock_fd >= 0) close(h->devlock_fd);
   if (h->devgate_fd >= 0) close(h->devgate_fd);
-  if (h->dFlags) hipFree(h->dFlags); if (h->dDrawOwn) hipFree(h->dDrawOwn); if (h->dScal) hipFree(h->dScal); if (h->hErr) hipHostFree(h->hErr);
+  if (h->dFlags) dfree(h->dFlags); if (h->dDrawOwn) dfree(h->dDrawOwn); if (h->dScal) dfree(h->dScal); if (h->hErr) hipHostFree(h->hErr);
   give_stream(h->device, h->stream);                    // synchronised at the top of this function
   delete h;
   return 0;
@@ -1139,7 +1197,7 @@ int bnmf_set_array(bnmf_handle* h, int id, const double* x, size_t n) {
   if (is_hyper(id) && n == 1) {
     // a broadcast scalar lives in the handle's block of scalars: the eight device allocations of the default hyper-prior values
     // were 20 ms of a bayesNMF() call
-    if (a.d && !a.slab) HIPCHK(hipFree(a.d));
+    if (a.d && !a.slab) HIPCHK(dfree(a.d));
     a.d = h->dScal + id; a.slab = true;
     // the value travels as a kernel argument: the first small host-to-device copy of a handle created after another one had been
     // destroyed took 13-24 ms (BNMF_TIMING marks), every time
@@ -1152,8 +1210,8 @@ int bnmf_set_array(bnmf_handle* h, int id, const double* x, size_t n) {
   }
   if (n != len) return fail(BNMF_ESIZE, "bnmf_set_array: id %d expects %zu values, got %zu", id, len, n);
   const size_t nslot = is_prior_param(id) ? 2 : 1;
-  if (a.d && (a.n != len || a.slab)) { if (!a.slab) HIPCHK(hipFree(a.d)); a.d = nullptr; a.slab = false; }
-  if (!a.d) HIPCHK(hipMalloc(&a.d, nslot * len * sizeof(double)));
+  if (a.d && (a.n != len || a.slab)) { if (!a.slab) HIPCHK(dfree(a.d)); a.d = nullptr; a.slab = false; }
+  if (!a.d) HIPCHK(dmalloc(&a.d, nslot * len * sizeof(double)));
   HIPCHK(hipMemcpy(a.d + (nslot == 2 ? (size_t)cur_slot(h) * len : 0), x, len * sizeof(double), hipMemcpyHostToDevice));
   a.n = len; a.stride = 1; a.set = true;
   // which columns n (P side) / rows n (E side) carry a missing (NaN) entry
@@ -1264,8 +1322,8 @@ static int ensure_metrics(bnmf_handle* h, size_t rows) {
   h->metrics_rows = rows;
   HIPCHK(hipHostMalloc((void**)&h->hMetrics, rows * BNMF_NMETRIC * sizeof(double), hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void**)&h->dMetrics, h->hMetrics, 0));
-  HIPCHK(hipFree(h->dRaw));
-  HIPCHK(hipMalloc(&h->dRaw, rows * 8 * sizeof(double)));
+  HIPCHK(dfree(h->dRaw));
+  HIPCHK(dmalloc(&h->dRaw, rows * 8 * sizeof(double)));
   refresh_dev(h);
   return 0;
 }
@@ -1686,12 +1744,12 @@ static int ensure_rings(bnmf_handle* h) {
     if (!h->dZsRecRing) {
       const double gb = (double)h->wcap * (double)h->zs_recwords * 4.0 / 1e9;
       const char* e = getenv("BNMF_ZRING_GB");
-      if (gb <= (e ? atof(e) : 32.0)) HIPCHK(hipMalloc(&h->dZsRecRing, (size_t)h->wcap * h->zs_recwords * sizeof(uint32_t)));
+      if (gb <= (e ? atof(e) : 32.0)) HIPCHK(dmalloc(&h->dZsRecRing, (size_t)h->wcap * h->zs_recwords * sizeof(uint32_t)));
     }
   } else if (h->dZ && !h->zring) {                         // samples$Z (R/bayesNMF_sampler.R:245-252): K*N*G ints per kept sample
     const double gb = (double)h->wcap * (double)id_len(h, BNMF_Z) * 4.0 / 1e9;
     const char* e = getenv("BNMF_ZRING_GB");
-    if (gb <= (e ? atof(e) : 32.0)) HIPCHK(hipMalloc(&h->zring, (size_t)h->wcap * id_len(h, BNMF_Z) * sizeof(int32_t)));
+    if (gb <= (e ? atof(e) : 32.0)) HIPCHK(dmalloc(&h->zring, (size_t)h->wcap * id_len(h, BNMF_Z) * sizeof(int32_t)));
   }
   return 0;
 }
@@ -1878,7 +1936,7 @@ static int sweep(bnmf_handle* h, int row, Timer& tm) {
   // k_edraw works on E_t.  (The P side needs nothing: k_lpp precedes Esum, whose flag releases k_pdraw.)
   if (!lpe_from_ring(h)) {
     if (!h->E_alt) {
-      HIPCHK(hipMalloc(&h->E_alt, (size_t)h->cfg.N * h->cfg.G * sizeof(double)));
+      HIPCHK(dmalloc(&h->E_alt, (size_t)h->cfg.N * h->cfg.G * sizeof(double)));
       HIPCHK(hipMemsetAsync(h->E_alt, 0, (size_t)h->cfg.N * h->cfg.G * sizeof(double), h->stream));
     }
     std::swap(h->arr[BNMF_E].d, h->E_alt);
@@ -2284,7 +2342,7 @@ int bnmf_map(bnmf_handle* h, int last_n, double ci, double* P_mean, double* E_me
   if (want_ci && !qS && (size_t)kt * 2 * 64 * sizeof(double) > 160 * 1024)
     return fail(BNMF_EINVAL, "bnmf_map: credible_interval %.3g over %d samples needs %d order statistics per element (device limit 160): take the window with bnmf_window", ci, nu, kt);
   const size_t words = (size_t)nu * N + 3 * (lenP + lenE) + 2 * (size_t)G + N + ((size_t)nu + 1) / 2 + 8;
-  if (words > h->map_words) { if (h->dMap) HIPCHK(hipFree(h->dMap)); h->dMap = nullptr; HIPCHK(hipMalloc(&h->dMap, words * sizeof(double))); h->map_words = words; }
+  if (words > h->map_words) { if (h->dMap) HIPCHK(dfree(h->dMap)); h->dMap = nullptr; HIPCHK(dmalloc(&h->dMap, words * sizeof(double))); h->map_words = words; }
   double* cs = h->dMap; double* mP = cs + (size_t)nu * N; double* loP = mP + lenP; double* hiP = loP + lenP;
   double* mE = hiP + lenP; double* loE = mE + lenE; double* hiE = loE + lenE;
   double* colsse = hiE + lenE; double* colkl = colsse + G; double* dA = colkl + G; int* dslots = (int*)(dA + N);
@@ -2476,8 +2534,8 @@ int bnmf_assign(bnmf_handle* h, int last_n, const int32_t* used, const double* r
   const size_t oRef = 0, oN2 = oRef + up(refT.size() * 8), oOut = oN2 + up((size_t)R * 8), oSl = oOut + up(nout * 8), oSig = oSl + up((size_t)nu * sizeof(int)),
                oCol = oSig + up((size_t)nk * sizeof(int)), need = oCol + up((size_t)nu * std::min(nk, R) * sizeof(int32_t));
   if (need > h->asg_bytes) {
-    if (h->dAsg) { HIPCHK(hipFree(h->dAsg)); h->dAsg = nullptr; h->asg_bytes = 0; }
-    HIPCHK(hipMalloc(&h->dAsg, need));
+    if (h->dAsg) { HIPCHK(dfree(h->dAsg)); h->dAsg = nullptr; h->asg_bytes = 0; }
+    HIPCHK(dmalloc(&h->dAsg, need));
     h->asg_bytes = need;
   }
   double *dRef = (double*)(h->dAsg + oRef), *dN2 = (double*)(h->dAsg + oN2), *dOut = (double*)(h->dAsg + oOut);
@@ -2553,7 +2611,7 @@ int bnmf_ubench(int device, double* philox_words_per_s, double* copy_gbs) {
   {
     const int wgs = prop.multiProcessorCount * 8, nq = 4000;                 // 8 waves per SIMD
     uint32_t* d = nullptr;
-    HIPCHK(hipMalloc(&d, (size_t)wgs * 256 * sizeof(uint32_t)));
+    HIPCHK(dmalloc(&d, (size_t)wgs * 256 * sizeof(uint32_t)));
     hipLaunchKernelGGL(k_ubench_philox, dim3(wgs), dim3(256), 0, 0, d, 200, 1u);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipEventRecord(e0, 0));
@@ -2562,12 +2620,12 @@ int bnmf_ubench(int device, double* philox_words_per_s, double* copy_gbs) {
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     *philox_words_per_s = 4.0 * nq * (double)wgs * 256.0 / (ms * 1e-3);
-    hipFree(d);
+    dfree(d);
   }
   {
     const size_t bytes = (size_t)1 << 30;
     char *a = nullptr, *b = nullptr;
-    HIPCHK(hipMalloc(&a, bytes)); HIPCHK(hipMalloc(&b, bytes));
+    HIPCHK(dmalloc(&a, bytes)); HIPCHK(dmalloc(&b, bytes));
     HIPCHK(hipMemset(a, 1, bytes));
     HIPCHK(hipMemcpy(b, a, bytes, hipMemcpyDeviceToDevice));
     HIPCHK(hipDeviceSynchronize());
@@ -2577,7 +2635,7 @@ int bnmf_ubench(int device, double* philox_words_per_s, double* copy_gbs) {
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     *copy_gbs = 4.0 * 2.0 * (double)bytes / (ms * 1e-3) / 1e9;               // read + write
-    hipFree(a); hipFree(b);
+    dfree(a); dfree(b);
   }
   hipEventDestroy(e0); hipEventDestroy(e1);
   return 0;
@@ -2587,13 +2645,13 @@ int bnmf_ubench(int device, double* philox_words_per_s, double* copy_gbs) {
 int bnmf_test_math(int device, int fn, const double* in, double* out, size_t n) {
   HIPCHK(hipSetDevice(device));
   double *di, *dou;
-  HIPCHK(hipMalloc(&di, n * sizeof(double)));
-  HIPCHK(hipMalloc(&dou, n * sizeof(double)));
+  HIPCHK(dmalloc(&di, n * sizeof(double)));
+  HIPCHK(dmalloc(&dou, n * sizeof(double)));
   HIPCHK(hipMemcpy(di, in, n * sizeof(double), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_test_math, dim3((n + 255) / 256), dim3(256), 0, 0, fn, di, dou, n);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(out, dou, n * sizeof(double), hipMemcpyDeviceToHost));
-  hipFree(di); hipFree(dou);
+  dfree(di); dfree(dou);
   return 0;
 }
 int bnmf_test_sampler(int device, int which, uint64_t seed, uint32_t chain, uint32_t var, uint32_t elem0, uint32_t iter,
@@ -2601,8 +2659,8 @@ int bnmf_test_sampler(int device, int which, uint64_t seed, uint32_t chain, uint
   HIPCHK(hipSetDevice(device));
   if (int rc = ensure_alut(device)) return rc;
   double *da, *db, *dc, *dou;
-  HIPCHK(hipMalloc(&da, n * sizeof(double))); HIPCHK(hipMalloc(&db, n * sizeof(double)));
-  HIPCHK(hipMalloc(&dc, n * sizeof(double))); HIPCHK(hipMalloc(&dou, n * sizeof(double)));
+  HIPCHK(dmalloc(&da, n * sizeof(double))); HIPCHK(dmalloc(&db, n * sizeof(double)));
+  HIPCHK(dmalloc(&dc, n * sizeof(double))); HIPCHK(dmalloc(&dou, n * sizeof(double)));
   std::vector<double> zeros(n, 0.0);
   HIPCHK(hipMemcpy(da, a ? a : zeros.data(), n * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(db, b ? b : zeros.data(), n * sizeof(double), hipMemcpyHostToDevice));
@@ -2611,17 +2669,17 @@ int bnmf_test_sampler(int device, int which, uint64_t seed, uint32_t chain, uint
                      var, elem0, iter, da, db, dc, dou, n);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(out, dou, n * sizeof(double), hipMemcpyDeviceToHost));
-  hipFree(da); hipFree(db); hipFree(dc); hipFree(dou);
+  dfree(da); dfree(db); dfree(dc); dfree(dou);
   return 0;
 }
 static int test_philox_r(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4], int rounds) {
   HIPCHK(hipSetDevice(device));
   uint32_t* d;
-  HIPCHK(hipMalloc(&d, 16));
+  HIPCHK(dmalloc(&d, 16));
   hipLaunchKernelGGL(k_test_philox, dim3(1), dim3(1), 0, 0, ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], d, rounds);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(out, d, 16, hipMemcpyDeviceToHost));
-  hipFree(d);
+  dfree(d);
   return 0;
 }
 int bnmf_test_philox(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { return test_philox_r(device, ctr, key, out, 10); }

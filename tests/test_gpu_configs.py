@@ -488,3 +488,25 @@ def test_two_processes_share_the_device():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run(["bash", os.path.join(root, "tools", "two_process_check.sh"), "2"], capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_recreated_handle_does_not_wait_for_remapped_memory():
+    """the first stream synchronisation after a bnmf_create that followed a bnmf_destroy waited 8-13 ms (27 ms with
+    round 5's Mhat buffers) — freed device memory made again is mapped lazily, at the first submission that touches it
+    (tools/recreate.py).  A destroyed handle's blocks now go to a per-device pool and the next handle of the same shape takes them from
+    there: the calls between bnmf_create and the first iteration of a re-created handle take well under a millisecond each again.
+    (Bound: 5 ms for the eight scalar bnmf_set_array calls together; they took 27 ms.)  bnmf_trim gives the pool back."""
+    import time
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.engine import trim
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    M, _, _ = synth_counts(96, 10000, 8, 20250218)
+    waits = []
+    for life in range(3):
+        e = Engine(M, 20, prior="gamma", seed=1, window=50)
+        t0 = time.perf_counter(); apply_hyperprior_params(e, "gamma", M, 20); waits.append(1e3 * (time.perf_counter() - t0))
+        e.init(); e.run(5)
+        e.close()
+    assert max(waits[1:]) < 5.0, waits
+    assert trim(0) > 20e6                       # the pooled blocks (Mhat alone is 23 MB) and the cached rings go back to the device
+    assert trim(0) == 0
