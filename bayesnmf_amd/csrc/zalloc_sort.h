@@ -14,7 +14,8 @@
 // No cell switch, no prefix scan, no random LDS address inside the loop.  The histogram is flushed per item into the
 // block's zG[n][k] / zK[n][column] (LDS atomics), those once per block into ZsumG (global integer atomics: exact,
 // order-independent) and ZsumK (plain stores: a column belongs to one block).  The per-column metric terms need the
-// canonical W = 64 order over the rows: they are separate small tasks (lane = row) at the end of the block's task list.
+// canonical W = 64 order over the rows: rounds 3-4 formed Mhat a second time for them, lane = row ("metric tasks"); since round 5 the
+// lane of a cell's first item stores the Mhat it has formed (s.mh) and colterms.h sums the terms from there, beside the next allocation kernel.
 // save_Z (round 4; samples$Z, R/sample_params.R:80-84, R/bayesNMF_sampler.R:245-252): the same kernel with s.rec set.  A lane's
 // histogram is its item's share of Z[k, ., g]; the flush also writes it — packed as the flush packs it, two 16-bit counts per
 // word — to the record buffer rec[task][word][lane]: one coalesced 256-byte store per word and task.  k_zexpand then turns a
