@@ -402,6 +402,7 @@ __global__ __launch_bounds__(HALF ? RK_TH : RK_T) void k_rank_sweep(Dev d, uint3
   double lg0[(REG && !NORMAL) ? CPW : 1], lg1[(REG && !NORMAL) ? RK_P : 1];   // lgamma(M + 1) of the wave's cells
   int mm0[REG ? CPW : 1], mm1[REG ? RK_P : 1];
   unsigned xc = 0u;                                        // HALF: publications so far (the same count in both waves of a block)
+  bool xdead = false;                                      // HALF: a wait for the first half has timed out: the launch is lost, wait for nothing more
   const int half = lane >> 5, row1 = 64 + (lane & 31);    // slot 1: this lane's column of the pair and its row
   const bool lowv1 = lane < 32 && 64 + lane < K;          // lanes that own an accumulator with a second row
   // block sum of the wave's 8 columns from the lanes' accumulators: 8 canonical trees, then columns in ascending order (lane 0)
@@ -420,10 +421,14 @@ __global__ __launch_bounds__(HALF ? RK_TH : RK_T) void k_rank_sweep(Dev d, uint3
       ++xc;
       if (whalf) {                                         // the second half continues the first half's sum
         unsigned spins = 0;
-        while (__hip_atomic_load(&xcht[wblk][xc & 3u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != xc && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(0);
-        // bounded like every wait of the sweep: a first half that never arrives (it cannot, short of a fault) fails the launch, not the chain's bits
-        if (spins >= (1u << 26) && lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bs = xchv[wblk][xc & 3u];
+        // bounded like every wait of the sweep: a first half that never arrives (it cannot, short of a fault) fails the launch, not the chain's bits.
+        // after ONE time-out the wave waits for nothing any more (xdead) — the launch is lost (the host poisons the handle), every
+        // later publication of this block would otherwise sit through the same bound again — and takes +0.0 instead of a slot that may be stale.
+        while (!xdead && __hip_atomic_load(&xcht[wblk][xc & 3u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != xc) {
+          if (++spins >= (1u << 26)) { xdead = true; if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          __builtin_amdgcn_s_sleep(0);
+        }
+        bs = xdead ? 0.0 : xchv[wblk][xc & 3u];
       }
 #pragma unroll
       for (int c = 0; c < CPW; ++c) {

@@ -114,6 +114,18 @@ def lib():
     return _LIB
 
 
+_RUN = None
+
+
+def _run_fn():
+    """bnmf_run with plain-integer argument types (handle and buffer as addresses): no per-call conversion objects"""
+    global _RUN
+    if _RUN is None:
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
+        _RUN = proto(("bnmf_run", lib()))
+    return _RUN
+
+
 def _chk(rc):
     if rc != 0:
         raise BnmfError(rc, lib().bnmf_last_error().decode())
@@ -196,12 +208,15 @@ class Engine:
         h = C.c_void_p()
         _chk(lib().bnmf_create(C.byref(cfg), M.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(h)))
         self._h = h
+        self._hv = h.value
+        self._run = _run_fn()
         self.M = M
 
     def close(self):
         if getattr(self, "_h", None):
             lib().bnmf_destroy(self._h)
             self._h = None
+            self._hv = None
 
     def __del__(self):
         try:
@@ -248,7 +263,11 @@ class Engine:
 
     def run(self, n_iter, converged=False, metrics=True):
         out = np.empty((n_iter, NMETRIC)) if metrics else None
-        _chk(lib().bnmf_run(self._h, n_iter, int(converged), _dp(out) if metrics else None))
+        # (the hot call of every driver loop: the bound function and the handle's integer value are looked up once, the buffer goes in as
+        # its address — the generic path cost 16 us per call, 1 % of a 20-iteration call at the metric configuration)
+        rc = self._run(self._hv, n_iter, 1 if converged else 0, out.ctypes.data if metrics else None)
+        if rc != 0:
+            _chk(rc)
         return out
 
     def profile(self, n_iter, converged=False):

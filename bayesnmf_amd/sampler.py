@@ -451,19 +451,27 @@ class bayesNMF_sampler:
     def _post_warmup_on_engine(self, cc, pw):
         """The MH models' post-warm-up iterations (R/bayesNMF_sampler.R:332-384) as one engine call; the final MAP (kept
         signatures, credible intervals) is then taken from the device window as after the reference's last check."""
-        rows, maps, st = self._chain.run_post_warmup(cc, self._cc_state(), pw)
-        if len(rows):
-            self._append_metrics(rows)
-            self.state["iter"] = int(rows[-1, 0])
-        self._absorb_map_rows(maps, cc)
-        self._absorb_cc_state(st)
-        self.get_MAP(final=True)
-        # The reference's last check is update_MAP_metrics(final = TRUE) on the KEPT signatures (R/bayesNMF_sampler.R:364-375); the
-        # engine's rows come from bnmf_map over all N.  With excluded signatures the two differ: the last row is rebuilt here from the
-        # final MAP (n_params, BIC, and RMSE / KL when the device values are not attached to it).
-        if len(maps) and len(self.MAP.get("keep_sigs", [])) < self.dims["N"] and not self.state["MAP_metrics"].empty:
-            self.state["MAP_metrics"] = self.state["MAP_metrics"].iloc[:-1].reset_index(drop=True)
-            self._update_MAP_metrics(final=True)
+        # The reference's LAST check is get_MAP(final = TRUE) + check_convergence(final = TRUE): MAP metrics AND convergence bookkeeping on
+        # the KEPT signatures (R/bayesNMF_sampler.R:364-375).  The engine's checks are over all N (bnmf_map), which is what every check
+        # but the last wants — so the engine runs up to the last regular check before the end, the rest of the iterations are one plain
+        # bnmf_run, and the final check is made here, exactly as the reference makes it (ADVICE r4: rounds 3-4 rebuilt the last
+        # MAP-metrics row but kept the all-N bookkeeping).
+        me = cc["MAP_every"]
+        it0 = int(self.state["iter"])
+        end = it0 + int(pw)
+        n1 = max(((end - 1) // me) * me - it0, 0)
+        if n1 > 0:
+            rows, maps, st = self._chain.run_post_warmup(cc, self._cc_state(), n1)
+            if len(rows):
+                self._append_metrics(rows)
+                self.state["iter"] = int(rows[-1, 0])
+            self._absorb_map_rows(maps, cc)
+            self._absorb_cc_state(st)
+        n2 = end - int(self.state["iter"])
+        if n2 > 0:
+            self._append_metrics(self._chain.run(n2, converged=True))
+            self.state["iter"] = end
+        self._check(final=True)
 
     def _run_until_on_engine(self, cc):
         """The warm-up loop (blocks, MAP, MAP metrics, convergence bookkeeping) as one engine call (SURVEY.md 8 f2);

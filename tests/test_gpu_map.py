@@ -137,7 +137,7 @@ def test_bayesNMF_uses_device_map(tmp_path, monkeypatch):
     s.close()
 
 
-@pytest.mark.parametrize("model", ["gamma_fixed", "gamma_rank", "truncnormal_mh"])
+@pytest.mark.parametrize("model", ["gamma_fixed", "gamma_rank", "truncnormal_mh", "truncnormal_mh_rank"])
 def test_run_until_matches_blockwise_loop(model, tmp_path):
     """f2: the warm-up loop on the engine side (bnmf_run_until: blocks, MAP, MAP metrics, check_convergence_) gives the
     same chain, the same MAP-metrics table and the same stopping point as the block-by-block host loop."""
@@ -151,6 +151,11 @@ def test_run_until_matches_blockwise_loop(model, tmp_path):
     elif model == "gamma_rank":
         kw, rank = dict(prior="gamma", prop_temp=0.3), range(1, 7)
         cc = new_convergence_control(MAP_over=60, MAP_every=30, miniters=90, maxiters=420, tol=0.01)
+    elif model == "truncnormal_mh_rank":
+        # the default model WITH excluded signatures at the end: the last check (get_MAP(final = TRUE) + check_convergence on the kept
+        # signatures, R/bayesNMF_sampler.R:364-375) must leave the same MAP-metrics row AND the same bookkeeping on both paths
+        kw, rank = dict(prior="truncnormal", post_warmup=50, prop_temp=0.3), range(1, 7)
+        cc = new_convergence_control(MAP_over=60, MAP_every=30, miniters=90, maxiters=420, tol=0.01)
     else:
         kw, rank = dict(prior="truncnormal", post_warmup=40), 3
         cc = new_convergence_control(MAP_over=60, MAP_every=30, miniters=90, maxiters=300, tol=0.01)
@@ -160,7 +165,8 @@ def test_run_until_matches_blockwise_loop(model, tmp_path):
                      save_all_samples=False, seed=5, engine_side_convergence=eng, **kw)
         res.append(dict(iter=s.state["iter"], why=s.state.get("why"), sm=s.state["sample_metrics"].to_numpy(),
                         mm=s.state["MAP_metrics"].to_numpy(), cols=list(s.state["MAP_metrics"].columns), P=s.MAP["P"].copy(),
-                        st={k: s.state.get(k) for k in ("inarow_no_change", "inarow_no_best", "inarow_na", "best_iter", "converged_iter")}))
+                        st={k: s.state.get(k) for k in ("inarow_no_change", "inarow_no_best", "inarow_na", "best_iter", "converged_iter")},
+                        pm=(s.state.get("prev_MAP_metric"), s.state.get("best_MAP_metric")), keep=list(np.asarray(s.MAP["keep_sigs"]).ravel())))
         s.close()
     a, b = res
     assert a["iter"] == b["iter"] and a["why"] == b["why"] and a["st"] == b["st"]
@@ -168,3 +174,6 @@ def test_run_until_matches_blockwise_loop(model, tmp_path):
     assert a["cols"] == b["cols"] and a["mm"].shape == b["mm"].shape
     assert np.allclose(a["mm"], b["mm"], rtol=1e-10, equal_nan=True)
     assert np.allclose(a["P"], b["P"], rtol=1e-12)
+    assert a["keep"] == b["keep"] and np.allclose(a["pm"], b["pm"], rtol=1e-10, equal_nan=True)
+    if model == "truncnormal_mh_rank":
+        assert len(a["keep"]) < 6                                                   # the case is there for excluded signatures
