@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import bayesnmf_amd.engine as E
-    E.LIB_PATH = os.path.join(os.path.dirname(E.LIB_PATH), "libbnmf_zsprof.so")
+    E.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bin", "libbnmf_zsprof.so")
     from bayesnmf_amd.setup import apply_hyperprior_params, synth_counts
     G = 10000
     M, _, _ = synth_counts(96, G, 8, 20250218)

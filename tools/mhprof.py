@@ -6,7 +6,7 @@ import sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bayesnmf_amd.engine as E  # noqa: E402
-E.LIB_PATH = os.path.join(os.path.dirname(E.LIB_PATH), "libbnmf_zsprof.so")
+E.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bin", "libbnmf_zsprof.so")
 from bayesnmf_amd.setup import apply_hyperprior_params, synth_counts  # noqa: E402
 M, _, _ = synth_counts(96, 5000, 8, 20250221)
 conv = os.environ.get("CONV", "0") == "1"

@@ -1,12 +1,12 @@
 """In-kernel section timers of k_zalloc_step (libbnmf_zpprof.so, built with -DZPPROF): share of the waves' time per section.
-Build: hipcc <Makefile flags> -DZPPROF -o bayesnmf_amd/libbnmf_zpprof.so bayesnmf_amd/csrc/api.hip     CFG=4|5  G5=columns of config 5"""
+Build: hipcc <Makefile flags> -DZPPROF -o tools/bin/libbnmf_zpprof.so bayesnmf_amd/csrc/api.hip     CFG=4|5  G5=columns of config 5"""
 import ctypes as C
 import os
 import sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bayesnmf_amd.engine as E  # noqa: E402
-E.LIB_PATH = os.path.join(os.path.dirname(E.LIB_PATH), "libbnmf_zpprof.so")
+E.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bin", "libbnmf_zpprof.so")
 from bayesnmf_amd.setup import apply_hyperprior_params, synth_counts  # noqa: E402
 
 cfg = os.environ.get("CFG", "4")

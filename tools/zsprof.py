@@ -1,12 +1,12 @@
 """In-kernel section timers of k_zalloc_sort (libbnmf_zsprof.so, built with -DZSPROF): share of the waves' time per section.
-Build: hipcc <Makefile flags> -DZSPROF -o bayesnmf_amd/libbnmf_zsprof.so bayesnmf_amd/csrc/api.hip"""
+Build: hipcc <Makefile flags> -DZSPROF -o tools/bin/libbnmf_zsprof.so bayesnmf_amd/csrc/api.hip"""
 import ctypes as C
 import os
 import sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bayesnmf_amd.engine as E  # noqa: E402
-E.LIB_PATH = os.path.join(os.path.dirname(E.LIB_PATH), "libbnmf_zsprof.so")
+E.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bin", "libbnmf_zsprof.so")
 from bayesnmf_amd.setup import apply_hyperprior_params, synth_counts  # noqa: E402
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
