@@ -352,13 +352,13 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
     if (GBc <= 64) {
       const size_t sh = zsort_shared_bytes((int)K, (int)N, KP, GBc, false), wv = zsort_wave_bytes(nblk, (int)N);
       W = 0;
-      for (int w : {16, 12, 8, 6, 4}) if (sh + (size_t)w * wv <= budget) { W = w; break; }
+      for (int w : {16, 14, 12, 8, 6, 4}) if (sh + (size_t)w * wv <= budget) { W = w; break; }
       if (W) break;
     }
     if (nb >= (long)G) break;
   }
   if (!W || GBc > 64) return 0;
-  if (const char* e = getenv("BNMF_ZSW")) { const int w = atoi(e); if (w == 4 || w == 6 || w == 8 || w == 12 || w == 16) W = w; }
+  if (const char* e = getenv("BNMF_ZSW")) { const int w = atoi(e); if (w == 4 || w == 6 || w == 8 || w == 12 || w == 14 || w == 16) W = w; }
   // columns -> blocks
   std::vector<long> ctot(G, 0);
   for (size_t g = 0; g < G; ++g) { long sacc = 0; for (size_t k = 0; k < K; ++k) sacc += M[k + K * g]; ctot[g] = sacc; }
@@ -613,7 +613,13 @@ static int build_zstep(bnmf_handle* h, const int32_t* M, int n_cu) {
 // hardware queue up at the first submission cost 15-30 ms of a 50 ms bnmf_create (a BIC sweep creates one handle per rank).
 static std::mutex g_stream_mtx;
 static std::vector<hipStream_t> g_stream_pool[64];
-static int take_stream(int device, hipStream_t* out) {
+// (Round 5, measured and NOT adopted: stream priorities.  The steady iteration is 80.6 us in most processes and 83.3 us in about a quarter
+// of them — in those the side-stream kernels run faster and the allocation kernel slower: how the queues' dispatches interleave differs
+// from process to process (tools/ablong.py, tools/bimodal.sh).  hipStreamCreateWithPriority with the main stream high and the side streams
+// low — or the reverse — makes the slow order the common one, and all three streams in one non-default class puts them on one hardware
+// queue: 106-111 us.  Plain streams it is; the allocation kernel raises its waves' issue priority instead: zalloc_sort.h.)
+static int take_stream(int device, hipStream_t* out, int kind = 0) {
+  (void)kind;
   if (device < 0 || device >= 64) return fail(BNMF_EINVAL, "device ordinal %d out of range", device);
   {
     std::lock_guard<std::mutex> lock(g_stream_mtx);
@@ -623,7 +629,8 @@ static int take_stream(int device, hipStream_t* out) {
   HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
   return 0;
 }
-static void give_stream(int device, hipStream_t st) {
+static void give_stream(int device, hipStream_t st, int kind = 0) {
+  (void)kind;
   if (!st) return;
   if (device < 0 || device >= 64) { hipStreamDestroy(st); return; }
   std::lock_guard<std::mutex> lock(g_stream_mtx);
@@ -853,8 +860,8 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
   const size_t K = cfg->K, G = cfg->G, N = cfg->N;
   CreateClock clk;
   if (int rc = take_stream(h->device, &h->stream)) return rc;
-  if (int rc = take_stream(h->device, &h->side)) return rc;
-  if (int rc = take_stream(h->device, &h->side2)) return rc;
+  if (int rc = take_stream(h->device, &h->side, 1)) return rc;
+  if (int rc = take_stream(h->device, &h->side2, 1)) return rc;
   clk.mark("streams");
   // one open file description per handle: flock() then also separates the handles of ONE process (BNMF_DEVLOCK=0: no file lock)
   h->devlock_off = getenv("BNMF_DEVLOCK") && atoi(getenv("BNMF_DEVLOCK")) == 0;
@@ -1156,7 +1163,7 @@ int bnmf_destroy(bnmf_handle* h) {
   if (h->dZsItems) dfree(h->dZsItems); if (h->dZsBlocks) dfree(h->dZsBlocks); if (h->dZsCols) dfree(h->dZsCols); if (h->dZsProf) dfree(h->dZsProf); if (h->dZsM) dfree(h->dZsM); if (h->dZsRec) dfree(h->dZsRec); if (h->dZsRecRing) dfree(h->dZsRecRing); if (h->dZsMh) dfree(h->dZsMh);
   if (h->dMhat) dfree(h->dMhat); if (h->dAccPn) dfree(h->dAccPn); if (h->dAccEpart) dfree(h->dAccEpart); if (h->dNzE) dfree(h->dNzE);
   if (h->dEt) dfree(h->dEt); if (h->dMt) dfree(h->dMt); if (h->zring) dfree(h->zring);
-  if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_rank) hipEventDestroy(h->ev_rank); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); give_stream(h->device, h->side); give_stream(h->device, h->side2);
+  if (h->ev_draw) hipEventDestroy(h->ev_draw); if (h->ev_side) hipEventDestroy(h->ev_side); if (h->ev_sideP) hipEventDestroy(h->ev_sideP); if (h->ev_p) hipEventDestroy(h->ev_p); if (h->ev_rank) hipEventDestroy(h->ev_rank); if (h->ev_z) hipEventDestroy(h->ev_z); if (h->ev_red) hipEventDestroy(h->ev_red); give_stream(h->device, h->side, 1); give_stream(h->device, h->side2, 1);
   if (h->have_ev) for (auto& e : h->ev) hipEventDestroy(e);
   if (h->dMap) dfree(h->dMap);
   if (h->dAsg) dfree(h->dAsg);
@@ -1504,6 +1511,11 @@ static void launch_side_merged(bnmf_handle* h, uint32_t t, Timer& tm) {
   if (h->dbg_side_delay_us) hipLaunchKernelGGL(k_debug_delay, dim3(1), dim3(64), 0, h->side, h->dbg_side_delay_us);   // tests: a late P-side sweep
   dbg_delay(h, h->side);
   hipLaunchKernelGGL(k_side, dim3(nbP), dim3(RT), 0, h->side, h->dev, t, nbP, N, rec_at(h, t, fused_rec(h)), SideDone{h->dFlags + 8, h->dFlags + 9, (unsigned)nbP, t});
+  // (Round 5, measured and NOT adopted: releasing the side streams by the draw kernel's flag — one polling wavefront at the head of each side
+  // stream, P / E stored write-through, no stop event on the draw kernel.  The stop event costs ~6 us between the draw kernel's end and the
+  // allocation kernel's start in the traces and its signal reaches the side queues 12-20 us later, differently from process to process
+  // (tools/bimodal.sh: steady iteration 80.6 us in most processes, 83.3 us in about a quarter) — but with the flag the side kernels start
+  // WITH the allocation kernel and take its issue slots from its first task on: 80.3 -> 96.4 us per iteration, bit-exact.)
   hipStreamWaitEvent(h->side2, h->ev_draw, 0);
   if (h->red_issued && !h->red_on_side2) hipStreamWaitEvent(h->side2, h->ev_red, 0);   // lpPn slot reuse, see launch_side_P
   dbg_delay(h, h->side2);
@@ -1609,6 +1621,7 @@ static int launch_zalloc_t(bnmf_handle* h, uint32_t t) {
 #endif
   return launch_zreg_t<SZ, ZT_, false>(h, t);
 }
+static int zs_prio() { static const int v = getenv("BNMF_ZSPRIO") ? atoi(getenv("BNMF_ZSPRIO")) : 1; return v; }   // A/B: 0 = the allocation kernel at default issue priority
 // where the item records of iteration t go (save_Z on the sorted schedule): the sample's slot of the record ring, or the one buffer
 static uint32_t* zs_rec_at(const bnmf_handle* h, uint32_t t) {
   if (!h->dZsRec) return nullptr;
@@ -1616,7 +1629,7 @@ static uint32_t* zs_rec_at(const bnmf_handle* h, uint32_t t) {
 }
 // Z[k, n, g] of iteration t from its records into h->dZ (main stream)
 static void launch_zexpand(bnmf_handle* h, uint32_t t) {
-  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->zs_it16, h->zs_qmax, zs_rec_at(h, t), nullptr, h->dZsProf};
+  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->zs_it16, h->zs_qmax, zs_rec_at(h, t), nullptr, 0, h->dZsProf};
   hipLaunchKernelGGL(k_zexpand, dim3(h->zsg.nblocks), dim3(ZX_T), h->zx_lds, h->stream, sa, h->zx_cols);
   h->z_expanded_iter = (int)t;
 }
@@ -1630,7 +1643,7 @@ static int ensure_Z(bnmf_handle* h) {
 }
 template <int ZT_>
 static int launch_zsort_t(bnmf_handle* h, uint32_t t) {
-  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->zs_it16, h->zs_qmax, zs_rec_at(h, t), h->dZsMh + (size_t)(t % 3u) * h->cfg.K * h->cfg.G, h->dZsProf};
+  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->zs_it16, h->zs_qmax, zs_rec_at(h, t), h->dZsMh + (size_t)(t % 3u) * h->cfg.K * h->cfg.G, zs_prio(), h->dZsProf};
   auto go = [&](auto kern) -> int {
     if (h->z_attr_kernel != (const void*)kern) {
       HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1661,11 +1674,13 @@ static int launch_zsort_t(bnmf_handle* h, uint32_t t) {
 }
 static int launch_zsort(bnmf_handle* h, uint32_t t) {
 #ifdef BNMF_FASTBUILD
-  if (h->zs_w != 12) return fail(BNMF_EMODEL, "BNMF_FASTBUILD: only 12 waves");
+  if (h->zs_w == 14) return launch_zsort_t<896>(h, t);
+  if (h->zs_w != 12) return fail(BNMF_EMODEL, "BNMF_FASTBUILD: only 12 or 14 waves");
   return launch_zsort_t<768>(h, t);
 #else
   switch (h->zs_w) {
     case 16: return launch_zsort_t<1024>(h, t);
+    case 14: return launch_zsort_t<896>(h, t);
     case 12: return launch_zsort_t<768>(h, t);
     case 8: return launch_zsort_t<512>(h, t);
     case 6: return launch_zsort_t<384>(h, t);

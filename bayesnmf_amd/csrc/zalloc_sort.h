@@ -44,6 +44,7 @@ struct ZSArgs {
   int it16, qmax;                    // item format; quads per item (ZS_QMAX, or ZS_QMAX16 with 2-byte items)
   uint32_t* rec;                     // save_Z: [item slot / 64][(N + 1) / 2][64] the items' histograms, two 16-bit counts per word; else null
   double* mh;                        // [G][K] Mhat of every cell, left by the lane of the cell's first item for the per-column metric terms (colterms_pair)
+  int prio;                          // raise the waves' issue priority (api.hip; BNMF_ZSPRIO=0: not)
   unsigned long long* prof;          // -DZSPROF builds only: per-section s_memtime ticks summed over the waves (diagnostics)
 };
 // -DZSPROF: section timers.  [0] block set-up, [1] thresholds, [2] quad loops, [3] histogram flush, [4] metric tasks,
@@ -60,7 +61,9 @@ struct ZSArgs {
 #define BNMF_HD __host__ __device__ inline
 BNMF_HD int zsort_zrows(int N, bool pk) { return pk ? (N + 1) / 2 : N; }
 BNMF_HD size_t zsort_shared_bytes(int K, int N, int KP, int GBc, bool pk) {
-  size_t w = (size_t)zsort_zrows(N, pk) * (KP + GBc) + (size_t)K * GBc + GBc + 4;   // zG, zK, Ms, colid, ticket (32-bit words)
+  size_t w = (size_t)zsort_zrows(N, pk) * (KP + GBc) + GBc + 4;   // zG, zK, colid, ticket (32-bit words).  (Round 5: the block's slab of M is no longer copied
+                                                                 // to LDS — since the metric tasks are gone a count is read once, by its item's lane, straight from
+                                                                 // the block-ordered copy of M: 15 KB less, which is what lets 14 waves fit beside the tables)
   w = (w + 3) & ~(size_t)3;
   return (w * 4 + ((size_t)K * N + (size_t)N * GBc) * 8 + 15) & ~(size_t)15;   // + Pl, ae (fp64); the waves' slabs are 16-byte aligned
 }
@@ -84,10 +87,10 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
   const ZSBlock bk = s.blocks[blockIdx.x];
   uint32_t* zG = (uint32_t*)smem;                          // [ZR][KP]
   uint32_t* zK = zG + (size_t)ZR * KP;                     // [ZR][GBc]
-  int* Ms = (int*)(zK + (size_t)ZR * GBc);                 // [GBc][K] counts of the block's columns
-  int* colid = Ms + (size_t)K * GBc;                       // [GBc]
+  int* colid = (int*)(zK + (size_t)ZR * GBc);              // [GBc]
   uint32_t* ticket = (uint32_t*)(colid + GBc);
-  const size_t w32 = (((size_t)ZR * (KP + GBc) + (size_t)K * GBc + GBc + 4) + 3) & ~(size_t)3;
+  const size_t w32 = (((size_t)ZR * (KP + GBc) + GBc + 4) + 3) & ~(size_t)3;
+  const int32_t* Mb = s.Mblk + (size_t)K * bk.col0;        // [ncols][K] counts of the block's columns (global memory, L2)
   double* Pl = (double*)(smem + w32 * 4);                  // [N][K]
   double* ae = Pl + (size_t)K * N;                         // [N][GBc]  A[n] E[n, column]
   unsigned char* wbase = smem + zsort_shared_bytes(K, N, KP, GBc, PK) + (size_t)wave * zsort_wave_bytes(NBLK, N);
@@ -99,36 +102,47 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
 #endif
   ZSTIC(6);
   ZSTIC(0);
-  // ---------------- block set-up.  Three independent global-memory chains (P; the block's slab of M; column ids -> E) go
-  // to different waves, so that their latencies overlap instead of adding up
+  // ---------------- block set-up.  Round 5: every lane requests ALL its loads before it uses the first.  Rounds 3-4 gave the three
+  // global-memory chains (P; the block's slab of M; column ids -> E) to different waves, one element per round trip: the copy of P was 7.5
+  // round trips in a row, an A E product two dependent ones, 3 products per lane — 9.2 us of the kernel's 55 at the set-up barrier
+  // (section timers), in front of every block's first task since the metric tasks are gone.  Now: the column ids of the lane's products, then
+  // its share of P (UP elements), then — the ids have arrived — E; the LDS writes follow.  Two round trips.
   for (int i = lane; i < 2 * HW * 64; i += 64) hist[i] = 0;
   {
-    const int job = wave % 3, jw = wave / 3, nj = (ZW - job + 2) / 3;   // waves job, job + 3, ... do this job
-    const int jt = jw * 64 + lane, jn = nj * 64;
-    if (job == 0 || ZW < 3) {
-      const int jt0 = ZW < 3 ? tid : jt, jn0 = ZW < 3 ? ZT : jn;
-      for (int i = jt0; i < K * N; i += jn0) Pl[i] = d.P[i];
-    }
-    if (job == 1 || ZW < 3) {
-      const int jt0 = ZW < 3 ? tid : jt, jn0 = ZW < 3 ? ZT : jn;
-      const int32_t* Mb = s.Mblk + (size_t)K * bk.col0;
-      for (int i = jt0; i < K * bk.ncols; i += jn0) Ms[i] = Mb[i];
-      for (int i = jt0; i < ZR * KP; i += jn0) zG[i] = 0;
-    }
-    if (job == 2 || ZW < 3) {
-      const int jt0 = ZW < 3 ? tid : jt, jn0 = ZW < 3 ? ZT : jn;
-      for (int i = jt0; i < N * bk.ncols; i += jn0) {
-        const int gl = i / N, n = i - gl * N;
-        const int g = s.cols[bk.col0 + gl];
-        ae[(size_t)n * GBc + gl] = d.A[n] * d.E[n + (size_t)N * g];
+    constexpr int UA = 2, UP = 4;                          // per lane and chunk: one chunk each at the metric configuration (800 / 1,920 elements, 768 or 896 lanes)
+    const int nP = K * N, nA = N * bk.ncols;
+    const int nchunk = max(max((nA + UA * ZT - 1) / (UA * ZT), (nP + UP * ZT - 1) / (UP * ZT)), 1);
+    for (int ch = 0; ch < nchunk; ++ch) {
+      int gcol[UA], an_i[UA], ax[UA];
+      double an[UA], pv[UP], ev[UA];
+#pragma unroll
+      for (int u = 0; u < UA; ++u) {
+        const int i = (ch * UA + u) * ZT + tid;
+        const bool ok = i < nA;
+        const int gl = ok ? i / N : 0, n = ok ? i - gl * N : 0;
+        ax[u] = ok ? n * GBc + gl : -1; an_i[u] = n;
+        gcol[u] = s.cols[bk.col0 + gl];
+        an[u] = d.A[n];
       }
-      for (int i = jt0; i < bk.ncols; i += jn0) colid[i] = s.cols[bk.col0 + i];
-      for (int i = jt0; i < ZR * GBc; i += jn0) zK[i] = 0;
-      if (jt0 == 0) *ticket = 0;
+#pragma unroll
+      for (int u = 0; u < UP; ++u) { const int i = (ch * UP + u) * ZT + tid; pv[u] = i < nP ? d.P[i] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < UA; ++u) ev[u] = d.E[an_i[u] + (size_t)N * gcol[u]];
+#pragma unroll
+      for (int u = 0; u < UP; ++u) { const int i = (ch * UP + u) * ZT + tid; if (i < nP) Pl[i] = pv[u]; }
+#pragma unroll
+      for (int u = 0; u < UA; ++u) if (ax[u] >= 0) ae[ax[u]] = an[u] * ev[u];
     }
+    for (int i = tid; i < bk.ncols; i += ZT) colid[i] = s.cols[bk.col0 + i];
+    for (int i = tid; i < ZR * KP; i += ZT) zG[i] = 0;
+    for (int i = tid; i < ZR * GBc; i += ZT) zK[i] = 0;
+    if (tid == 0) *ticket = 0;
   }
   __syncthreads();
   ZSTOC(0);
+  // The kernel is bound by instruction issue and the side streams' kernels run beside it on the same SIMDs: its waves take the issue
+  // priority (timing only).  Small side launches raise theirs to 3 (kernels.h side_body): they are few and the next draw kernel waits for them.
+  if (s.prio) __builtin_amdgcn_s_setprio(2);
   const int nthr = N - 1;
   const int ntot = bk.ntask;
   const uint32_t hlb = lds_off(hist + lane);
@@ -156,7 +170,7 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
     const bool valid = it != 0xFFFFFFFFu;
     const int k = valid ? (int)(it & 1023u) : 0, gl = valid ? (int)((it >> 10) & 63u) : 0;
     const int q0 = valid ? (int)(it >> 16) * s.qmax : 0;
-    const int m = Ms[k + (size_t)K * gl];
+    const int m = Mb[k + (size_t)K * gl];
     const int g = colid[gl];
     int nq = 0, npad = 0;
     bool any = false;
