@@ -13,6 +13,7 @@ def same_bits(a, b):
     a_[nn] = 0.0; b_[nn] = 0.0
     return np.array_equal(a_.view(np.uint64), b_.view(np.uint64))
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
+rng_big = np.random.default_rng(7919 + int(os.environ.get("FUZZ_SEED", "1")))    # (its own stream: the cases of a seed stay what they were)
 n_cases = int(os.environ.get("FUZZ_N", "60"))
 bad = 0
 t0 = time.time()
@@ -28,6 +29,9 @@ for case in range(n_cases):
     M = rng.poisson(rng.gamma(0.7, 10.0, size=(K, G))).astype(np.int32)
     if rng.random() < 0.3: M[:, rng.integers(0, G)] = 0
     if rng.random() < 0.3: M[rng.integers(0, K), :] = 0
+    if rng_big.random() < 0.25:                           # a few large cells: the sorted schedule exports their fragments to other blocks
+        for _ in range(int(rng_big.integers(1, 5))):
+            M[rng_big.integers(0, K), rng_big.integers(0, G)] = int(rng_big.integers(8_193, 150_000))
     kw = dict(seed=int(rng.integers(1, 1000)), learning_rank=lr)
     save_Z = bool(rng.random() < 0.4) and model in ("gamma", "exponential")      # full mode of the Gibbs sweep: Z itself is compared
     if save_Z: kw["save_Z"] = True
