@@ -132,6 +132,9 @@ struct bnmf_handle {
   bool red_on_side2 = false;           // the last k_reduce was issued on side2 (then side2 needs no event to be ordered behind it)
   double* E_alt = nullptr;             // Gibbs sweep: the other E buffer (k_edraw of t+1 does not overwrite what k_lpe of t still reads)
   bool mh_prep_valid = false;          // MH / Normal models: Et, nzE are current and nzP is zero (k_mh_tail of the previous iteration)
+  bool mh_pipe = false;                // Poisson MH models at fixed rank through k_mh_ecol16: what followed the two sweeps is hosted BY them (mh.h; BNMF_MHPIPE=0: k_mh_tail)
+  bool mh_pipe_valid = false;          // ... and its Et / parity flag buffers are current
+  uint32_t mh_etail_pending = 0;       // ... the iteration whose E side (hyper sweep of the next, log-prior, record) has not been issued yet
   const void* z_attr_kernel = nullptr;   // allocation kernel whose dynamic-LDS limit has been raised for this handle
   bool red_pending = false, red_issued = false; uint32_t red_t = 0; int red_row = 0;   // k_reduce of the previous iteration, issued late
   int iter = 0;
@@ -1078,9 +1081,12 @@ static int create_impl(const bnmf_config* cfg, const int32_t* M, bnmf_handle* h)
         for (const void* kf : ks) HIPCHK(hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       }
     }
+    // Round 5: k_mh_tail's work hosted by the two sweep kernels (mh.h) — the Poisson MH models at fixed rank where the column sweep is k_mh_ecol16
+    h->mh_pipe = h->mhe16 && cfg->MH && cfg->likelihood == BNMF_POISSON && !cfg->learning_rank && h->mh_side_main && h->mh_side_tail && N <= RT;
+    if (const char* e = getenv("BNMF_MHPIPE")) h->mh_pipe = h->mh_pipe && atoi(e) != 0;      // diagnostics / tests: 0 = k_mh_tail between the sweeps
     HIPCHK(dmalloc(&h->dAccPn, 3 * N * sizeof(double)));
     HIPCHK(dmalloc(&h->dAccEpart, 3 * (size_t)h->nblkE * sizeof(double)));
-    HIPCHK(dmalloc(&h->dNzE, 2 * N * sizeof(int)));
+    HIPCHK(dmalloc(&h->dNzE, 6 * N * sizeof(int)));         // nzE[N], nzP[N] (k_mh_tail's), then the hosted form's nzE[2][N], nzP[2][N] by iteration parity
     HIPCHK(dmalloc(&h->dEt, N * G * sizeof(double)));
     HIPCHK(dmalloc(&h->dMt, K * G * sizeof(int32_t)));
     {
@@ -1284,7 +1290,7 @@ int bnmf_set_array(bnmf_handle* h, int id, const double* x, size_t n) {
   HIPCHK(hipStreamSynchronize(h->side2));
   clk.mark("set_array: sync side2");
   h->side_valid = false; h->side_main = false;   // state changed: the pre-issued k_side must be redone
-  h->mh_prep_valid = false;
+  h->mh_prep_valid = false; h->mh_pipe_valid = false;
   if (id == BNMF_R) { int r = (int)x[0]; HIPCHK(hipMemcpy(h->dR, &r, sizeof(int), hipMemcpyHostToDevice)); h->arr[BNMF_R].set = true; return 0; }
   if (id == BNMF_ZSUMK || id == BNMF_ZSUMG || id == BNMF_Z) {
     int32_t* dst = id == BNMF_ZSUMK ? h->dZsumK : id == BNMF_ZSUMG ? h->dZsumG : h->dZ;
@@ -1405,6 +1411,7 @@ int bnmf_get_stat(bnmf_handle* h, int what, double* out) {   // sizes of the sch
     case 1: *out = h->dZsMh ? (double)h->cfg.K * h->cfg.G * 8.0 : 0.0; return 0;            // bytes of Mhat left per iteration for the column terms
     case 2: *out = h->dZsRecRing ? 1.0 : 0.0; return 0;                                     // samples$Z kept as a ring of records
     case 3: *out = h->zs_eager ? 1.0 : 0.0; return 0;
+    case 4: *out = h->mh_pipe ? 1.0 : 0.0; return 0;                                        // MH sweep: k_mh_tail's work hosted by the two sweep kernels
     default: return fail(BNMF_EINVAL, "bnmf_get_stat: unknown statistic %d", what);
   }
 }
@@ -1930,20 +1937,34 @@ static void flush_reduce(bnmf_handle* h, Timer& tm) {
   h->red_pending = false;
 }
 // P and E updates of the MH models (R/sample_params.R:56-64 with sample_Pn/_En -> *_normal -> MH_*_poisson)
-static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged, bool poll = false) {
+struct MhPipe { MhETail et; MhPTail pt; };
+static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged, bool poll = false, const MhPipe* pp = nullptr) {
   const int K = h->cfg.K, N = h->cfg.N, G = h->cfg.G, S = h->mh_S;
   const bool normal = h->cfg.likelihood == BNMF_NORMAL;
   const int mhstep = (h->cfg.MH && converged && !normal) ? 1 : 0;
-  if (!h->mh_prep_valid) {                                   // first sweep after init / set_array; afterwards k_mh_tail prepares them
+  if (pp) {
+    if (!h->mh_pipe_valid) {                                 // first hosted sweep after init / set_array / a sweep of the other form
+      hipMemsetAsync(h->dNzE + 2 * N, 0, 4 * N * sizeof(int), h->stream);
+      hipLaunchKernelGGL(k_mh_nz, dim3(N), dim3(256), 0, h->stream, h->dev, h->dNzE + 2 * N + ((t - 1) & 1u) * N);
+      h->mh_pipe_valid = true; h->mh_prep_valid = false;
+    }
+  } else if (!h->mh_prep_valid) {                            // first sweep after init / set_array; afterwards k_mh_tail prepares them
     hipMemsetAsync(h->dNzE, 0, 2 * N * sizeof(int), h->stream);         // nzE[N], nzP[N]
     hipLaunchKernelGGL(k_mh_nz, dim3(N), dim3(256), 0, h->stream, h->dev, h->dNzE);
-    h->mh_prep_valid = true;
+    h->mh_prep_valid = true; h->mh_pipe_valid = false;
   }
   double* accP = h->arr[BNMF_ACC_P].d; double* accE = h->arr[BNMF_ACC_E].d;
   const bool regP = S <= MHP_W;                              // one 320-column segment per wave: the row's cells stay in registers
   const size_t ldsP = (4 * (size_t)S + 2 * N + 2 + (size_t)(PRE_W + 2) * N + ((regP && mhstep) ? (size_t)MH_CPL * MHP_T : 0)) * sizeof(double);
-  auto goP = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(K), dim3(MHP_T), ldsP, h->stream, h->dev, t, S, (const int*)h->dNzE, h->dNzE + N, accP, h->dMhat, h->dMhat + (size_t)K * h->cfg.G,
-                                                poll ? SideWait{h->dFlags + 1, h->dFlags + 1, t, h->dErr} : SideWait{}); };
+  const bool pipe = pp != nullptr;                         // hosted form (sweep_mh): parity flag buffers, hosted workgroups behind the rows / the column blocks
+  int* const nzb = h->dNzE + 2 * N;                        // nzE[2][N], nzP[2][N]
+  const int* nzE_in = pipe ? nzb + ((t - 1) & 1u) * N : h->dNzE;
+  int* nzP_io = pipe ? nzb + 2 * N + (t & 1u) * N : h->dNzE + N;
+  const MhETail et = pipe ? pp->et : MhETail{};
+  const int nhostP = pipe ? mh_etail_groups(et, N, MHP_T / ES_T) : 0;
+  const size_t ldsPx = pipe ? std::max<size_t>(ldsP, MHP_T * sizeof(double)) : ldsP;
+  auto goP = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(K + nhostP), dim3(MHP_T), ldsPx, h->stream, h->dev, t, S, nzE_in, nzP_io, accP, h->dMhat, h->dMhat + (size_t)K * h->cfg.G,
+                                                poll ? SideWait{h->dFlags + 1, h->dFlags + 1, t, h->dErr} : SideWait{}, et); };
   if (normal) { if (regP) goP(k_mh_prow<true, true, false>); else goP(k_mh_prow<true, false, false>); }
   else if (mhstep) { if (regP) goP(k_mh_prow<false, true, true>); else goP(k_mh_prow<false, false, true>); }
   else { if (regP) goP(k_mh_prow<false, true, false>); else goP(k_mh_prow<false, false, false>); }
@@ -1953,7 +1974,11 @@ static void launch_mh_PE(bnmf_handle* h, uint32_t t, int converged, bool poll = 
     const int gw = h->mhe_gw ? h->mhe_gw : (mhstep ? 32 : 16), cpw = 64 / gw;
     int g16 = ((G + cpw - 1) / cpw + 3) / 4; if (g16 > 2048) g16 = 2048;
     const size_t lds16 = (4 * (size_t)cpw * N * (1 + PRE_W) + 2 * (size_t)N) * sizeof(double);
-    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)(h->dNzE + N), accE, 0); };
+    const MhPTail pt = pipe ? pp->pt : MhPTail{};
+    const int nhostE = pipe ? mh_ptail_blocks(pt, N, h->cfg.MH) : 0;
+    const size_t lds16x = pipe ? std::max<size_t>(lds16, RT * sizeof(double)) : lds16;
+    int* nzE_set = pipe ? nzb + (t & 1u) * N : nullptr;
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(g16 + nhostE), dim3(MHE_T), lds16x, h->stream, h->dev, t, (const int*)nzP_io, accE, 0, nzE_set, g16, pt); };
     if (K <= 96 && !h->mhe_k128) {                         // register arrays for 96 rows (BNMF_MHE_K128=1: the 128-row form)
       if (gw == 16) { if (mhstep) go(k_mh_ecol16<false, true, 16, 96>); else go(k_mh_ecol16<false, false, 16, 96>); }
       else { if (mhstep) go(k_mh_ecol16<false, true, 32, 96>); else go(k_mh_ecol16<false, false, 32, 96>); }
@@ -1972,10 +1997,10 @@ static int launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells, bool with_r
       int g16 = ((G + cpw - 1) / cpw + 3) / 4; if (g16 > 2048) g16 = 2048;
       const size_t lds16 = (4 * (size_t)cpw * N * (1 + PRE_W) + 2 * (size_t)N) * sizeof(double);
       const bool k96 = h->cfg.K <= 96 && !h->mhe_k128;
-      if (gw == 16 && k96) hipLaunchKernelGGL((k_mh_ecol16<true, false, 16, 96>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
-      else if (gw == 16) hipLaunchKernelGGL((k_mh_ecol16<true, false, 16>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
-      else if (k96) hipLaunchKernelGGL((k_mh_ecol16<true, false, 32, 96>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
-      else hipLaunchKernelGGL((k_mh_ecol16<true, false, 32>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
+      if (gw == 16 && k96) hipLaunchKernelGGL((k_mh_ecol16<true, false, 16, 96>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig, (int*)nullptr, g16, MhPTail{});
+      else if (gw == 16) hipLaunchKernelGGL((k_mh_ecol16<true, false, 16>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig, (int*)nullptr, g16, MhPTail{});
+      else if (k96) hipLaunchKernelGGL((k_mh_ecol16<true, false, 32, 96>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig, (int*)nullptr, g16, MhPTail{});
+      else hipLaunchKernelGGL((k_mh_ecol16<true, false, 32>), dim3(g16), dim3(MHE_T), lds16, h->stream, h->dev, t, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig, (int*)nullptr, g16, MhPTail{});
     } else {
       int grid = (G + 3) / 4; if (grid > 2048) grid = 2048;
       hipLaunchKernelGGL(k_mh_ecol<true>, dim3(grid), dim3(MHE_T), h->mhe_lds, h->stream, h->dev, t, 0, (const int*)nullptr, h->arr[BNMF_ACC_E].d, draw_sig);
@@ -2005,7 +2030,84 @@ static int launch_mh_metrics(bnmf_handle* h, uint32_t t, bool cells, bool with_r
   h->mh_prep_valid = true;
   return 0;
 }
+// record_sample's arrays of iteration t in two groups: what the row sweep of t + 1 rewrites (P, its prior parameters of t, its acceptance
+// rates: copied beside the column sweep of t) and the rest (copied beside the row sweep of t + 1)
+static int record_args_split(bnmf_handle* h, uint32_t t, RecArgs& raP, RecArgs& raE) {
+  RecArgs ra;
+  if (int rc = record_args(h, t, ra)) return rc;
+  raP = RecArgs{}; raE = RecArgs{};
+  raE.R = ra.R; raE.Rdst = ra.Rdst;
+  const int pids[] = {BNMF_P, BNMF_ACC_P, BNMF_MU_P, BNMF_SIGMASQ_P, BNMF_LAMBDA_P, BNMF_ALPHA_P, BNMF_BETA_P};
+  for (int j = 0; j < ra.n; ++j) {
+    bool isP = false;
+    for (int id : pids) { const Arr& a = h->arr[id]; if (a.ring && ra.dst[j] >= a.ring && ra.dst[j] < a.ring + (size_t)h->wcap * id_len(h, id)) isP = true; }
+    RecArgs& o = isP ? raP : raE;
+    o.src[o.n] = ra.src[j]; o.dst[o.n] = ra.dst[j]; o.len[o.n] = ra.len[j]; o.n++;
+  }
+  return 0;
+}
+static MhETail mh_etail_args(bnmf_handle* h, uint32_t te, uint32_t t_next, int& rc) {   // the E side of iteration te (0: none pending); t_next: the iteration of the next column sweep
+  const int N = h->cfg.N;
+  MhETail et{};
+  rc = 0;
+  et.nz_zero = h->dNzE + 2 * N + (t_next & 1u) * N;
+  if (!te) return et;
+  RecArgs raP;
+  if ((rc = record_args_split(h, te, raP, et.ra))) return et;
+  et.on = 1; et.t = te;
+  et.nbE = (int)(((size_t)N * h->cfg.G + RT - 1) / RT); et.nblkE = h->nblkE;
+  et.nrec = (et.ra.n > 0 || et.ra.Rdst) ? 128 : 0;
+  et.accE = h->arr[BNMF_ACC_E].d; et.accE_part = accEp_slot(h, te); et.lpE_part = h->dlpE + (size_t)(te % 3u) * h->nblkE;
+  return et;
+}
+// the E side of the last iteration of a call: no row sweep behind it
+static int flush_mh_etail(bnmf_handle* h) {
+  if (!h->mh_etail_pending) return 0;
+  int rc = 0;
+  const MhETail et = mh_etail_args(h, h->mh_etail_pending, h->mh_etail_pending + 1, rc);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_mh_etail, dim3(mh_etail_groups(et, h->cfg.N, 4)), dim3(1024), 0, h->stream, h->dev, et);
+  h->mh_etail_pending = 0;
+  return 0;
+}
+// The hosted form of the sweep (Poisson MH models at fixed rank, k_mh_ecol16): two launches per iteration, k_mh_tail's work inside them (mh.h)
+static int sweep_mh_pipe(bnmf_handle* h, int row, int converged, Timer& tm) {
+  h->iter += 1;
+  const uint32_t t = (uint32_t)h->iter;
+  const int N = h->cfg.N;
+  use_slot(h, t);
+  if (!h->side_valid) launch_side(h, t, tm);              // first sweep after init / set_array: the prior parameters of t on the side streams
+  if (!h->side_main) { refresh_side_events(h); hipStreamWaitEvent(h->stream, h->ev_side, 0); hipStreamWaitEvent(h->stream, h->ev_sideP, 0); }
+  MhPipe pp{};
+  int rc = 0;
+  pp.et = mh_etail_args(h, h->mh_etail_pending, t, rc);
+  if (rc) return rc;
+  MhPTail& pt = pp.pt;
+  pt.on = 1; pt.t = t;
+  pt.nbP = (int)(((size_t)h->cfg.K * N + RT - 1) / RT);
+  RecArgs raE;
+  if ((rc = record_args_split(h, t, pt.ra, raE))) return rc;
+  pt.nrec = pt.ra.n > 0 ? 8 : 0;
+  pt.accP = h->arr[BNMF_ACC_P].d; pt.accPn = accPn_slot(h, t);
+  pt.nblkE = h->nblkE;
+  pt.nz_zero = h->dNzE + 2 * N + 2 * N + ((t + 1) & 1u) * N;
+  if (h->red_pending) {                                    // k_reduce's work for the iteration before: its E-side sums are issued with pp.et above
+    Dev dr = h->dev;
+    set_slot(h, dr, h->red_t);
+    pt.rs = RedSlots{dr.colsse, dr.colll, dr.colkl, dr.lpE_part, dr.lpPn, accPn_slot(h, h->red_t), accEp_slot(h, h->red_t), h->red_row, 1};
+    h->red_pending = false;
+  }
+  dbg_delay_main(h);
+  launch_mh_PE(h, t, converged, false, &pp);
+  dbg_delay_main(h);
+  h->mh_etail_pending = t;
+  h->flags_valid = false; h->side_valid = true; h->side_main = true;
+  launch_reduce(h, t, row, tm);
+  return 0;
+}
 static int sweep_mh(bnmf_handle* h, int row, int converged, Timer& tm) {
+  if (h->mh_pipe && !tm.on) return sweep_mh_pipe(h, row, converged, tm);
+  if (int rc = flush_mh_etail(h)) return rc;
   h->iter += 1;
   const uint32_t t = (uint32_t)h->iter;
   use_slot(h, t);
@@ -2145,7 +2247,7 @@ int bnmf_init(bnmf_handle* h, double* metrics_row1) {
     HIPCHK(hipMemset(h->dZsumK, 0, (size_t)h->cfg.N * h->cfg.G * sizeof(int32_t)));
     HIPCHK(hipMemset(h->dZsumG, 0, (size_t)h->cfg.K * h->cfg.N * sizeof(int32_t)));
     h->side_valid = false; h->side_main = false; h->flags_valid = false; h->z_gate_next = 0; h->z_gated_for = 0; h->gate_f0 = 1;
-    h->side_ev_stale = false; h->red_on_side2 = false; h->red_pending = false; h->red_issued = false; h->mh_prep_valid = false; h->ct_pending = 0; h->z_expanded_iter = 0;
+    h->side_ev_stale = false; h->red_on_side2 = false; h->red_pending = false; h->red_issued = false; h->mh_prep_valid = false; h->mh_pipe_valid = false; h->mh_etail_pending = 0; h->ct_pending = 0; h->z_expanded_iter = 0;
     h->inited = false;
   }
   const bnmf_config& c = h->cfg;
@@ -2295,6 +2397,7 @@ static int run_impl(bnmf_handle* h, int n_iter, int converged, double* metrics, 
   if (runclock) rc_issued = rc_us();
   const bool reduces_on_side2 = h->red_on_side2;          // fixed-rank sweep: every earlier k_reduce sits on side2, which flush_reduce's wait covers
   flush_colterms(h);                                       // the last iteration's column terms: no draw kernel behind it in this call
+  if (int rc = flush_mh_etail(h)) return rc;              // (hosted MH sweep) the last iteration's E side: no row sweep behind it in this call
   // Round 5: the main stream waits for EVERYTHING issued on the two side streams (a fresh event each) in front of the last reduction:
   // when it is idle so are they, and the two host-side synchronisations of idle streams that stood below (6 us each, at the end of
   // every call) are gone.  (flush_reduce's own wait for side2 is then a wait for an event that has fired.)

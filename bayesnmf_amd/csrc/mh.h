@@ -99,6 +99,121 @@ BNMF_DEV double mh_prior_or_cond_pre(const Dev& d, int e, uint32_t t, bool use_p
   return rtnorm0_pre(s, q.r, mu, dsqrt(var));
 }
 
+// ---- Round 5: what followed the two sweeps (k_mh_tail, below) as workgroups HOSTED by the sweep kernels themselves ----
+// k_mh_tail ran alone between the column sweep of t and the row sweep of t + 1 (18 us of config 3's 187).  Nothing in it needs both
+// sweeps: what reads P_t (the P-side hyper sweep of t + 1, the log-prior of P_t, its acceptance sums, record_sample's P-side arrays)
+// can run BESIDE the column sweep of t, which leaves P alone; what reads E_t (the E-side hyper sweep of t + 1, the log-prior of E_t,
+// Esum, record_sample's other arrays) BESIDE the row sweep of t + 1, which leaves E alone and occupies 96 of the 256 CUs.  The
+// hand-overs are the kernel boundaries themselves: no flag, no second stream.  What the row sweep needs of E_t — its transpose Et and
+// the all(E[n, ] == 0) flags — the column sweep writes as it finishes a column; the flags live in two buffers by iteration parity
+// (ecol(t) sets nzE[t & 1], prow(t + 1) reads it; prow(t) counts into nzP[t & 1], ecol(t) reads it) and the hosted workgroups clear
+// the buffer of the other parity.  k_reduce's work for iteration t - 1 rides beside the column sweep of t, as it rode in k_mh_tail(t).
+struct MhETail {             // E side of iteration t: hosted by k_mh_prow of t + 1 (or k_mh_etail at the end of a call)
+  int on;                    // 0: only the clearing of nz_zero
+  uint32_t t;
+  int nbE, nblkE, nrec;      // 256-lane units of the E-side hyper sweep, of the log-prior sums, of the record copy
+  const double* accE; double* accE_part; double* lpE_part;    // (the slots of iteration t: the hosting launch carries those of t + 1)
+  RecArgs ra;
+  int* nz_zero;              // [N] the flags the NEXT column sweep sets
+};
+struct MhPTail {             // P side of iteration t: hosted by the column sweep of t
+  int on;
+  uint32_t t;
+  int nbP, nrec;
+  const double* accP; double* accPn;
+  RecArgs ra;
+  RedSlots rs; int nblkE;    // k_reduce's work for the iteration before (rs.on)
+  int* nz_zero;              // [N] the counters the NEXT row sweep adds to
+};
+inline int mh_etail_groups(const MhETail& x, int N, int Q) {   // hosted workgroups of Q 256-lane units each (roles padded to whole workgroups)
+  if (!x.on) return 1;
+  return (x.nbE + Q - 1) / Q + (x.nblkE + Q - 1) / Q + (N + Q - 1) / Q + (x.nrec + Q - 1) / Q + 1;
+}
+inline int mh_ptail_blocks(const MhPTail& x, int N, int MH) { return !x.on ? 1 : x.nbP + N + x.nrec + 1 + (x.rs.on ? (MH ? 5 : 4) : 0); }
+// T lanes = T / 256 units side by side; every lane of the workgroup takes the same role (the roles' barriers are workgroup barriers)
+template <int T>
+BNMF_DEV void mh_etail_body(const Dev& d, const MhETail& x, int hw, int tid, double* buf) {
+  constexpr int Q = T / ES_T;
+  static_assert(ES_T == RT, "one unit width for the hyper sweep's, the log-prior's and the reductions' blocks");
+  if (!x.on) { if (tid < d.N) x.nz_zero[tid] = 0; return; }
+  const int q = tid / ES_T, lt = tid % ES_T;
+  double* qb = buf + q * ES_T;
+  const int wE = (x.nbE + Q - 1) / Q, wL = (x.nblkE + Q - 1) / Q, wS = (d.N + Q - 1) / Q, wR = (x.nrec + Q - 1) / Q;
+  if (hw < wE) {                                            // hyper sweep of the E-side prior parameters of t + 1 (k_side's E part)
+    const long e = ((long)hw * Q + q) * RT + lt;
+    if (e < (long)d.lenE) hyper_elem<1>(d, (int)e, x.t + 1, d.E[e], nullptr, nullptr);
+    return;
+  }
+  hw -= wE;
+  if (hw < wL) {                                            // log-prior / acceptance partial sums of 256 elements of E_t (k_lp_e)
+    const int be = hw * Q + q;
+    const long e = (long)be * ES_T + lt;
+    double lp = 0.0, ac = 0.0;
+    if (be < x.nblkE && e < (long)d.lenE) {
+      lp = prior_logdens<1>(d, (int)e, d.E[e], x.t);
+      if (x.accE) ac = (d.A[e % d.N] == 1.0) ? x.accE[e] : 0.0;
+    }
+    const double r = block_tree<ES_T>(lp, qb, lt);
+    if (lt == 0 && be < x.nblkE) x.lpE_part[be] = r;
+    if (x.accE) {
+      __syncthreads();
+      const double r2 = block_tree<ES_T>(ac, qb, lt);
+      if (lt == 0 && be < x.nblkE) x.accE_part[be] = r2;
+    }
+    return;
+  }
+  hw -= wL;
+  if (hw < wS) {                                            // Esum of t + 1 (k_side's first blocks)
+    const int n = hw * Q + q;
+    const bool ok = n < d.N;
+    const double r = canon1024_by256(d.E + (ok ? n : 0), ok ? (long)d.G : 0L, d.N, qb, lt);
+    if (ok && lt == 0) st_wt(&d.Esum[n], r);
+    return;
+  }
+  hw -= wS;
+  if (hw < wR) {                                            // record_sample of t: every array but the P-side ones
+    const size_t rt = (size_t)hw * T + tid, nth = (size_t)wR * T;
+    for (int j = 0; j < x.ra.n; ++j)
+      for (size_t i = rt; i < x.ra.len[j]; i += nth) x.ra.dst[j][i] = x.ra.src[j][i];
+    if (rt == 0 && x.ra.Rdst) *x.ra.Rdst = (double)*x.ra.R;
+    return;
+  }
+  if (tid < d.N) x.nz_zero[tid] = 0;
+}
+BNMF_DEV void mh_ptail_body(const Dev& d, const MhPTail& x, int hb, int tid, double* buf) {   // one 256-lane block
+  if (!x.on) { if (tid < d.N) x.nz_zero[tid] = 0; return; }
+  if (hb < x.nbP) {                                         // hyper sweep of the P-side prior parameters of t + 1 (k_side's P part)
+    const long e = (long)hb * RT + tid;
+    if (e < (long)d.lenP) hyper_elem<0>(d, (int)e, x.t + 1, d.P[e], nullptr, nullptr);
+    return;
+  }
+  hb -= x.nbP;
+  if (hb < d.N) {                                           // log-prior of column n of P_t and its acceptance sum (k_lp_p)
+    if (tid >= 64) return;
+    const int n = hb;
+    double a = 0.0, b = 0.0;
+    for (int k = tid; k < d.K; k += 64) { const int e = k + d.K * n; a = a + prior_logdens<0>(d, e, d.P[e], x.t); if (x.accP) b = b + x.accP[e]; }
+    a = wave_tree64(a); b = wave_tree64(b);
+    if (tid == 0) { d.lpPn[n] = a; if (x.accPn) x.accPn[n] = b; }
+    return;
+  }
+  hb -= d.N;
+  if (hb < x.nrec) {                                        // record_sample of t: the P-side arrays
+    const size_t rt = (size_t)hb * ES_T + tid, nth = (size_t)x.nrec * ES_T;
+    for (int j = 0; j < x.ra.n; ++j)
+      for (size_t i = rt; i < x.ra.len[j]; i += nth) x.ra.dst[j][i] = x.ra.src[j][i];
+    return;
+  }
+  hb -= x.nrec;
+  if (hb == 0) { if (tid < d.N) x.nz_zero[tid] = 0; return; }
+  if (x.rs.on) reduce_body(d, x.rs, x.nblkE, hb - 1, buf, tid);
+}
+// the E side of the LAST iteration of a call (no row sweep behind it to host it)
+__global__ __launch_bounds__(1024) void k_mh_etail(Dev d, MhETail x) {
+  __shared__ double buf[1024];
+  mh_etail_body<1024>(d, x, (int)blockIdx.x, (int)threadIdx.x, buf);
+}
+
 // nzE[n] = number of non-zero entries in row n of E (all(E[n,] == 0) test of sample_Pn_normal :56); also writes
 // the transpose Et[g + G n] = E[n, g] that the P-side kernels read (E is constant during the P updates): there a
 // wave's lanes walk consecutive columns g of ONE row, and E[n + N g] / M[k + K g] would be 64 cache lines per load
@@ -135,13 +250,17 @@ constexpr int MH_CPL = MH_SEG / 64;                       // cells per lane and 
 // exposures stay in registers for the whole sweep, the next factor's exposures are requested one factor ahead; otherwise
 // Mhat lives in `mhrow`.
 template <bool NORMAL, bool REG, bool MHSTEP /* the Metropolis-Hastings step runs (after convergence) */>
-__global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, const int* nzE, int* nzP, double* accP, double* mhrow, double* mhlog, SideWait sw) {
+__global__ __launch_bounds__(MHP_T) void k_mh_prow(Dev d, uint32_t t, int S, const int* nzE, int* nzP, double* accP, double* mhrow, double* mhlog, SideWait sw, MhETail et) {
   constexpr int mhstep = MHSTEP ? 1 : 0;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (!NORMAL && (int)blockIdx.x >= d.K) {              // hosted: the E side of what followed the column sweep of t - 1 (the rows come first in the grid)
+    if (!NORMAL) mh_etail_body<MHP_T>(d, et, (int)blockIdx.x - d.K, (int)threadIdx.x, (double*)smem);
+    return;
+  }
 #ifdef ZSPROF
   const unsigned long long mhsK0 = __builtin_amdgcn_s_memrealtime();
 #endif
   side_wait(sw, threadIdx.x);                           // prior parameters of iteration t (k_side on the side stream)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = d.K, G = d.G, N = d.N, k = blockIdx.x;
   double* part = (double*)smem;                         // [4][S] segment partial sums
@@ -548,12 +667,16 @@ BNMF_DEV double grp_bcast0(double v, int lane) {          // lane 0 of the group
 // KM: the rows the lanes' register arrays are sized for — 128, or 96 (the 96 trinucleotide contexts: a quarter fewer registers and no empty
 // rounds over rows 96..127; the kernel sits at the edge of two waves per SIMD)
 template <bool METRICS_ONLY, bool MHSTEP, int GW, int KM = MHE16_KMAX>
-__global__ __launch_bounds__(MHE_T) void k_mh_ecol16(Dev d, uint32_t t, const int* nzP, double* accE, int draw_sig) {
+__global__ __launch_bounds__(MHE_T) void k_mh_ecol16(Dev d, uint32_t t, const int* nzP, double* accE, int draw_sig, int* nzE_set, int ncolblk, MhPTail pt) {
   constexpr int MHE16_RPL = KM / GW;                      // rows per lane
   constexpr int NS = 64 / GW;                             // accumulator slots per lane
   constexpr int CPW = 64 / GW;                            // columns per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (!METRICS_ONLY && (int)blockIdx.x >= ncolblk) {      // hosted: the P side of what followed the sweeps (behind the column blocks in the grid)
+    if (!METRICS_ONLY) mh_ptail_body(d, pt, (int)blockIdx.x - ncolblk, tid, (double*)smem);
+    return;
+  }
   const int j = lane % GW, grp = lane / GW;
   const int K = d.K, G = d.G, N = d.N;
   double* ec = (double*)smem + (size_t)(wave * CPW + grp) * N * (1 + PRE_W);   // [N] current column of E, one per group
@@ -566,7 +689,7 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol16(Dev d, uint32_t t, const in
   const double LOG1 = dlog(1.0);
   const bool normal = d.likelihood == BNMF_NORMAL;
   const int ngrp = (G + CPW - 1) / CPW;                       // sets of CPW columns
-  for (int gq = blockIdx.x * (MHE_T / 64) + wave; gq < ngrp; gq += gridDim.x * (MHE_T / 64)) {
+  for (int gq = blockIdx.x * (MHE_T / 64) + wave; gq < ngrp; gq += ncolblk * (MHE_T / 64)) {
     MHSTAMP(S0);
     const int g = gq * CPW + grp;
     const bool live = g < G;                                  // a row beyond G works on column G - 1 and writes nothing
@@ -698,6 +821,10 @@ __global__ __launch_bounds__(MHE_T) void k_mh_ecol16(Dev d, uint32_t t, const in
 #endif
       }
     }
+    // (round 5) what the NEXT row sweep needs of the finished column: its row of the transpose and the all(E[n, ] == 0) flags (k_mh_tail's
+    // Et blocks counted the non-zero entries; the sweeps only ask whether there are any)
+    if (!METRICS_ONLY && nzE_set && live)
+      for (int i = j; i < N; i += GW) { const double x = ec[i]; d.Et[g + (size_t)G * i] = x; if (x != 0.0) nzE_set[i] = 1; }
     // fresh Mhat of the (updated) column: residuals for sigmasq, then the metric terms (R/utils.R:412-471)
     double cfresh[MHE16_RPL];
 #pragma unroll

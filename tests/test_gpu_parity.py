@@ -487,6 +487,49 @@ def test_mh_chain_bitexact(prior, G, gw, monkeypatch):
     assert (acc >= 0).all() and (acc <= 1).all() and acc.mean() > 0.5
 
 
+@pytest.mark.parametrize("prior", ["truncnormal", "exponential"])
+def test_mh_sweep_hosting_what_followed_it_matches_the_tail_kernel(prior, monkeypatch):
+    """Round 5: k_mh_tail ran alone between the column sweep of t and the row sweep of t + 1.  Its P side (hyper
+    sweep of t + 1, log-prior, acceptance sums, record_sample's P-side arrays, k_reduce of t - 1) is now hosted by the column sweep of t, its E
+    side by the row sweep of t + 1 — or by k_mh_etail at the end of a call.  Calls of several lengths (the E side of a call's last iteration is
+    flushed, the others are hosted), both phases, with a window: every recorded array of every retained sample, the current state and the
+    metric rows bit-identical to the oracle (R/bayesNMF_sampler.R:268-330, :651-672), and to the form with k_mh_tail (BNMF_MHPIPE=0)."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    M, _, _ = synth_counts(96, 333, 4, 20250223)
+    N, W = 7, 6
+    pp = ["Mu_p", "Sigmasq_p", "Mu_e", "Sigmasq_e"] if prior == "truncnormal" else ["Lambda_p", "Lambda_e"]
+    names = ["P", "E", "P_acceptance_rate", "E_acceptance_rate"] + pp
+    o = O.Oracle(M, N, prior=prior, MH=True, seed=9, nthreads=8)
+    apply_hyperprior_params(o, prior, M, N)
+    o.init()
+    calls = [(4, False), (1, False), (5, False), (3, True), (6, True), (2, True)]
+    hist, rows, it = {1: {nm: o.get(nm).copy() for nm in names}}, [], 1
+    for n, conv in calls:
+        for _ in range(n):
+            rows.append(o.run(1, converged=conv)[0].copy()); it += 1
+            hist[it] = {nm: o.get(nm).copy() for nm in names}
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("BNMF_MHPIPE", pipe)
+        e = Engine(M, N, prior=prior, MH=True, seed=9, window=W)
+        assert e.stat(4) == float(pipe == "1")
+        apply_hyperprior_params(e, prior, M, N)
+        e.init()
+        it, r = 1, 0
+        for n, conv in calls:
+            me = e.run(n, converged=conv)
+            assert np.array_equal(np.stack(rows[r:r + n]).view(np.uint64), me.view(np.uint64)), (pipe, it)
+            it += n; r += n
+            for nm in names:
+                assert np.array_equal(hist[it][nm].view(np.uint64), e.get(nm).view(np.uint64)), (nm, it, pipe)
+                win = e.window(nm, min(W, it))
+                for j, i2 in enumerate(range(it - min(W, it) + 1, it + 1)):
+                    assert np.array_equal(win[j].view(np.uint64), hist[i2][nm].view(np.uint64)), (nm, i2, it, pipe)
+        e.close()
+    o.close()
+
+
 def test_mh_chain_with_sixty_factors_bitexact():
     """N = 60: the E-side kernel's LDS (N x 9 doubles per column, 16 columns per workgroup, + A and the zero-column flags) is above
     64 KiB and needs the attribute set at bnmf_create; the chain stays bit-exact, with excluded factors in the sweep."""
