@@ -2135,7 +2135,11 @@ static int sweep_mh(bnmf_handle* h, int row, int converged, Timer& tm) {
 // BNMF_GATE=0 / 1 forces it off / on (diagnostics).
 static bool gate_enabled(const bnmf_handle* h) {
   if (h->gate_forced >= 0) return h->gate_forced != 0;
-  return (size_t)h->cfg.K * h->cfg.G >= 250000;   // tools/gatesize.py, round 3: 45.2 / 51.1 us at K = 96, G = 2,000; 59.4 / 52.7 at G = 3,000; 107 / 92.5 at G = 10,000
+  // tools/gatesize.py (us per iteration without / with, K = 96, N = 20, recording on).  Round 3: 45.2 / 51.1 at G = 2,000; 59.4 / 52.7 at G = 3,000;
+  // 107 / 92.5 at G = 10,000 -> from 250,000 cells.  Round 5 (the sorted schedule without metric tasks, the two draw kernels' and the side
+  // kernels' chains shortened): 48.3 / 55.4 at G = 3,000; 56.4 / 58.9 at 4,000; 63.6 / 59.3 at 5,000; 72.4 / 67.0 at 7,000; 85.9 / 84.1 at
+  // 10,000 -> the crossover has moved up
+  return (size_t)h->cfg.K * h->cfg.G >= 440000;
 }
 static int sweep(bnmf_handle* h, int row, Timer& tm) {
   h->iter += 1;

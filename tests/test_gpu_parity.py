@@ -669,7 +669,7 @@ def test_fixed_rank_with_excluded_factors(prior):
 def test_merged_draw_kernel_bitexact(prior, window, gate, monkeypatch):
     """The steady-state fixed-rank sweep in its two forms: k_pdraw + k_edraw polling the hyper sweep's flags (BNMF_GATE=0), and
     the merged draw kernel behind an allocation kernel whose last lane has waited for them (BNMF_GATE=1; the default from
-    K x G = 250,000 cells on).  Same draws: P, E, Z statistics, metrics and the recorded window bit-exact against the oracle
+    K x G = 440,000 cells on).  Same draws: P, E, Z statistics, metrics and the recorded window bit-exact against the oracle
     over several bnmf_run calls (the first sweep of every call and the sweeps after a set() take the two-kernel form)."""
     import oracle as O
     from bayesnmf_amd import Engine
