@@ -458,10 +458,39 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
       bunits[dst].push_back({u.k, gl, u.f0, u.nf});
     }
   }
+  // Quads per item.  Round 5 (end): chosen per data set where no cell is large enough to be spread.  A wave alone with its task runs a quad in
+  // ~0.33 us (one dependent chain; tools/zstamps.py, tools/zsmall.py) and the waves of a SIMD share its issue at about twice that per wave
+  // and quad: with few cells per block (K = 96, G = 2,000: 13 tasks for 14 waves) the kernel WAS its largest task — 64 quads with 2-byte
+  // items, 20 of its 34 us.  Estimated per block in quad units, T = 6 for a task's thresholds: max(T + largest item, 2 (quads / 64 + T tasks)
+  // / W); the candidate with the smallest worst block wins, the larger one on a near-tie (fewer items, fewer thresholds).  Measured, device
+  // time of the kernel in us at K = 96, N = 20 with 64 / 32 / 16 / 8 / 4 quads per item: G = 250: 35.1 / 24.8 / 19.6 / 16.9 / 16.3; 1,000: 35.8 /
+  // 25.3 / 20.2 / 19.6 / 21.2; 2,000: 36.2 / 26.5 / 23.3 / 24.0 / 29.1; 4,000: 37.2 / 31.6 / 30.1 / 34.0 / 44.1; 10,000: 52.7 / 53.4 / 56.7 / 69.0 /
+  // 94.1.  The draws do not depend on it (Philox counter = cell, count index).  BNMF_ZSQMAX: tests.
+  int qsel = 0;
+  if (!spread && (long long)h->maxM <= ZS_BIG) {          // (above: the fragment index of a 4-byte item is 16 bits)
+    const int cand[5] = {64, 32, 16, 8, 4};
+    double worst[5] = {0, 0, 0, 0, 0};
+    for (int b = 0; b < nb; ++b) {
+      long Q = 0, I[5] = {0, 0, 0, 0, 0}; int maxqt = 0;
+      for (int g : bcols[b]) for (size_t k = 0; k < K; ++k) {
+        const int m = M[k + K * (size_t)g], qt = m > 0 ? (m + 3) >> 2 : 0;
+        Q += qt; maxqt = std::max(maxqt, qt);
+        for (int c = 0; c < 5; ++c) I[c] += qt ? (qt + cand[c] - 1) / cand[c] : 1;
+      }
+      for (int c = 0; c < 5; ++c) {
+        const double est = std::max(6.0 + std::min(cand[c], maxqt), 2.0 * ((double)Q / 64.0 + 6.0 * (double)((I[c] + 63) / 64)) / (double)W);
+        worst[c] = std::max(worst[c], est);
+      }
+    }
+    double best = 1e300;
+    for (int c = 0; c < 5; ++c) if (worst[c] < 0.95 * best) { best = worst[c]; qsel = cand[c]; }
+    if (const char* e = getenv("BNMF_ZSQMAX")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) qsel = v; }
+  }
   // 2-byte items where row, column-in-block and fragment index fit 7 + 6 + 3 bits (and 0xFFFF stays free for the empty lane)
-  bool it16 = K <= 127 && GBc <= 64 && (long long)h->maxM <= 8LL * 4 * ZS_QMAX16;
+  bool it16 = K <= 127 && GBc <= 64 && (long long)h->maxM <= 8LL * 4 * (qsel ? qsel : ZS_QMAX16);
   if (const char* e = getenv("BNMF_ZSIT16")) it16 = it16 && atoi(e) != 0;           // diagnostics / tests: 0 = 4-byte items
-  const int qmax = (it16 || (long long)h->maxM > 65534LL * 4 * ZS_QMAX) ? ZS_QMAX16 : ZS_QMAX;   // (4-byte items: 128 counts per fragment, 256 where a cell would need more than 65,534 of them)
+  // (large cells spread over the blocks: 4-byte items of 128 counts per fragment, 256 where a cell would need more than 65,534 of them)
+  const int qmax = qsel ? qsel : (it16 || (long long)h->maxM > 65534LL * 4 * ZS_QMAX) ? ZS_QMAX16 : ZS_QMAX;
   std::vector<ZSBlock> blocks(nb);
   std::vector<int> cols;
   std::vector<uint32_t> items;
@@ -573,8 +602,8 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   h->zs_lds = (zsort_shared_bytes((int)K, (int)N, KP, GBc, pk) + (size_t)W * zsort_wave_bytes(nblk, (int)N) + 15) & ~(size_t)15;
   h->z_sort = true;
 #ifdef ZSPROF
-  HIPCHK(dmalloc(&h->dZsProf, 8 * sizeof(unsigned long long)));
-  HIPCHK(hipMemset(h->dZsProf, 0, 8 * sizeof(unsigned long long)));
+  HIPCHK(dmalloc(&h->dZsProf, (8 + 3 * 16 * 8) * sizeof(unsigned long long)));   // section ticks, then the stamps of three blocks' waves (-DZSPROF)
+  HIPCHK(hipMemset(h->dZsProf, 0, (8 + 3 * 16 * 8) * sizeof(unsigned long long)));
 #endif
   return 0;
 }
@@ -1379,6 +1408,14 @@ int bnmf_debug_rank(bnmf_handle* h, unsigned long long* out, size_t n) {   // di
   HIPCHK(hipMemcpy(out, h->dRankDbg, n * 8, hipMemcpyDeviceToHost));
   return h->rank_grid;
 }
+#ifdef ZSPROF
+int bnmf_debug_zstamps(bnmf_handle* h, unsigned long long* out) {   // diagnostics (-DZSPROF): [3 blocks][16 waves][8] s_memrealtime stamps of the last k_zalloc_sort
+  if (!h || !h->dZsProf) return fail(BNMF_ESTATE, "not a -DZSPROF build, or the kernel is not in use");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(out, h->dZsProf + 8, 3 * 16 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return 0;
+}
+#endif
 int bnmf_debug_zsort(bnmf_handle* h, unsigned long long* out) {   // diagnostics (-DZSPROF / -DZPPROF builds): section ticks of k_zalloc_sort / k_zalloc_step, then reset
   unsigned long long* src = h ? (h->dZsProf ? h->dZsProf : h->zpg.prof) : nullptr;
   if (!src) return fail(BNMF_ESTATE, "not a -DZSPROF / -DZPPROF build, or the kernel is not in use");
@@ -1411,6 +1448,7 @@ int bnmf_get_stat(bnmf_handle* h, int what, double* out) {   // sizes of the sch
     case 1: *out = h->dZsMh ? (double)h->cfg.K * h->cfg.G * 8.0 : 0.0; return 0;            // bytes of Mhat left per iteration for the column terms
     case 2: *out = h->dZsRecRing ? 1.0 : 0.0; return 0;                                     // samples$Z kept as a ring of records
     case 3: *out = h->zs_eager ? 1.0 : 0.0; return 0;
+    case 5: *out = h->z_sort ? (double)h->zs_qmax : 0.0; return 0;                          // quads per item of the sorted schedule (chosen per data set)
     case 4: *out = h->mh_pipe ? 1.0 : 0.0; return 0;                                        // MH sweep: k_mh_tail's work hosted by the two sweep kernels
     default: return fail(BNMF_EINVAL, "bnmf_get_stat: unknown statistic %d", what);
   }
@@ -2138,8 +2176,9 @@ static bool gate_enabled(const bnmf_handle* h) {
   // tools/gatesize.py (us per iteration without / with, K = 96, N = 20, recording on).  Round 3: 45.2 / 51.1 at G = 2,000; 59.4 / 52.7 at G = 3,000;
   // 107 / 92.5 at G = 10,000 -> from 250,000 cells.  Round 5 (the sorted schedule without metric tasks, the two draw kernels' and the side
   // kernels' chains shortened): 48.3 / 55.4 at G = 3,000; 56.4 / 58.9 at 4,000; 63.6 / 59.3 at 5,000; 72.4 / 67.0 at 7,000; 85.9 / 84.1 at
-  // 10,000 -> the crossover has moved up
-  return (size_t)h->cfg.K * h->cfg.G >= 440000;
+  // 10,000 -> the crossover has moved up; with the quads per item chosen per data set (build_zsort): 45.5 / 52.9 at G = 3,000; 49.0 / 54.3 at 4,000;
+  // 59.8 / 60.6 at 5,000; 72.7 / 68.9 at 7,000; 85.6 / 83.5 at 10,000
+  return (size_t)h->cfg.K * h->cfg.G >= 550000;
 }
 static int sweep(bnmf_handle* h, int row, Timer& tm) {
   h->iter += 1;

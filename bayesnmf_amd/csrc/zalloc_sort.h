@@ -53,9 +53,12 @@ struct ZSArgs {
 #ifdef ZSPROF
 #define ZSTIC(i) const uint64_t zstic_##i = __builtin_amdgcn_s_memtime()
 #define ZSTOC(i) zsprof[i] += __builtin_amdgcn_s_memtime() - zstic_##i
+// wall-clock stamps (s_memrealtime, 100 MHz) of the waves of three blocks: prof[8 + (sel * 16 + wave) * 8 + j] (tools/zstamps.py)
+#define ZSSTAMP(j) do { if (s.prof && zs_sel >= 0 && lane == 0) s.prof[8 + (zs_sel * 16 + wave) * 8 + (j)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define ZSTIC(i)
 #define ZSTOC(i)
+#define ZSSTAMP(j)
 #endif
 // host and device agree on the LDS layout through these.  PK: zG / zK hold two factors per word (16-bit halves, as the
 // lanes' histograms do), chosen at bnmf_create when no half can overflow
@@ -101,6 +104,11 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
 #ifdef ZSPROF
   uint64_t zsprof[8] = {0, 0, 0, 0, 0, 0, 0, 1};
 #endif
+#ifdef ZSPROF
+  int zs_ntask = 0;
+  const int zs_sel = blockIdx.x == 0 ? 0 : blockIdx.x == 128 ? 1 : blockIdx.x == gridDim.x - 1 ? 2 : -1;
+#endif
+  ZSSTAMP(0);
   ZSTIC(6);
   ZSTIC(0);
   // ---------------- block set-up.  Round 5: every lane requests ALL its loads before it uses the first.  Rounds 3-4 gave the three
@@ -139,8 +147,10 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
     for (int i = tid; i < ZR * GBc; i += ZT) zK[i] = 0;
     if (tid == 0) *ticket = 0;
   }
+  ZSSTAMP(1);
   __syncthreads();
   ZSTOC(0);
+  ZSSTAMP(2);
   // The kernel is bound by instruction issue and the side streams' kernels run beside it on the same SIMDs: its waves take the issue
   // priority (timing only).  Small side launches raise theirs to 3 (kernels.h side_body): they are few and the next draw kernel waits for them.
   if (s.prio) __builtin_amdgcn_s_setprio(2);
@@ -230,6 +240,9 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
     };
     wave_lds_fence();
     ZSTOC(1);
+#ifdef ZSPROF
+    if (zs_ntask == 0) ZSSTAMP(6);
+#endif
     ZSTIC(2);
     // full quads, then each lane's last quad (the only one that can hold pads)
     if (any) for (int i = 0; __builtin_amdgcn_ballot_w64(i < nq - 1) != 0; ++i)
@@ -237,6 +250,10 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
     if (nq > 0) quad(q0 + nq - 1, 1u, npad > 2 ? 0u : 1u, npad > 1 ? 0u : 1u, npad > 0 ? 0u : 1u);
     wave_lds_fence();
     ZSTOC(2);
+#ifdef ZSPROF
+    if (zs_ntask == 0) ZSSTAMP(7);
+    ++zs_ntask;
+#endif
     ZSTIC(3);
     // flush the lane's histogram into the block's tables
     if (s.rec) {                       // save_Z: the item's record (lanes without counts write zeros: their histogram is clear)
@@ -264,9 +281,11 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
     ZSTOC(3);
     }
   }
+  ZSSTAMP(3);
   ZSTIC(5);
   __syncthreads();
   ZSTOC(5);
+  ZSSTAMP(4);
   {
   ZSTIC(0);                                               // (profile builds: the epilogue is charged to the set-up slot)
   // ---------------- block epilogue: ZsumK of the block's columns (plain stores), ZsumG (global integer atomics)
@@ -284,6 +303,7 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
   ZSTOC(0);
   }
   ZSTOC(6);
+  ZSSTAMP(5);
 #ifdef ZSPROF
   if (s.prof && lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&s.prof[i], (unsigned long long)zsprof[i]);
 #endif

@@ -166,7 +166,7 @@ int bnmf_get_iter(bnmf_handle* h, int* iter);
 /* sizes of the handle's per-iteration buffers (bench.py's byte counts): what = 0 bytes of item records written per iteration (save_Z on the
  * sorted schedule: samples$Z is kept as these records and expanded when read), 1 bytes of Mhat left for the per-column metric terms,
  * 2 whether samples$Z is a ring of records, 3 whether Z is expanded every iteration (BNMF_ZEAGER=1), 4 whether the MH sweep hosts what followed
- * its two kernels inside them (Poisson MH models at fixed rank; BNMF_MHPIPE=0: no) */
+ * its two kernels inside them (Poisson MH models at fixed rank; BNMF_MHPIPE=0: no), 5 the quads (4 counts) per item of the sorted schedule */
 int bnmf_get_stat(bnmf_handle* h, int what, double* out);
 
 /* average device time (ms) of each kernel class over n_iter iterations, measured with HIP

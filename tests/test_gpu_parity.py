@@ -669,7 +669,7 @@ def test_fixed_rank_with_excluded_factors(prior):
 def test_merged_draw_kernel_bitexact(prior, window, gate, monkeypatch):
     """The steady-state fixed-rank sweep in its two forms: k_pdraw + k_edraw polling the hyper sweep's flags (BNMF_GATE=0), and
     the merged draw kernel behind an allocation kernel whose last lane has waited for them (BNMF_GATE=1; the default from
-    K x G = 440,000 cells on).  Same draws: P, E, Z statistics, metrics and the recorded window bit-exact against the oracle
+    K x G = 550,000 cells on).  Same draws: P, E, Z statistics, metrics and the recorded window bit-exact against the oracle
     over several bnmf_run calls (the first sweep of every call and the sweeps after a set() take the two-kernel form)."""
     import oracle as O
     from bayesnmf_amd import Engine
@@ -1080,6 +1080,41 @@ def test_ablate_variable_is_not_read_by_the_product_library(monkeypatch):
         assert np.array_equal(o.get("ZsumG").astype(np.int32), e.get("ZsumG")) and e.get("ZsumG").sum() == M.sum()
         assert np.array_equal(o.get("ZsumK").astype(np.int32), e.get("ZsumK"))
         e.close()
+
+
+@pytest.mark.parametrize("save_Z", [False, True])
+def test_quads_per_item_do_not_change_the_draws(save_Z, monkeypatch):
+    """The sorted schedule cuts a cell into items of at most q quads (4 q counts); `build_zsort` picks q per data set since the end of round 5
+    (few cells per block: small items, so that a block's work spreads over its waves — DESIGN.md 5b).  The draws of a count depend on its
+    cell and its index only (R/sample_params.R:253-265 allocates each count independently given the cell's probabilities): every q gives
+    the oracle's bits — Z statistics, Z itself with save_Z, P, E, metric rows — and the default choice is one of them."""
+    import oracle as O
+    from bayesnmf_amd import Engine
+    from bayesnmf_amd.setup import synth_counts, apply_hyperprior_params
+    M, _, _ = synth_counts(96, 300, 4, 31)
+    M = np.asfortranarray(M); M[5, 7] = 3000; M[80, 250] = 777
+    N = 20
+    kw = dict(save_Z=True) if save_Z else {}
+    o = O.Oracle(M, N, prior="gamma", seed=4, nthreads=8, **kw)
+    apply_hyperprior_params(o, "gamma", M, N)
+    o.init(); mo = o.run(3)
+    names = ("ZsumK", "ZsumG", "P", "E") + (("Z",) if save_Z else ())
+    want = {nm: np.asarray(o.get(nm), dtype=np.float64) for nm in names}
+    chosen = set()
+    for q in (None, "4", "8", "16", "32", "64"):
+        if q: monkeypatch.setenv("BNMF_ZSQMAX", q)
+        else: monkeypatch.delenv("BNMF_ZSQMAX", raising=False)
+        e = Engine(M, N, prior="gamma", seed=4, **kw)
+        if q: assert e.stat(5) == float(q)
+        else: chosen.add(e.stat(5))
+        apply_hyperprior_params(e, "gamma", M, N)
+        e.init(); me = e.run(3)
+        for nm in names:
+            assert np.array_equal(want[nm], np.asarray(e.get(nm), dtype=np.float64)), (nm, q)
+        assert np.array_equal(mo[:, :9].view(np.uint64), me[:, :9].view(np.uint64)), q
+        e.close()
+    assert chosen <= {4.0, 8.0, 16.0, 32.0, 64.0} and chosen != {64.0}      # 300 columns over 256 blocks: small items
+    o.close()
 
 
 def test_large_cells_are_spread_over_the_blocks(monkeypatch):
