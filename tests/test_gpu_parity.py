@@ -510,6 +510,8 @@ def test_mh_sweep_hosting_what_followed_it_matches_the_tail_kernel(prior, monkey
         for _ in range(n):
             rows.append(o.run(1, converged=conv)[0].copy()); it += 1
             hist[it] = {nm: o.get(nm).copy() for nm in names}
+    o.run(3, converged=True); o.run(2, converged=True)            # (below: a profile pass — k_mh_tail, one kernel at a time — between hosted calls)
+    last = {nm: o.get(nm).copy() for nm in names}
     for pipe in ("1", "0"):
         monkeypatch.setenv("BNMF_MHPIPE", pipe)
         e = Engine(M, N, prior=prior, MH=True, seed=9, window=W)
@@ -526,6 +528,9 @@ def test_mh_sweep_hosting_what_followed_it_matches_the_tail_kernel(prior, monkey
                 win = e.window(nm, min(W, it))
                 for j, i2 in enumerate(range(it - min(W, it) + 1, it + 1)):
                     assert np.array_equal(win[j].view(np.uint64), hist[i2][nm].view(np.uint64)), (nm, i2, it, pipe)
+        e.profile(3, converged=True); e.run(2, converged=True)    # the two forms of the sweep alternate on one handle
+        for nm in names:
+            assert np.array_equal(last[nm].view(np.uint64), e.get(nm).view(np.uint64)), (nm, "after a profile pass", pipe)
         e.close()
     o.close()
 
