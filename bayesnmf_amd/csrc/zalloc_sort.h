@@ -77,7 +77,6 @@ BNMF_HD size_t zsort_wave_bytes(int NBLK, int N) { return (size_t)NBLK * 64 * 16
 // (128 VGPRs) a wave slot on every SIMD — at 133 VGPRs they could not start before the first workgroups here had ended
 template <int ZT, int NBLK /* threshold blocks per cell: covers N <= 5 NBLK */, bool PK>
 __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_zalloc_sort(ZSArgs s, uint32_t t, ZSGeom zg) {
-  constexpr int ZW = ZT / 64;
   constexpr int NPV = NBLK - 1;                           // pivots: threshold 5j + 4 closes block j
   constexpr int NC = 5 * NBLK;                            // factors covered
   constexpr int NMIN = NBLK == 1 ? 1 : 5 * (NBLK - 1) + 1; // smallest N routed here
@@ -85,7 +84,6 @@ __global__ __launch_bounds__(ZT) __attribute__((amdgpu_waves_per_eu(4))) void k_
   const ZArgs& d = s.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = d.K, N = d.N, KP = zg.KP, GBc = zg.GBc;
-  const int KR = (K + 63) >> 6;
   const int HW = (N + 1) >> 1;
   const int ZR = PK ? HW : N;                              // rows of zG / zK
   const ZSBlock bk = s.blocks[blockIdx.x];

@@ -10,7 +10,7 @@ M, _, _ = synth_counts(96, G, 8, 20250218)
 e = E.Engine(M, 20, prior="gamma", seed=1, window=0); apply_hyperprior_params(e, "gamma", M, 20); e.init(); e.run(50, metrics=False)
 L = E.lib(); out = (C.c_ulonglong * (3 * 16 * 8))()
 L.bnmf_debug_zstamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
-e.run(1, metrics=False)
+(e.profile(1) if os.environ.get("ZSTAMP_PROFILE") else e.run(1, metrics=False))   # ZSTAMP_PROFILE=1: the kernel alone on the device (profile mode)
 L.bnmf_debug_zstamps(e._h, out)
 v = np.array(list(out), dtype=np.float64).reshape(3, 16, 8)
 t0 = v[:, :, 0][v[:, :, 0] > 0].min()            # (stamps 6 / 7 of a wave without a task are stale: only values after t0 count)
