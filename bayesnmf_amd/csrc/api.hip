@@ -1684,6 +1684,10 @@ static void launch_side_early(bnmf_handle* h, uint32_t t) {
   hipStreamWaitEvent(h->side2, h->ev_draw, 0);
   dbg_delay(h, h->side2);
   hipLaunchKernelGGL(k_side, dim3(nbP), dim3(RT), 0, h->side2, h->dev, t, nbP, h->cfg.N, rec_at(h, t, fused_rec(h)), SideDone{});
+  // Esum of t needs E only: summed here, beside the rank sweep (end of round 5).  Behind the rank sweep — where its flag has to be raised, see
+  // launch_side_late — its 50 workgroups sat beside the allocation kernel for 121 us of a 10 us reduction, and the next k_pdraw polled for them
+  dbg_delay(h, h->side2);
+  hipLaunchKernelGGL(k_side, dim3(h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{});
   hipStreamWaitEvent(h->side, h->ev_draw, 0);
   dbg_delay(h, h->side);
   hipLaunchKernelGGL(k_side, dim3(nbE), dim3(RT), 0, h->side, h->dev, t, nbP, h->cfg.N + nbP, rec_at(h, t, fused_rec(h)), SideDone{h->dFlags, h->dFlags + 1, (unsigned)nbE, t});
@@ -1697,10 +1701,10 @@ static void launch_side_late(bnmf_handle* h, uint32_t t, Timer& tm) {
   hipLaunchKernelGGL(k_lpp, dim3(h->cfg.N), dim3(64), 0, h->side2, h->dev, t - 1);   // log-prior of the P just drawn
   dbg_delay(h, h->side2);
   hipLaunchKernelGGL(k_lpe, dim3(h->nblkE), dim3(ES_T), 0, h->side2, h->dev, t - 1, lpe_src(h, t - 1)); // ... and of the E just drawn
-  // Esum last: its flag [3] releases the next iteration's draws, which overwrite the P and E the two kernels above read
-  const int nbP = (int)(((size_t)h->cfg.K * h->cfg.N + RT - 1) / RT);
+  // Esum's flag [3] last: it releases the next iteration's draws, which overwrite the P and E the two kernels above read (the sums
+  // themselves were made by launch_side_early on this stream)
   dbg_delay(h, h->side2);
-  hipLaunchKernelGGL(k_side, dim3(h->cfg.N), dim3(RT), 0, h->side2, h->dev, t, nbP, 0, RecDst{}, SideDone{h->dFlags + 2, h->dFlags + 3, (unsigned)h->cfg.N, t});
+  hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(64), 0, h->side2, h->dFlags + 3, t);
   hipEventRecord(h->ev_sideP, h->side2);
   hipStreamWaitEvent(h->side, h->ev_sideP, 0);
   hipEventRecord(h->ev_side, h->side);

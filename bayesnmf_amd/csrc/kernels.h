@@ -243,6 +243,12 @@ __global__ __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(152))) void k_si
   side_body(d, t, nbP, blockIdx.x + blk0, gridDim.x, rec, sd, buf, threadIdx.x);   // one launch (blk0 = 0) or one launch per part
 }
 
+// publishes an epoch in a flag that side_wait polls: for results an EARLIER kernel of the same stream has stored (the stream's order and
+// the kernel boundary put them in front of the flag)
+__global__ void k_raise_flag(unsigned* flag, unsigned epoch) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- k_pdraw: one workgroup of 128 lanes per factor n ----
 // sample_Pn_poisson R/sample_Pn.R:98-120 (dispatch :11-42); Psum[n] and the log-prior of column n
 // are reduced canonically (W = 64) over k.
