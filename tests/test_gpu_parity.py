@@ -1147,7 +1147,10 @@ def test_large_cells_are_spread_over_the_blocks(monkeypatch):
         want3 = {nm: o.get(nm).copy() for nm in ("ZsumK", "ZsumG", "P", "E")}
         o.run(2)
         want5 = {nm: o.get(nm).copy() for nm in ("ZsumK", "P", "E")}
-        for spread in ("1", "0"):
+        for spread in ("1", "1 merged", "0"):
+            # ("1 merged": the merged draw kernel + gated allocation kernel, which long chains take — it zeroes the accumulated ZsumK too)
+            monkeypatch.setenv("BNMF_GATE", "1" if spread.endswith("merged") else "0")
+            spread = spread.split()[0]
             monkeypatch.setenv("BNMF_ZSSPREAD", spread)
             if spread == "0" and not spread_off_ok:
                 with pytest.raises(BnmfError, match="4,000,000"):      # every cell at home: the old limit
