@@ -548,6 +548,14 @@ static int build_zsort(bnmf_handle* h, const int32_t* M, int n_cu) {
   }
   for (int b = 0; b < nb; ++b) pk = pk && bpk[b];
   if (const char* e = getenv("BNMF_ZSPK")) pk = pk && atoi(e) != 0;                 // diagnostics / tests: 0 = one factor per word
+  // the waves per workgroup were sized for one factor per word (the block tables' larger form); with two per word the tables are half as
+  // large and, at the metric configuration, 14 waves fit where 12 did.  tools/ablong.py, sixteen processes alternating on one box: 12 waves
+  // 80.3 us per iteration in three of eight processes and 81.4-83.0 in the others (the stop-event mode of DESIGN.md 5b), 14 waves 81.3-81.6
+  // in seven of eight (80.3 in one): 82.1 against 81.3 us on average
+  if (pk && !getenv("BNMF_ZSW")) {
+    const size_t sh = zsort_shared_bytes((int)K, (int)N, KP, GBc, true), wv = zsort_wave_bytes(nblk, (int)N);
+    for (int w : {16, 14, 12, 8, 6, 4}) if (sh + (size_t)w * wv <= budget) { W = std::max(W, w); break; }
+  }
   std::vector<int32_t> Mblk(K * G);
   for (int b = 0; b < nb; ++b) {
     ZSBlock& bk = blocks[b];
